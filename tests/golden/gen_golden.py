@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by EXECUTING the reference's own hot-path code on CPU.
+
+Runs only in the build container (needs /root/reference and `transformers`); the GPU box and the test
+suite consume the committed `tests/golden/*.npz` outputs.  Nothing from the reference is copied: the
+`ClassDef`/`FunctionDef` nodes of `DrlClassifier`, `MMDStatistic`, `pdist`, `permutation_test_mat`
+(drl_classifier_ec_mmd_final_mul.py :149-600) and `HSIC` & friends (drl_classifier_ec_hsic.py :529-547)
+are AST-extracted at run time and exec'd in a namespace whose `BertModel.from_pretrained` returns a
+locally constructed `transformers.BertModel(BertConfig(...))` -- no model name is fetched.
+
+Weights are NOT stored: they are regenerated from `oracle.carel_oracle.init_params(seed)` (numpy
+RandomState, frozen stream) and loaded into the reference model with `load_state_dict`, so a fixture is
+inputs + expected outputs + seeds only (a few hundred KB).
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import carel_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def extract(path, names):
+    src = open(path, encoding="utf8").read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert {n.name for n in keep} == set(names), (names, [n.name for n in keep])
+    return ast.Module(body=keep, type_ignores=[])
+
+
+def reference_namespace(opt_ns, cfg: O.EncoderConfig):
+    import math
+    import transformers
+    from torch.autograd import Variable
+
+    def make_bert():
+        c = transformers.BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden,
+                                    num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                                    intermediate_size=cfg.intermediate, max_position_embeddings=cfg.max_pos,
+                                    type_vocab_size=cfg.type_vocab, layer_norm_eps=cfg.ln_eps,
+                                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                    hidden_act="gelu")
+        c._attn_implementation = "eager"
+        return transformers.BertModel(c)
+
+    def make_roberta():
+        c = transformers.RobertaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden,
+                                       num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                                       intermediate_size=cfg.intermediate, max_position_embeddings=cfg.max_pos,
+                                       type_vocab_size=cfg.type_vocab, layer_norm_eps=cfg.ln_eps,
+                                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                       hidden_act="gelu", pad_token_id=cfg.pad_id)
+        c._attn_implementation = "eager"
+        return transformers.RobertaModel(c)
+
+    class _Stub:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def from_pretrained(self, *a, **k):    # local construction, nothing fetched
+            return self.fn()
+
+    ns = dict(torch=torch, nn=nn, math=math, Variable=Variable, opt=opt_ns, np=np,
+              BertModel=_Stub(make_bert), RobertaModel=_Stub(make_roberta))
+    mod = extract(os.path.join(REF, "drl_classifier_ec_mmd_final_mul.py"),
+                  ["DrlClassifier", "MMDStatistic", "pdist", "permutation_test_mat"])
+    exec(compile(mod, "<reference:drl_classifier_ec_mmd_final_mul.py>", "exec"), ns)
+    return ns
+
+
+def to_opt_ns(opt: O.Opt):
+    return types.SimpleNamespace(**vars(opt))
+
+
+def build_reference_model(cfg, opt, wseed):
+    ns = reference_namespace(to_opt_ns(opt), cfg)
+    torch.manual_seed(1234)
+    model = ns["DrlClassifier"](ns["opt"])
+    P = O.init_params(cfg, opt, seed=wseed)
+    sd = model.state_dict()
+    extra = [k for k in sd if k not in P]
+    # non-parameter buffers (position_ids / token_type_ids) may exist depending on transformers version
+    assert all(("position_ids" in k) or ("token_type_ids" in k) for k in extra), extra
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    model.load_state_dict({**{k: sd[k] for k in extra}, **P})
+    return ns, model, P
+
+
+def slices(t: torch.Tensor, n=64):
+    """A deterministic sparse sample of a tensor (first n, last n, n strided)."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return torch.cat((f[:n], f[-n:], f[::step][:n])).numpy().astype(np.float32)
+
+
+SLICE_KEYS = [
+    "encoder.embeddings.word_embeddings.weight",
+    "encoder.embeddings.position_embeddings.weight",
+    "encoder.embeddings.token_type_embeddings.weight",
+    "encoder.embeddings.LayerNorm.weight",
+    "encoder.encoder.layer.0.attention.self.query.weight",
+    "encoder.encoder.layer.0.attention.self.key.bias",
+    "encoder.encoder.layer.0.attention.self.value.weight",
+    "encoder.encoder.layer.0.attention.output.dense.weight",
+    "encoder.encoder.layer.0.attention.output.LayerNorm.bias",
+    "encoder.encoder.layer.0.intermediate.dense.weight",
+    "encoder.encoder.layer.0.intermediate.dense.bias",
+    "encoder.encoder.layer.0.output.dense.weight",
+    "encoder.encoder.layer.0.output.LayerNorm.weight",
+    "encoder.encoder.layer.1.attention.self.query.weight",
+    "encoder.encoder.layer.1.output.dense.bias",
+    "encoder.pooler.dense.weight",
+    "encoder.pooler.dense.bias",
+    "emotion_mu.weight", "emotion_log_var.bias", "cause_mu.weight", "cause_log_var.weight",
+    "emotion_classifier.weight", "cause_classifier.weight", "pair_classifier.weight", "pair_classifier.bias",
+    "decoder.weight", "decoder.bias",
+]
+
+
+def run_case(name, cfg, opt, B, S, wseed, bseed, shape="A", steps=3, iteration0=3, all_negative=False,
+             grads=True):
+    ns, model, P = build_reference_model(cfg, opt, wseed)
+    batch = O.synthetic_batch(B, S, cfg, opt.pair_bow_dim, seed=bseed, shape=shape)
+    if all_negative:
+        batch["labels"].zero_()
+        batch["cau_labels"].zero_()
+    model.train()          # all dropout probabilities are 0 in these fixtures (opt.dropout=0, HF p=0)
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr)
+    rec = dict(meta=np.array([B, S, cfg.layers, cfg.vocab_size, opt.pair_bow_dim, wseed, bseed, steps,
+                              iteration0], dtype=np.int64),
+               shape=np.array(shape), variant=np.array(cfg.variant),
+               versions=np.array(f"torch={torch.__version__};transformers={__import__('transformers').__version__}"))
+    for k, v in batch.items():
+        rec["in_" + k] = v.numpy()
+    losses = []
+    for s in range(steps):
+        torch.manual_seed(1000 + s)
+        eps_e = torch.randn(opt.ec_dim)
+        eps_c = torch.randn(opt.ec_dim)
+        rec[f"eps_e_{s}"] = eps_e.numpy()
+        rec[f"eps_c_{s}"] = eps_c.numpy()
+        torch.manual_seed(1000 + s)   # the reference draws eps_e then eps_c from the global stream (:215-216)
+        loss = model(batch["input_ids"], batch["attention_masks"], batch["token_type_ids"], batch["emo_labels"],
+                     batch["cau_labels"], batch["labels"], batch["bow_reps"], iteration0 + s)
+        if s == 0:
+            # per-term / latent capture: re-run the reference's own sub-methods on the same noise
+            with torch.no_grad():
+                pooled = model.encoder(batch["input_ids"], attention_mask=batch["attention_masks"],
+                                       token_type_ids=batch["token_type_ids"]).pooler_output
+                mu_e, lv_e = model.get_emotion_emb(pooled)
+                mu_c, lv_c = model.get_cause_emb(pooled)
+                z_e = mu_e + eps_e * torch.exp(lv_e)
+                z_c = mu_c + eps_c * torch.exp(lv_c)
+                z = torch.cat((z_e, z_c), 1)
+                rec["pooled"] = pooled.numpy()
+                rec["mu_e"], rec["lv_e"], rec["mu_c"], rec["lv_c"] = (t.numpy() for t in (mu_e, lv_e, mu_c, lv_c))
+                rec["t_emo"] = model.get_emotion_mul_loss(z_e, batch["emo_labels"]).numpy()
+                rec["t_cau"] = model.get_cause_mul_loss(z_c, batch["cau_labels"]).numpy()
+                rec["t_mmd"] = ns["MMDStatistic"](B, B)(z_e, z_c, [0.1]).numpy()
+                pl = model.get_pair_mul_loss(z, batch["labels"])
+                rec["t_pair"] = np.float32(pl if isinstance(pl, int) else pl.numpy())
+                w = model.get_annealed_weight(iteration0, opt.ec_kl_lambda)
+                rec["t_kl_e"] = (w * model.get_kl_loss(mu_e, lv_e)).numpy()
+                rec["t_kl_c"] = (w * model.get_kl_loss(mu_c, lv_c)).numpy()
+                rec["t_rec"] = model.get_reconstruct_loss(nn.Softmax(dim=1)(model.decoder(z)), batch["bow_reps"]).numpy()
+        with torch.autograd.set_detect_anomaly(True):
+            optim.zero_grad()
+            loss.backward()
+            if s == 0 and grads:
+                named = dict(model.named_parameters())
+                for k in SLICE_KEYS:
+                    if k in named:
+                        g = named[k].grad
+                        rec["g_" + k] = slices(g if g is not None else torch.zeros_like(named[k]))
+                        rec["gn_" + k] = np.float32(0.0 if g is None else g.norm().item())
+            optim.step()
+        losses.append(loss.item())
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    named = dict(model.named_parameters())
+    for k in SLICE_KEYS:
+        if k in named:
+            rec["w_" + k] = slices(named[k])
+    # eval-mode predictions with fresh noise (:265-282)
+    model.eval()
+    torch.manual_seed(77)
+    rec["pred_eps_e"] = torch.randn(opt.ec_dim).numpy()
+    rec["pred_eps_c"] = torch.randn(opt.ec_dim).numpy()
+    torch.manual_seed(77)
+    with torch.no_grad():
+        preds = model.get_pair_preds(batch["input_ids"], batch["attention_masks"], batch["token_type_ids"])
+    rec["preds"] = np.array(preds, dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "losses", losses, "terms",
+          {k: float(rec[k]) for k in ("t_mmd", "t_emo", "t_cau", "t_pair", "t_kl_e", "t_kl_c", "t_rec")})
+
+
+def run_statistics():
+    cfg, opt = O.EncoderConfig(layers=1, vocab_size=100), O.Opt(pair_bow_dim=10)
+    ns = reference_namespace(to_opt_ns(opt), cfg)
+    rec = {}
+    rs = np.random.RandomState(5)
+    for tag, (n1, n2, d) in dict(a=(64, 64, 24), b=(33, 33, 24), c=(2, 2, 24), d=(512, 512, 24), e=(16, 40, 7)).items():
+        s1 = torch.from_numpy(rs.standard_normal((n1, d)).astype(np.float32) * 0.7)
+        s2 = torch.from_numpy(rs.standard_normal((n2, d)).astype(np.float32) * 1.3 + 0.2)
+        mmd, kern = ns["MMDStatistic"](n1, n2)(s1, s2, [0.1], ret_matrix=True)
+        mmd2 = ns["MMDStatistic"](n1, n2)(s1, s2, [0.1, 0.5, 2.0])
+        rec[f"{tag}_s1"], rec[f"{tag}_s2"] = s1.numpy(), s2.numpy()
+        rec[f"{tag}_mmd"], rec[f"{tag}_mmd3"] = mmd.numpy(), mmd2.numpy()
+        rec[f"{tag}_kern_slice"] = slices(kern, 32)
+        rec[f"{tag}_pdist_slice"] = slices(ns["pdist"](s1, s2), 32)
+        # gradients of -mmd wrt the samples (what training back-propagates, :233)
+        a, b = s1.clone().requires_grad_(True), s2.clone().requires_grad_(True)
+        (-ns["MMDStatistic"](n1, n2)(a, b, [0.1])).backward()
+        rec[f"{tag}_g1"], rec[f"{tag}_g2"] = a.grad.numpy(), b.grad.numpy()
+    # HSIC (ablation head, config 5)
+    hs = {}
+    mod = extract(os.path.join(REF, "drl_classifier_ec_hsic.py"), ["pairwise_distances", "GaussianKernelMatrix", "HSIC"])
+    saved = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self       # the reference hard-codes .cuda() (:545)
+    try:
+        exec(compile(mod, "<reference:drl_classifier_ec_hsic.py>", "exec"), dict(torch=torch), hs)
+        hs_ns = dict(torch=torch)
+        exec(compile(mod, "<reference:drl_classifier_ec_hsic.py>", "exec"), hs_ns)
+        for tag, m in dict(a=64, b=17).items():
+            x = torch.from_numpy(rs.standard_normal((m, 24)).astype(np.float32) * 0.5)
+            y = torch.from_numpy(rs.standard_normal((m, 24)).astype(np.float32) * 0.5)
+            rec[f"h{tag}_x"], rec[f"h{tag}_y"] = x.numpy(), y.numpy()
+            rec[f"h{tag}_hsic"] = hs_ns["HSIC"](x, y).numpy()
+    finally:
+        torch.Tensor.cuda = saved
+    np.savez_compressed(os.path.join(OUT, "statistics.npz"), **rec)
+    print("statistics", {k: float(v) for k, v in rec.items() if k.endswith(("_mmd", "_hsic"))})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    run_statistics()
+    nodrop = dict(dropout=0.0)
+    run_case("zh_small", O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=257, **nodrop),
+             B=8, S=128, wseed=11, bseed=21)
+    run_case("zh_ragged", O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=513, **nodrop),
+             B=16, S=128, wseed=12, bseed=22, shape="B", steps=2)
+    run_case("zh_allneg", O.EncoderConfig(layers=1, vocab_size=500), O.Opt(pair_bow_dim=130, **nodrop),
+             B=8, S=128, wseed=13, bseed=23, all_negative=True, steps=1)
+    run_case("zh_s64", O.EncoderConfig(layers=2, vocab_size=800), O.Opt(pair_bow_dim=300, **nodrop),
+             B=8, S=64, wseed=16, bseed=26, steps=1)
+    run_case("en_small", O.EncoderConfig(layers=2, vocab_size=1200, max_pos=514, type_vocab=1, ln_eps=1e-5,
+                                         variant="roberta", pad_id=1),
+             O.Opt(language="en", pair_bow_dim=257, **nodrop), B=8, S=128, wseed=14, bseed=24, shape="B", steps=1)
+    run_case("zh_full12", O.EncoderConfig(), O.Opt(pair_bow_dim=1000, **nodrop), B=8, S=128, wseed=15, bseed=25,
+             steps=1)
