@@ -1,0 +1,89 @@
+"""ctypes binding of libcarel_hip.so (C ABI declared in include/carel_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is
+raised -- nothing here (or anywhere in this package) routes through a CPU/eager implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcarel_hip.so")
+ABI_VERSION = 1
+
+
+class CarelError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("form", C.c_int32), ("epilogue", C.c_int32), ("splits", C.c_int32),
+                ("out_bf16", C.c_void_p), ("out2_bf16", C.c_void_p), ("out_f32", C.c_void_p),
+                ("bias", C.c_void_p), ("resid_f32", C.c_void_p), ("aux_bf16", C.c_void_p),
+                ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
+                ("drop_p", C.c_float)]
+
+
+class MmdArgs(C.Structure):
+    _fields_ = [("s1", C.c_void_p), ("s2", C.c_void_p), ("ld1", C.c_int64), ("ld2", C.c_int64),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("d", C.c_int32), ("n_alphas", C.c_int32),
+                ("alphas", C.c_float * 8), ("eps", C.c_float),
+                ("mmd_out", C.c_void_p), ("kernels_out", C.c_void_p),
+                ("grad_mmd", C.c_void_p), ("g1", C.c_void_p), ("g2", C.c_void_p)]
+
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol of the header exports
+SIGNATURES = {
+    "carel_abi_version": (C.c_int, []),
+    "carel_init": (C.c_int, [C.c_int]),
+    "carel_last_error": (C.c_char_p, []),
+    "carel_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
+    "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
+    "carel_selftest_layouts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly if it is absent or of the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CarelError(
+            "libcarel_hip.so not found at %s -- build it with `python -m carel_vae_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.carel_abi_version()
+    if v != ABI_VERSION:
+        raise CarelError("libcarel_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().carel_last_error().decode("utf8", "replace")
+        raise CarelError("%s failed (%d): %s" % (what or "carel call", rc, msg))
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """data_ptr of a tensor (or None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

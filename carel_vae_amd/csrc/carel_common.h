@@ -1,0 +1,164 @@
+// Shared device helpers for the CAREL-VAE gfx950 kernels: vector types, bf16 conversion, the
+// counter-based dropout hash (bit-identical to oracle/carel_oracle.py::_mix32), wave reductions and
+// the LDS tile images + MFMA fragment loaders used by gemm.hip / attention.hip.
+//
+// gfx950 only (wave64, MFMA 16x16x32 / 32x32x16 bf16, ds_read_b64_tr_b16, global_load_lds_dwordx4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace carel {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;   // raw bf16 bits in memory
+
+#define CAREL_LDS __attribute__((address_space(3)))
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN stays NaN
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---------------------------------------------------------------- dropout hash
+__device__ __host__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+struct Dropout {          // passed by value to kernels
+  uint32_t key;           // mix32(seed + site * 0x9E3779B9)
+  uint32_t thresh;        // keep iff hash >= thresh ; 0 => dropout disabled
+  float scale;            // 1/(1-p)
+  uint32_t idx_offset;    // added to the linear element index (DP shard offset)
+};
+__device__ __forceinline__ float dropout_mult(const Dropout& d, uint32_t idx) {
+  if (d.thresh == 0u) return 1.0f;
+  return (mix32((idx + d.idx_offset) ^ d.key) >= d.thresh) ? d.scale : 0.0f;
+}
+
+// ---------------------------------------------------------------- reductions (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024; `red` is >= 16 floats of LDS; result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// =========================================================================================
+// LDS tile images.  Both are written by global_load_lds_dwordx4 (lane-linear 1 KiB per wave
+// instruction), so the XOR swizzle is applied to the per-lane SOURCE address and again on reads.
+//
+//  ROW image  ("K-contiguous"):  [rows][64 bf16]   128-B rows, 8 chunks of 16 B per row.
+//      physical chunk = chunk ^ (row & 7)          -> ds_read_b128 fragment reads conflict-free
+//  COL image  ("K-strided", read with ds_read_b64_tr_b16): [64 k-rows][128 bf16]  256-B rows,
+//      16 chunks per row.  physical chunk = chunk ^ swz_col(krow)
+// =========================================================================================
+__device__ __forceinline__ int swz_col(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
+
+// byte offset inside a ROW image of (row, 16-B chunk)
+__device__ __forceinline__ int row_img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// byte offset inside a COL image of (krow, 16-B chunk)
+__device__ __forceinline__ int col_img_off(int krow, int chunk) { return krow * 256 + ((chunk ^ swz_col(krow)) << 4); }
+
+// Issue the glds loads that fill a ROW image tile of `ROWS` rows x 64 bf16 from a row-major global
+// matrix (leading dimension ld elements), starting at element (row0, k0).  256 threads.
+template <int ROWS>
+__device__ __forceinline__ void stage_row_image(const bf16_t* __restrict__ g, long ld, long row0, long k0,
+                                                char* lds_tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NINSTR = ROWS / 8;            // 1 KiB pieces (8 rows each)
+#pragma unroll
+  for (int i = 0; i < NINSTR / 4; ++i) {
+    const int q = wave * (NINSTR / 4) + i;
+    const int r = q * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const bf16_t* src = g + (row0 + r) * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds(src, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
+  }
+}
+// COL image: 64 k-rows x 128 columns, global matrix is [k][x] row-major.
+__device__ __forceinline__ void stage_col_image(const bf16_t* __restrict__ g, long ld, long krow0, long x0,
+                                                char* lds_tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave * 4 + i;               // 16 pieces of 4 k-rows
+    const int r = q * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ swz_col(r);
+    const bf16_t* src = g + (krow0 + r) * ld + x0 + c * 8;
+    __builtin_amdgcn_global_load_lds(src, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
+  }
+}
+
+// ---- 16x16x32 fragments: lane l holds X[row = x0 + (l&15)][k = k0 + 8*(l>>4) + j], j = 0..7 ----
+// from a ROW image (k0 multiple of 8 within the 64-wide tile)
+__device__ __forceinline__ bf16x8 frag16_row(const char* tile, int x0, int k0) {
+  const int l = threadIdx.x & 63;
+  const int row = x0 + (l & 15), chunk = (k0 >> 3) + (l >> 4);
+  return *(const bf16x8*)(tile + row_img_off(row, chunk));
+}
+// from a COL image: two transposed reads of 4 k-rows x 16 columns per 16-lane group
+__device__ __forceinline__ bf16x8 frag16_col(const char* tile, int x0, int k0) {
+  const int l = threadIdx.x & 63;
+  const int g = l >> 4, q = (l & 15) >> 2, p = l & 3;
+  const int chunk = (x0 >> 3) + (p >> 1), sub = (p & 1) * 8;
+  const int r0 = k0 + 8 * g + q, r1 = r0 + 4;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(tile + col_img_off(r0, chunk) + sub));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(tile + col_img_off(r1, chunk) + sub));
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 32x32 accumulator: register r (0..15) of lane l is element [row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+__device__ __forceinline__ int acc32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+}  // namespace carel

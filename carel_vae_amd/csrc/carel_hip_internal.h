@@ -1,0 +1,28 @@
+// Internal host-side helpers shared by the translation units of libcarel_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/carel_hip.h"
+#include "carel_common.h"
+
+namespace carel {
+
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+inline Dropout make_dropout(uint32_t seed, uint32_t site, float p, uint32_t idx_offset) {
+  Dropout d;
+  d.key = mix32(seed + site * 0x9E3779B9u);
+  d.idx_offset = idx_offset;
+  if (p <= 0.f) { d.thresh = 0u; d.scale = 1.f; }
+  else if (p >= 1.f) { d.thresh = 0xFFFFFFFFu; d.scale = 0.f; }
+  else {
+    d.thresh = (uint32_t)((double)p * 4294967296.0);
+    d.scale = (float)(1.0 / (1.0 - (double)p));
+    if (d.thresh == 0u) d.scale = 1.f;
+  }
+  return d;
+}
+
+}  // namespace carel

@@ -1,0 +1,104 @@
+"""bf16 MFMA GEMM (forward / dgrad / wgrad forms, every epilogue) against fp64 matmul of the same
+bf16-rounded operands.  Tolerance: fp32 accumulation-order noise only (1e-5 relative, written below)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from carel_vae_amd import _lib as L
+from oracle import carel_oracle as O
+from tests.gpu_util import gemm, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5       # fp32 accumulate vs fp64 reference on identical bf16 inputs
+TOL_BF16 = 6e-3  # outputs stored as bf16 (2^-8 half-ulp relative)
+
+
+def _rand(shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (1024, 768, 768), (512, 2304, 768), (256, 768, 3072)])
+def test_forward_nt_bias_bf16(M, N, K):
+    A, W, b = _rand((M, K), 1, 1).bfloat16(), _rand((N, K), 0.05, 2).bfloat16(), _rand((N,), 0.1, 3)
+    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_BF16, M, N, K, out_bf16=out, bias=b)
+    ref = A.double() @ W.double().t() + b.double()
+    assert rel_err(out, ref) < TOL_BF16
+    # exactness of the fp32 accumulator itself: f32 output path
+    outf = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    gemm(A, W, L.GEMM_NT, L.EPI_ADD_F32, M, N, K, out_f32=outf)
+    assert rel_err(outf, A.double() @ W.double().t()) < TOL
+
+
+def test_forward_gelu_epilogue():
+    M, N, K = 256, 3072, 768
+    A, W, b = _rand((M, K), 1, 4).bfloat16(), _rand((N, K), 0.05, 5).bfloat16(), _rand((N,), 0.1, 6)
+    u = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    g = torch.empty_like(u)
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out_bf16=u, out2_bf16=g, bias=b)
+    ref_u = (A.double() @ W.double().t() + b.double())
+    assert rel_err(u, ref_u) < TOL_BF16
+    uu = u.double()
+    ref_g = 0.5 * uu * (1 + torch.erf(uu / math.sqrt(2)))
+    assert rel_err(g, ref_g) < TOL_BF16
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_forward_dropout_residual_epilogue(p):
+    M, N, K = 256, 768, 768
+    A, W, b = _rand((M, K), 1, 7).bfloat16(), _rand((N, K), 0.05, 8).bfloat16(), _rand((N,), 0.1, 9)
+    r = _rand((M, N), 1, 10)
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    seed, site, off = 1234, O.site_attn_out(2), 5 * N
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=out, bias=b, resid=r, drop=(seed, site, off, p))
+    y = (A.double() @ W.double().t() + b.double())
+    if p > 0:
+        idx = (np.arange(M * N, dtype=np.uint64) + np.uint64(off)).astype(np.uint32)
+        keep = O.dropout_keep(seed, site, idx, p).reshape(M, N)
+        y = y * torch.from_numpy(keep.astype(np.float64) / (1 - p)).cuda()
+        assert abs(keep.mean() - (1 - p)) < 0.01
+    assert rel_err(out, y + r.double()) < TOL
+
+
+def test_dgrad_nn_forms():
+    M, Nout, Nin = 384, 3072, 768            # dX[M,Nin] = dY[M,Nout] @ W[Nout,Nin]
+    dY, W = _rand((M, Nout), 1, 11).bfloat16(), _rand((Nout, Nin), 0.05, 12).bfloat16()
+    r = _rand((M, Nin), 1, 13)
+    out = torch.empty((M, Nin), device="cuda", dtype=torch.float32)
+    gemm(dY, W, L.GEMM_NN, L.EPI_ADD_F32, M, Nin, Nout, out_f32=out, resid=r)
+    assert rel_err(out, dY.double() @ W.double() + r.double()) < TOL
+    ob = torch.empty((M, Nin), device="cuda", dtype=torch.bfloat16)
+    gemm(dY, W, L.GEMM_NN, L.EPI_BIAS_BF16, M, Nin, Nout, out_bf16=ob)
+    assert rel_err(ob, dY.double() @ W.double()) < TOL_BF16
+    # dgrad through GELU: du = (dy @ W2) * gelu'(u)      W2 is [768, 3072]
+    dy2, W2 = _rand((M, 768), 1, 14).bfloat16(), _rand((768, 3072), 0.05, 15).bfloat16()
+    u = _rand((M, 3072), 1.5, 16).bfloat16()
+    du = torch.empty((M, 3072), device="cuda", dtype=torch.bfloat16)
+    gemm(dy2, W2, L.GEMM_NN, L.EPI_DGELU_BF16, M, 3072, 768, out_bf16=du, aux=u)
+    uu = u.double()
+    gp = 0.5 * (1 + torch.erf(uu / math.sqrt(2))) + uu * torch.exp(-0.5 * uu * uu) / math.sqrt(2 * math.pi)
+    assert rel_err(du, (dy2.double() @ W2.double()) * gp) < TOL_BF16
+
+
+@pytest.mark.parametrize("T,Nout,Nin,splits", [(1024, 768, 768, 8), (2048, 2304, 768, 4), (512, 128, 3072, 1)])
+def test_wgrad_tn_split_k(T, Nout, Nin, splits):
+    dY, X = _rand((T, Nout), 1, 17).bfloat16(), _rand((T, Nin), 1, 18).bfloat16()
+    slabs = torch.empty((splits, Nout, Nin), device="cuda", dtype=torch.float32)
+    gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, Nout, Nin, T, splits=splits, out_f32=slabs)
+    dW = torch.full((Nout, Nin), 7.0, device="cuda", dtype=torch.float32)
+    lib = L.load()
+    L.check(lib.carel_slab_reduce_f32(slabs.data_ptr(), dW.data_ptr(), Nout * Nin, splits, 0, L.current_stream()))
+    ref = dY.double().t() @ X.double()
+    assert rel_err(dW, ref) < TOL
+    L.check(lib.carel_slab_reduce_f32(slabs.data_ptr(), dW.data_ptr(), Nout * Nin, splits, 1, L.current_stream()))
+    assert rel_err(dW, 2 * ref) < TOL
+
+
+def test_bad_shapes_are_refused():
+    A = torch.zeros((100, 64), device="cuda", dtype=torch.bfloat16)
+    out = torch.empty((100, 128), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(L.CarelError):
+        gemm(A, A, L.GEMM_NT, L.EPI_BIAS_BF16, 100, 128, 64, out_bf16=out)

@@ -1,0 +1,68 @@
+"""RBF-MMD operator (MMDStatistic/pdist, ref :537-596) through the C ABI vs. golden vectors + oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from carel_vae_amd import _lib as L
+from oracle import carel_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run_mmd(s1, s2, alphas, ret_matrix=False, grad=None):
+    n1, n2, d = s1.shape[0], s2.shape[0], s1.shape[1]
+    a = L.MmdArgs()
+    a.s1, a.s2, a.ld1, a.ld2 = s1.data_ptr(), s2.data_ptr(), s1.stride(0), s2.stride(0)
+    a.n1, a.n2, a.d, a.n_alphas, a.eps = n1, n2, d, len(alphas), 1e-5
+    for i, v in enumerate(alphas):
+        a.alphas[i] = v
+    out = torch.zeros(1, device="cuda")
+    kern = torch.zeros((n1 + n2, n1 + n2), device="cuda") if ret_matrix else None
+    a.mmd_out = out.data_ptr()
+    a.kernels_out = None if kern is None else kern.data_ptr()
+    lib = L.load()
+    L.check(lib.carel_rbf_mmd_fwd(C.byref(a), L.current_stream()), "mmd fwd")
+    g1 = g2 = None
+    if grad is not None:
+        g = torch.tensor([grad], device="cuda", dtype=torch.float32)
+        g1, g2 = torch.zeros((n1, d), device="cuda"), torch.zeros((n2, d), device="cuda")
+        a.grad_mmd, a.g1, a.g2 = g.data_ptr(), g1.data_ptr(), g2.data_ptr()
+        L.check(lib.carel_rbf_mmd_bwd(C.byref(a), L.current_stream()), "mmd bwd")
+    torch.cuda.synchronize()
+    return out.item(), kern, g1, g2
+
+
+def test_mmd_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "statistics.npz"), allow_pickle=False)
+    for tag in "abcde":
+        s1, s2 = torch.from_numpy(z[f"{tag}_s1"]).cuda(), torch.from_numpy(z[f"{tag}_s2"]).cuda()
+        mmd, kern, g1, g2 = run_mmd(s1, s2, [0.1], ret_matrix=True, grad=-1.0)
+        np.testing.assert_allclose(mmd, float(z[f"{tag}_mmd"]), rtol=2e-5, atol=2e-7)
+        _, kref = O.mmd_statistic(s1.cpu(), s2.cpu(), [0.1], ret_matrix=True)
+        np.testing.assert_allclose(kern.cpu().numpy(), kref.numpy(), rtol=1e-5, atol=1e-6)
+        # gradient of -mmd (what the training loss back-propagates, ref :233)
+        scale = np.abs(z[f"{tag}_g1"]).max()
+        np.testing.assert_allclose(g1.cpu().numpy(), z[f"{tag}_g1"], rtol=2e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(g2.cpu().numpy(), z[f"{tag}_g2"], rtol=2e-4, atol=2e-5 * scale)
+        mmd3, _, _, _ = run_mmd(s1, s2, [0.1, 0.5, 2.0])
+        np.testing.assert_allclose(mmd3, float(z[f"{tag}_mmd3"]), rtol=2e-5, atol=2e-7)
+
+
+def test_mmd_properties_and_errors():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((64, 24), generator=g).cuda()
+    # identical samples: cross and within kernels agree up to the diagonal treatment -> small value
+    m_same, _, _, _ = run_mmd(x, x.clone(), [0.1])
+    y = (torch.randn((64, 24), generator=g) * 3 + 2).cuda()
+    m_far, _, _, _ = run_mmd(x, y, [0.1])
+    assert m_far > m_same
+    # strided views (columns of a wider matrix) are accepted via ld
+    wide = torch.randn((64, 48), generator=g).cuda()
+    m1, _, _, _ = run_mmd(wide[:, :24], wide[:, 24:], [0.1])
+    m2, _, _, _ = run_mmd(wide[:, :24].contiguous(), wide[:, 24:].contiguous(), [0.1])
+    assert m1 == m2
+    with pytest.raises(L.CarelError):
+        run_mmd(x[:1], x[:1], [0.1])      # n = 1 divides by zero in the reference
