@@ -34,6 +34,25 @@ class MmdArgs(C.Structure):
                 ("grad_mmd", C.c_void_p), ("g1", C.c_void_p), ("g2", C.c_void_p)]
 
 
+class EmbedArgs(C.Structure):
+    _fields_ = [("input_ids", C.c_void_p), ("token_type_ids", C.c_void_p),
+                ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("batch", C.c_int32), ("seq_len", C.c_int32), ("hidden", C.c_int32),
+                ("vocab_size", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
+                ("roberta", C.c_int32), ("pad_id", C.c_int32),
+                ("drop_seed", C.c_uint32), ("drop_idx_offset", C.c_uint32), ("drop_p", C.c_float),
+                ("x_f32", C.c_void_p), ("x_bf16", C.c_void_p), ("stats", C.c_void_p)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("attention_mask", C.c_void_p), ("ctx", C.c_void_p), ("lse", C.c_void_p),
+                ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
+                ("batch", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+                ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
+                ("drop_p", C.c_float)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
 
@@ -47,6 +66,18 @@ SIGNATURES = {
     "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_selftest_layouts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
+    "carel_embed_ln_bwd_blocks": (C.c_int, [C.c_int64]),
+    "carel_embed_ln_bwd": (C.c_int, [C.POINTER(EmbedArgs)] + [C.c_void_p] * 8),
+    "carel_layernorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_layernorm_bwd_blocks": (C.c_int, [C.c_int64]),
+    "carel_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_float] + [C.c_void_p] * 7),
+    "carel_colsum_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_void_p]),
+    "carel_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "carel_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
 }
 
 _lib = None

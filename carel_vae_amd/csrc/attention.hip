@@ -1,0 +1,358 @@
+// Self-attention forward / backward for one (sample, head) per workgroup, S <= 128, head_dim = 64.
+// Replaces transformers BertSelfAttention (eager_attention_forward: QK^T * scale + additive key mask ->
+// softmax -> dropout -> P V) and its autograd backward; reached from
+// drl_classifier_ec_mmd_final_mul.py:202-206 / :841.
+//
+// qkv is the fused projection output [T, 3*768] bf16 (q | k | v), head h at columns h*64.
+// Forward  : per wave 32 queries.  S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with the KEY on the accumulator
+//            row (registers) and the QUERY on the lane, so softmax over keys is in-lane + one half swap,
+//            and the probability tile is directly the B operand of O^T = V^T P^T (no LDS round trip).
+// Backward : per wave 32 keys (key on the lane).  S and dP accumulators are directly the B operands of
+//            dV^T = dO^T P and dK^T = Q^T dS; dS^T crosses LDS once for dQ^T = K^T dS^T.
+// K/V/Q/dO tiles are LDS images with 128-B rows filled by global_load_lds_dwordx4; the XOR swizzle
+// f_att serves both the row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16).
+#include "carel_hip_internal.h"
+
+namespace carel {
+
+constexpr int HD = 64;        // head dim
+constexpr int NH = 12;        // heads
+constexpr int HID = NH * HD;  // 768
+constexpr int QKV_LD = 3 * HID;
+
+__device__ __forceinline__ int f_att(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int att_off(int row, int chunk) { return row * 128 + ((chunk ^ f_att(row)) << 4); }
+
+// fill an image of `rows` x 64 bf16 from a row-major global matrix (row stride ld elements); 256 threads
+__device__ __forceinline__ void stage_att(const bf16_t* __restrict__ g, long ld, int rows, char* img) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = wave; q < (rows >> 3); q += 4) {
+    const int r = q * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ f_att(r);
+    __builtin_amdgcn_global_load_lds(g + (long)r * ld + c * 8, (CAREL_LDS void*)(img + q * 1024), 16, 0, 0);
+  }
+}
+
+// 32x32x16 operand whose own-matrix row is on the lane: X[row = r0 + (l&31)][kk = 16*s + 8*(l>>5) + j]
+__device__ __forceinline__ bf16x8 frag32_row(const char* img, int r0, int s) {
+  const int l = threadIdx.x & 63;
+  return *(const bf16x8*)(img + att_off(r0 + (l & 31), 2 * s + (l >> 5)));
+}
+// 32x32x16 operand read TRANSPOSED from an image M[kk][x]: lane holds M[kk(j)][x = x0 + (l&31)].
+//   PERM = false: kk(j) = kb + 8*(l>>5) + j                      (natural order)
+//   PERM = true : kk(j) = kb + 8*(j>>2) + 4*(l>>5) + (j&3)        (pairs with an accumulator tile used as
+//                                                                  the other operand, carel_common.h)
+template <bool PERM>
+__device__ __forceinline__ bf16x8 frag32_tr(const char* img, int x0, int kb) {
+  const int l = threadIdx.x & 63;
+  const int g = l >> 4, hh = g >> 1, qq = (l & 15) >> 2, p = l & 3;
+  const int chunk = ((x0 + 16 * (g & 1)) >> 3) + (p >> 1), sub = (p & 1) * 8;
+  const int r0 = PERM ? (kb + 4 * hh + qq) : (kb + 8 * hh + qq);
+  const int r1 = PERM ? (r0 + 8) : (r0 + 4);
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(img + att_off(r0, chunk) + sub));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(img + att_off(r1, chunk) + sub));
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator as the bf16 B operand of k-step s (rows of the tile = kk)
+__device__ __forceinline__ bf16x8 acc_as_operand(const f32x16& x, int s) {
+  s16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(x[8 * s + j]);
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ bf16x8 load_frag_global(const bf16_t* p) { return *(const bf16x8*)p; }
+
+struct AttnParams {
+  const bf16_t* qkv;        // [B*S, 2304]
+  const long* att_mask;     // [B, S] (1 = attend) or null
+  bf16_t* ctx;              // fwd out / bwd in  [B*S, 768]
+  float* lse;               // [B, NH, S]
+  const bf16_t* dctx;       // bwd in   [B*S, 768]
+  bf16_t* dqkv;             // bwd out  [B*S, 2304]
+  int B, S;
+  Dropout drop;             // element index ((b*NH + h)*S + q)*S + k
+};
+
+constexpr float MASK_NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, as HF adds it
+constexpr int ATTN_BWD_LDS = 16384 + 16384 + 32768 + 1024;
+
+// =========================================================================================== forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 512];
+  char* kimg = smem;
+  char* vimg = smem + 16384;
+  float* maskadd = (float*)(smem + 32768);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
+  const int S = p.S, nkt = S >> 5;
+  const long row0 = (long)b * S;
+  const bf16_t* qbase = p.qkv + row0 * QKV_LD + h * HD;
+  stage_att(qbase + HID, QKV_LD, S, kimg);
+  stage_att(qbase + 2 * HID, QKV_LD, S, vimg);
+  for (int k = threadIdx.x; k < S; k += 256)
+    maskadd[k] = (p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave >= nkt) return;                       // no barrier below this point
+  const int q0 = wave * 32;
+  const int hh = lane >> 5;
+  // Q fragments (B operand of S^T = K Q^T): Q[q0 + (l&31)][16s + 8hh + j]
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = load_frag_global(qbase + (long)(q0 + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
+
+  f32x16 x[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[kt][r] = 0.f;
+    if (kt < nkt) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) x[kt] = mfma32(frag32_row(kimg, kt * 32, s), qf[s], x[kt]);
+    }
+  }
+  // softmax over keys: this lane holds, for query q0+(l&31), keys kt*32 + acc32_row(r, lane)
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt < nkt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = x[kt][r] * 0.125f + maskadd[kt * 32 + acc32_row(r, lane)];
+        x[kt][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float lsum = 0.f;
+  const uint32_t ebase = (uint32_t)((((long)b * NH + h) * S + (q0 + (lane & 31))) * S);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt < nkt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(x[kt][r] - m);
+        lsum += e;
+        x[kt][r] = e * dropout_mult(p.drop, ebase + kt * 32 + acc32_row(r, lane));
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (hh == 0) p.lse[((long)b * NH + h) * S + q0 + (lane & 31)] = m + __logf(lsum);
+  const float inv = 1.0f / lsum;
+  // O^T[d][q] = sum_k V^T[d][k] P^T[k][q]
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt < nkt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_as_operand(x[kt], s);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag32_tr<true>(vimg, dt * 32, kt * 32 + 16 * s), pf, o[dt]);
+      }
+    }
+  }
+  bf16_t* crow = p.ctx + (row0 + q0 + (lane & 31)) * HID + h * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = dt * 32 + 8 * i + 4 * hh;
+      uint2 v = {pack2bf(o[dt][4 * i] * inv, o[dt][4 * i + 1] * inv), pack2bf(o[dt][4 * i + 2] * inv, o[dt][4 * i + 3] * inv)};
+      *(uint2*)(crow + d) = v;
+    }
+}
+
+// =========================================================================================== backward
+__device__ __forceinline__ int swz_ds(int k) { return ((k & 3) << 3) | ((k >> 2) & 7); }
+__device__ __forceinline__ int ds_off(int k, int q) { return k * 256 + ((((q >> 2) ^ swz_ds(k)) & 31) << 3) + (q & 3) * 2; }
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ATTN_BWD_LDS bytes
+  char* qimg = smem;                 // Q  [S][64]
+  char* doimg = smem + 16384;        // dO [S][64]; re-used for K in the dQ phase
+  char* dsimg = smem + 32768;        // dS^T [k][q] bf16, 256-B rows
+  float* lse = (float*)(smem + 65536);
+  float* delta = lse + 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
+  const int S = p.S, nt = S >> 5;
+  const long row0 = (long)b * S;
+  const bf16_t* qbase = p.qkv + row0 * QKV_LD + h * HD;
+  const bf16_t* dobase = p.dctx + row0 * HID + h * HD;
+  const bf16_t* obase = p.ctx + row0 * HID + h * HD;
+  stage_att(qbase, QKV_LD, S, qimg);
+  stage_att(dobase, HID, S, doimg);
+  for (int k = threadIdx.x; k < S; k += 256) lse[k] = p.lse[((long)b * NH + h) * S + k];
+  {  // delta[q] = sum_d dO[q][d] * O[q][d]; 2 threads per query, 32 d each
+    const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+    float s = 0.f;
+    if (q < S) {
+      const uint4* a = (const uint4*)(dobase + (long)q * HID + half * 32);
+      const uint4* c = (const uint4*)(obase + (long)q * HID + half * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 u = a[i], v = c[i];
+        s += bf2f((bf16_t)(u.x & 0xffff)) * bf2f((bf16_t)(v.x & 0xffff)) + bf2f((bf16_t)(u.x >> 16)) * bf2f((bf16_t)(v.x >> 16));
+        s += bf2f((bf16_t)(u.y & 0xffff)) * bf2f((bf16_t)(v.y & 0xffff)) + bf2f((bf16_t)(u.y >> 16)) * bf2f((bf16_t)(v.y >> 16));
+        s += bf2f((bf16_t)(u.z & 0xffff)) * bf2f((bf16_t)(v.z & 0xffff)) + bf2f((bf16_t)(u.z >> 16)) * bf2f((bf16_t)(v.z >> 16));
+        s += bf2f((bf16_t)(u.w & 0xffff)) * bf2f((bf16_t)(v.w & 0xffff)) + bf2f((bf16_t)(u.w >> 16)) * bf2f((bf16_t)(v.w >> 16));
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    if (q < S && half == 0) delta[q] = s;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int hh = lane >> 5;
+  const int kw = wave * 32;                 // this wave's keys
+  const bool active = wave < nt;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  if (active) {
+    // K, V rows of this wave's keys as B operands: X[key = kw + (l&31)][16s + 8hh + j]
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = load_frag_global(qbase + HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
+      vf[s] = load_frag_global(qbase + 2 * HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
+    }
+    const int key = kw + (lane & 31);
+    const float madd = (p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f;
+    for (int qt = 0; qt < nt; ++qt) {
+      f32x16 sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sa = mfma32(frag32_row(qimg, qt * 32, s), kf[s], sa);     // S[q][k]
+        dp = mfma32(frag32_row(doimg, qt * 32, s), vf[s], dp);    // dP[q][k]
+      }
+      f32x16 pd, dsv;                                             // dropped probabilities, dS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qt * 32 + acc32_row(r, lane);
+        const float pr = __expf(sa[r] * 0.125f + madd - lse[q]);
+        const float dm = dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
+        pd[r] = pr * dm;
+        dsv[r] = pr * (dp[r] * dm - delta[q]) * 0.125f;            // includes the 1/sqrt(d) of the scores
+      }
+      // dS^T[k][q] -> LDS (4 consecutive q per register group)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = qt * 32 + 8 * i + 4 * hh;
+        uint2 v = {pack2bf(dsv[4 * i], dsv[4 * i + 1]), pack2bf(dsv[4 * i + 2], dsv[4 * i + 3])};
+        *(uint2*)(dsimg + ds_off(key, q)) = v;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_as_operand(pd, s), df = acc_as_operand(dsv, s);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = mfma32(frag32_tr<true>(doimg, dt * 32, qt * 32 + 16 * s), pf, dv[dt]);   // dV^T[d][k]
+          dk[dt] = mfma32(frag32_tr<true>(qimg, dt * 32, qt * 32 + 16 * s), df, dk[dt]);    // dK^T[d][k]
+        }
+      }
+    }
+    bf16_t* out = p.dqkv + (row0 + key) * QKV_LD + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = dt * 32 + 8 * i + 4 * hh;
+        uint2 a = {pack2bf(dk[dt][4 * i], dk[dt][4 * i + 1]), pack2bf(dk[dt][4 * i + 2], dk[dt][4 * i + 3])};
+        uint2 c = {pack2bf(dv[dt][4 * i], dv[dt][4 * i + 1]), pack2bf(dv[dt][4 * i + 2], dv[dt][4 * i + 3])};
+        *(uint2*)(out + HID + d) = a;
+        *(uint2*)(out + 2 * HID + d) = c;
+      }
+  }
+  __syncthreads();                           // every wave: dO image dead, dS^T complete
+  stage_att(qbase + HID, QKV_LD, S, doimg);  // K image for the dQ phase
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!active) return;
+  // dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]   for this wave's 32 queries q = kw + ..
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  {
+    const int g = lane >> 4, g1 = g & 1, h2 = g >> 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    for (int ks = 0; ks < (S >> 4); ++ks) {
+      // B operand: dS^T[k = 16ks + 8*h2 + j][q = kw + (l&31)] via transposed reads of the dS^T image
+      const int kr0 = 16 * ks + 8 * h2 + qq, kr1 = kr0 + 4;
+      const int qcol = kw + 16 * g1 + 4 * pp;
+      s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(dsimg + ds_off(kr0, qcol)));
+      s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(dsimg + ds_off(kr1, qcol)));
+      s16x8 bb = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, bb);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(frag32_tr<false>(doimg, dt * 32, 16 * ks), bf, dq[dt]);
+    }
+  }
+  bf16_t* out = p.dqkv + (row0 + kw + (lane & 31)) * QKV_LD + h * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = dt * 32 + 8 * i + 4 * hh;
+      uint2 a = {pack2bf(dq[dt][4 * i], dq[dt][4 * i + 1]), pack2bf(dq[dt][4 * i + 2], dq[dt][4 * i + 3])};
+      *(uint2*)(out + d) = a;
+    }
+}
+
+}  // namespace carel
+
+using namespace carel;
+
+static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who, bool bwd) {
+  if (!a) return set_error(CAREL_ERR_ARG, "%s: null args", who);
+  if (a->heads != NH || a->head_dim != HD) return set_error(CAREL_ERR_SHAPE, "%s: heads/head_dim must be %d/%d", who, NH, HD);
+  if (a->seq_len < 32 || a->seq_len > 128 || (a->seq_len & 31)) return set_error(CAREL_ERR_SHAPE, "%s: seq_len must be 32, 64, 96 or 128 (got %d)", who, a->seq_len);
+  if (a->batch <= 0) return set_error(CAREL_ERR_SHAPE, "%s: batch must be positive", who);
+  if (!a->qkv || !a->ctx || !a->lse) return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  if (bwd && (!a->dctx || !a->dqkv)) return set_error(CAREL_ERR_ARG, "%s: null gradient tensor", who);
+  p->qkv = (const bf16_t*)a->qkv; p->att_mask = (const long*)a->attention_mask; p->ctx = (bf16_t*)a->ctx;
+  p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
+  p->B = a->batch; p->S = a->seq_len;
+  p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
+  return CAREL_OK;
+}
+
+extern "C" int carel_attention_fwd(const carel_attn_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnParams p;
+  int rc = attn_prepare(a, &p, "carel_attention_fwd", false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.B * NH), dim3(256), 0, stream, p);
+  return check_launch("attn_fwd_kernel");
+}
+
+extern "C" int carel_attention_bwd(const carel_attn_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnParams p;
+  int rc = attn_prepare(a, &p, "carel_attention_bwd", true);
+  if (rc) return rc;
+  static bool attr_set = false;     // idempotent; a benign race sets it twice
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.B * NH), dim3(256), ATTN_BWD_LDS, stream, p);
+  return check_launch("attn_bwd_kernel");
+}

@@ -1,0 +1,447 @@
+// Row-wise kernels of the encoder: embeddings + LayerNorm (HF BertEmbeddings / RobertaEmbeddings),
+// sub-layer LayerNorm forward/backward (BertSelfOutput.LayerNorm, BertOutput.LayerNorm) with the
+// sub-layer dropout's backward fused in, embedding backward (scatter-add), and column sums (bias grads).
+// All are HBM-bound: one wave per 768-wide row, 16-byte accesses, 1 KiB per wave instruction.
+// Reached from drl_classifier_ec_mmd_final_mul.py:202-206 (forward) and :841 (backward).
+#include "carel_hip_internal.h"
+
+namespace carel {
+
+constexpr int H = 768;          // hidden size (bert_dim, ref :40)
+constexpr int NV = H / 256;     // float4 chunks per lane
+
+struct Row { float4 v[NV]; };
+
+__device__ __forceinline__ Row load_row(const float* __restrict__ p, int lane) {
+  Row r;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r.v[i] = *(const float4*)(p + (i * 64 + lane) * 4);
+  return r;
+}
+__device__ __forceinline__ void store_row(float* __restrict__ p, int lane, const Row& r) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) *(float4*)(p + (i * 64 + lane) * 4) = r.v[i];
+}
+__device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ p, int lane, const Row& r) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    uint2 o = {pack2bf(r.v[i].x, r.v[i].y), pack2bf(r.v[i].z, r.v[i].w)};
+    *(uint2*)(p + (i * 64 + lane) * 4) = o;
+  }
+}
+__device__ __forceinline__ float row_sum(const Row& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+  return wave_sum(s);
+}
+#define ROW_FOREACH(expr)                                             \
+  _Pragma("unroll") for (int i = 0; i < NV; ++i) {                    \
+    { float& a = A.v[i].x; const float b = B.v[i].x; const float c = Cc.v[i].x; const int e = 0; expr; } \
+    { float& a = A.v[i].y; const float b = B.v[i].y; const float c = Cc.v[i].y; const int e = 1; expr; } \
+    { float& a = A.v[i].z; const float b = B.v[i].z; const float c = Cc.v[i].z; const int e = 2; expr; } \
+    { float& a = A.v[i].w; const float b = B.v[i].w; const float c = Cc.v[i].w; const int e = 3; expr; } \
+  }
+
+// normalise X in place given gamma/beta rows; returns mean, rstd
+__device__ __forceinline__ void ln_normalise(Row& X, const Row& G, const Row& Bt, float eps, float& mean, float& rstd) {
+  mean = row_sum(X) * (1.0f / H);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = X.v[i].x - mean, b = X.v[i].y - mean, c = X.v[i].z - mean, d = X.v[i].w - mean;
+    s += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = wave_sum(s) * (1.0f / H);
+  rstd = rsqrtf(var + eps);
+  Row& A = X; const Row& B = G; const Row& Cc = Bt;
+  ROW_FOREACH(a = (a - mean) * rstd * b + c; (void)e)
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward:  x = LN(h)  -> x_f32 (residual stream), x_bf16 (next GEMM operand), stats
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, long rows,
+                                                     float* __restrict__ x_f32, bf16_t* __restrict__ x_bf16,
+                                                     float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  Row X = load_row(h + row * H, lane);
+  const Row G = load_row(gamma, lane), Bt = load_row(beta, lane);
+  float mean, rstd;
+  ln_normalise(X, G, Bt, eps, mean, rstd);
+  if (x_f32) store_row(x_f32 + row * H, lane, X);
+  if (x_bf16) store_row_bf16(x_bf16 + row * H, lane, X);
+  if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Embeddings:  x0 = dropout(LN(word[ids] + pos[pid] + type[tt]))
+// position ids: BERT arange(S); RoBERTa cumsum(ids != pad) * (ids != pad) + pad
+// ------------------------------------------------------------------------------------------
+struct EmbedArgs {
+  const long* ids; const long* tt;
+  const float* word; const float* pos; const float* type;
+  const float* gamma; const float* beta;
+  float eps; int S; long rows; int roberta; int pad_id; int vocab, max_pos, type_vocab;
+  Dropout drop;
+};
+
+__device__ __forceinline__ int position_id(const EmbedArgs& a, long row, int lane) {
+  const int s = (int)(row % a.S);
+  if (!a.roberta) return s;
+  const long base = row - s;
+  int cnt = 0;
+  for (int c0 = 0; c0 <= s; c0 += 64) {
+    const int j = c0 + lane;
+    const bool nz = (j <= s) && (a.ids[base + j] != a.pad_id);
+    cnt += __popcll(__ballot(nz));
+  }
+  const bool self_nz = a.ids[row] != a.pad_id;
+  return (self_nz ? cnt : 0) + a.pad_id;
+}
+
+__device__ __forceinline__ Row embed_gather(const EmbedArgs& a, long row, int lane, int& pid, int& tid_) {
+  long id = a.ids[row];
+  id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);        // clamp: never read out of bounds
+  pid = position_id(a, row, lane);
+  pid = pid >= a.max_pos ? a.max_pos - 1 : pid;
+  long t = a.tt ? a.tt[row] : 0;
+  tid_ = (int)(t < 0 ? 0 : (t >= a.type_vocab ? a.type_vocab - 1 : t));
+  Row A = load_row(a.word + id * H, lane);
+  const Row B = load_row(a.pos + (long)pid * H, lane), Cc = load_row(a.type + (long)tid_ * H, lane);
+  ROW_FOREACH(a = a + b + c; (void)e)
+  return A;
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a, float* __restrict__ x_f32, bf16_t* __restrict__ x_bf16,
+                                                        float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  int pid, tid_;
+  Row X = embed_gather(a, row, lane, pid, tid_);
+  const Row G = load_row(a.gamma, lane), Bt = load_row(a.beta, lane);
+  float mean, rstd;
+  ln_normalise(X, G, Bt, a.eps, mean, rstd);
+  if (a.drop.thresh) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const uint32_t e0 = (uint32_t)(row * H + (i * 64 + lane) * 4);
+      X.v[i].x *= dropout_mult(a.drop, e0); X.v[i].y *= dropout_mult(a.drop, e0 + 1);
+      X.v[i].z *= dropout_mult(a.drop, e0 + 2); X.v[i].w *= dropout_mult(a.drop, e0 + 3);
+    }
+  }
+  store_row(x_f32 + row * H, lane, X);
+  store_row_bf16(x_bf16 + row * H, lane, X);
+  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward core on one row: dxhat = dy*g ; dh = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat))
+// On return DY holds dh, XH holds xhat*dy_in (the dgamma contribution), and dbeta contribution is dy_in
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_bwd_row(Row& DY /*in: dy, out: dh*/, Row& XH /*in: h, out: dy*xhat*/, const Row& G,
+                                           float mean, float rstd) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float* d = &DY.v[i].x; float* x = &XH.v[i].x; const float* g = &G.v[i].x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (x[e] - mean) * rstd;
+      const float dxh = d[e] * g[e];
+      s1 += dxh; s2 += dxh * xh;
+      x[e] = xh;
+    }
+  }
+  s1 = wave_sum(s1) * (1.0f / H);
+  s2 = wave_sum(s2) * (1.0f / H);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float* d = &DY.v[i].x; float* x = &XH.v[i].x; const float* g = &G.v[i].x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dy = d[e], xh = x[e];
+      d[e] = rstd * (dy * g[e] - s1 - xh * s2);
+      x[e] = dy * xh;
+    }
+  }
+}
+
+constexpr int LNB_ROWS = 16;   // rows per block in the backward kernels (4 per wave)
+
+// combine the 4 waves' column partials through LDS and write them: part[blk][slot][H]
+__device__ __forceinline__ void write_partials(float* lds /*[4][H]*/, const Row& acc, float* __restrict__ dst, int lane, int wave) {
+  __syncthreads();
+  store_row(lds + wave * H, lane, acc);
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) dst[c] = (lds[c] + lds[H + c]) + (lds[2 * H + c] + lds[3 * H + c]);
+}
+
+// dy_out: grad w.r.t. the LN output (f32).  Outputs: dh (f32, grad w.r.t. the LN input = residual-path
+// gradient), dyb (bf16, dh * dropout-mask of the sub-layer output = grad w.r.t. the GEMM result),
+// partials[blk][3][H] = {dgamma, dbeta, dbias}.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy_out, const float* __restrict__ h,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     long rows, Dropout drop, float* __restrict__ dh,
+                                                     bf16_t* __restrict__ dyb, float* __restrict__ partials) {
+  __shared__ float lds[4 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Row G = load_row(gamma, lane);
+  Row accG, accB, accBias;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) accG.v[i] = accB.v[i] = accBias.v[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int r = wave; r < LNB_ROWS; r += 4) {
+    const long row = (long)blockIdx.x * LNB_ROWS + r;
+    if (row >= rows) break;
+    Row DY = load_row(dy_out + row * H, lane);
+    Row XH = load_row(h + row * H, lane);
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { accB.v[i].x += DY.v[i].x; accB.v[i].y += DY.v[i].y; accB.v[i].z += DY.v[i].z; accB.v[i].w += DY.v[i].w; }
+    ln_bwd_row(DY, XH, G, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { accG.v[i].x += XH.v[i].x; accG.v[i].y += XH.v[i].y; accG.v[i].z += XH.v[i].z; accG.v[i].w += XH.v[i].w; }
+    if (dh) store_row(dh + row * H, lane, DY);
+    if (drop.thresh) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const uint32_t e0 = (uint32_t)(row * H + (i * 64 + lane) * 4);
+        DY.v[i].x *= dropout_mult(drop, e0); DY.v[i].y *= dropout_mult(drop, e0 + 1);
+        DY.v[i].z *= dropout_mult(drop, e0 + 2); DY.v[i].w *= dropout_mult(drop, e0 + 3);
+      }
+    }
+    if (dyb) store_row_bf16(dyb + row * H, lane, DY);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { accBias.v[i].x += DY.v[i].x; accBias.v[i].y += DY.v[i].y; accBias.v[i].z += DY.v[i].z; accBias.v[i].w += DY.v[i].w; }
+  }
+  float* dst = partials + (long)blockIdx.x * 3 * H;
+  write_partials(lds, accG, dst, lane, wave);
+  write_partials(lds, accB, dst + H, lane, wave);
+  write_partials(lds, accBias, dst + 2 * H, lane, wave);
+}
+
+// Embedding backward: dx0 (f32 grad of the embedding output) -> LN backward -> scatter-add into the
+// word / position tables (float atomics, 256 contiguous bytes per wave instruction), per-block partials
+// for LN gamma/beta and the (<= 2 row) token-type table: partials[blk][2 + type_vocab][H].
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float* __restrict__ dx0,
+                                                        const float* __restrict__ stats, float* __restrict__ dword,
+                                                        float* __restrict__ dpos, float* __restrict__ partials) {
+  __shared__ float lds[4 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Row G = load_row(a.gamma, lane);
+  Row accG, accB, accT0, accT1;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) accG.v[i] = accB.v[i] = accT0.v[i] = accT1.v[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int r = wave; r < LNB_ROWS; r += 4) {
+    const long row = (long)blockIdx.x * LNB_ROWS + r;
+    if (row >= a.rows) break;
+    int pid, tid_;
+    Row XH = embed_gather(a, row, lane, pid, tid_);
+    Row DY = load_row(dx0 + row * H, lane);
+    if (a.drop.thresh) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const uint32_t e0 = (uint32_t)(row * H + (i * 64 + lane) * 4);
+        DY.v[i].x *= dropout_mult(a.drop, e0); DY.v[i].y *= dropout_mult(a.drop, e0 + 1);
+        DY.v[i].z *= dropout_mult(a.drop, e0 + 2); DY.v[i].w *= dropout_mult(a.drop, e0 + 3);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { accB.v[i].x += DY.v[i].x; accB.v[i].y += DY.v[i].y; accB.v[i].z += DY.v[i].z; accB.v[i].w += DY.v[i].w; }
+    ln_bwd_row(DY, XH, G, stats[row * 2], stats[row * 2 + 1]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { accG.v[i].x += XH.v[i].x; accG.v[i].y += XH.v[i].y; accG.v[i].z += XH.v[i].z; accG.v[i].w += XH.v[i].w; }
+    long id = a.ids[row];
+    id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+    float* wrow = dword + id * H;
+    float* prow = dpos + (long)pid * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      atomicAdd(wrow + c, DY.v[i].x); atomicAdd(wrow + c + 1, DY.v[i].y);
+      atomicAdd(wrow + c + 2, DY.v[i].z); atomicAdd(wrow + c + 3, DY.v[i].w);
+      atomicAdd(prow + c, DY.v[i].x); atomicAdd(prow + c + 1, DY.v[i].y);
+      atomicAdd(prow + c + 2, DY.v[i].z); atomicAdd(prow + c + 3, DY.v[i].w);
+    }
+    Row& T = tid_ == 0 ? accT0 : accT1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { T.v[i].x += DY.v[i].x; T.v[i].y += DY.v[i].y; T.v[i].z += DY.v[i].z; T.v[i].w += DY.v[i].w; }
+  }
+  const int slots = 2 + a.type_vocab;
+  float* dst = partials + (long)blockIdx.x * slots * H;
+  write_partials(lds, accG, dst, lane, wave);
+  write_partials(lds, accB, dst + H, lane, wave);
+  write_partials(lds, accT0, dst + 2 * H, lane, wave);
+  if (a.type_vocab > 1) write_partials(lds, accT1, dst + 3 * H, lane, wave);
+}
+
+// out[c] (+)= sum_p partials[p][c]   (c < n, p < nparts): 64 columns per block, 4 row-lanes, fixed order
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                             int n, int nparts, int accumulate) {
+  __shared__ float lds[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < n) for (int p = rl; p < nparts; p += 4) s += partials[(long)p * n + c];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    const float t = (lds[threadIdx.x] + lds[64 + threadIdx.x]) + (lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+// same reduction, but column c goes to outs.p[c / seg][c % seg] (null pointers are skipped)
+struct SegOuts { float* p[4]; };
+__global__ __launch_bounds__(256) void partial_reduce_seg_kernel(const float* __restrict__ partials, SegOuts outs, int seg,
+                                                                 int n, int nparts) {
+  __shared__ float lds[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < n) for (int p = rl; p < nparts; p += 4) s += partials[(long)p * n + c];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    const float t = (lds[threadIdx.x] + lds[64 + threadIdx.x]) + (lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+    float* o = outs.p[c / seg];
+    if (o) o[c % seg] = t;
+  }
+}
+
+// Column sums of a bf16 matrix [rows, n] (bias gradients): partials[rowchunk][n], 256 rows per chunk
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, long rows, int n,
+                                                          float* __restrict__ partials) {
+  __shared__ float lds[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + cg * 8;
+  const long r0 = (long)blockIdx.y * 256;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < n) {
+    for (long r = r0 + rl; r < r0 + 256 && r < rows; r += 8) {
+      const uint4 v = *(const uint4*)(x + r * ld + col);
+      acc[0] += bf2f((bf16_t)(v.x & 0xffff)); acc[1] += bf2f((bf16_t)(v.x >> 16));
+      acc[2] += bf2f((bf16_t)(v.y & 0xffff)); acc[3] += bf2f((bf16_t)(v.y >> 16));
+      acc[4] += bf2f((bf16_t)(v.z & 0xffff)); acc[5] += bf2f((bf16_t)(v.z >> 16));
+      acc[6] += bf2f((bf16_t)(v.w & 0xffff)); acc[7] += bf2f((bf16_t)(v.w >> 16));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lds[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += lds[r][c];
+    partials[(long)blockIdx.y * n + blockIdx.x * 256 + c] = s;
+  }
+}
+
+}  // namespace carel
+
+using namespace carel;
+
+static EmbedArgs make_embed(const carel_embed_args* a) {
+  EmbedArgs e;
+  e.ids = (const long*)a->input_ids; e.tt = (const long*)a->token_type_ids;
+  e.word = (const float*)a->word_emb; e.pos = (const float*)a->pos_emb; e.type = (const float*)a->type_emb;
+  e.gamma = (const float*)a->ln_gamma; e.beta = (const float*)a->ln_beta;
+  e.eps = a->ln_eps; e.S = a->seq_len; e.rows = (long)a->batch * a->seq_len; e.roberta = a->roberta; e.pad_id = a->pad_id;
+  e.vocab = a->vocab_size; e.max_pos = a->max_pos; e.type_vocab = a->type_vocab;
+  e.drop = make_dropout(a->drop_seed, 0u, a->drop_p, a->drop_idx_offset);
+  return e;
+}
+
+static int embed_check(const carel_embed_args* a, const char* who) {
+  if (!a) return set_error(CAREL_ERR_ARG, "%s: null args", who);
+  if (a->hidden != H) return set_error(CAREL_ERR_SHAPE, "%s: hidden must be %d (got %d)", who, H, a->hidden);
+  if (!a->input_ids || !a->word_emb || !a->pos_emb || !a->type_emb || !a->ln_gamma || !a->ln_beta)
+    return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  if (a->batch <= 0 || a->seq_len <= 0 || a->type_vocab < 1 || a->type_vocab > 2 || a->seq_len > a->max_pos)
+    return set_error(CAREL_ERR_SHAPE, "%s: bad batch/seq_len/type_vocab", who);
+  return CAREL_OK;
+}
+
+extern "C" int carel_embed_ln_fwd(const carel_embed_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = embed_check(a, "carel_embed_ln_fwd");
+  if (rc) return rc;
+  if (!a->x_f32 || !a->x_bf16 || !a->stats) return set_error(CAREL_ERR_ARG, "carel_embed_ln_fwd: null output");
+  EmbedArgs e = make_embed(a);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((e.rows + 3) / 4)), dim3(256), 0, stream, e, (float*)a->x_f32,
+                     (bf16_t*)a->x_bf16, (float*)a->stats);
+  return check_launch("embed_fwd_kernel");
+}
+
+extern "C" int carel_embed_ln_bwd_blocks(int64_t rows) { return (int)((rows + LNB_ROWS - 1) / LNB_ROWS); }
+
+extern "C" int carel_embed_ln_bwd(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_,
+                                  void* dgamma, void* dbeta, void* partials, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = embed_check(a, "carel_embed_ln_bwd");
+  if (rc) return rc;
+  if (!dx0 || !dword || !dpos || !dtype_ || !dgamma || !dbeta || !partials || !a->stats)
+    return set_error(CAREL_ERR_ARG, "carel_embed_ln_bwd: null tensor");
+  EmbedArgs e = make_embed(a);
+  const int nblk = carel_embed_ln_bwd_blocks(e.rows);
+  const int slots = 2 + e.type_vocab;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblk), dim3(256), 0, stream, e, (const float*)dx0, (const float*)a->stats,
+                     (float*)dword, (float*)dpos, (float*)partials);
+  rc = check_launch("embed_bwd_kernel");
+  if (rc) return rc;
+  SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dtype_;
+  so.p[3] = e.type_vocab > 1 ? (float*)dtype_ + H : nullptr;
+  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((slots * H + 63) / 64), dim3(256), 0, stream, (const float*)partials,
+                     so, H, slots * H, nblk);
+  return check_launch("partial_reduce_seg_kernel");
+}
+
+extern "C" int carel_layernorm_fwd(const void* h, const void* gamma, const void* beta, float eps, int64_t rows, int32_t hidden,
+                                   void* x_f32, void* x_bf16, void* stats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hidden != H) return set_error(CAREL_ERR_SHAPE, "carel_layernorm_fwd: hidden must be %d", H);
+  if (!h || !gamma || !beta || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_fwd: bad arguments");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const float*)h, (const float*)gamma,
+                     (const float*)beta, eps, (long)rows, (float*)x_f32, (bf16_t*)x_bf16, (float*)stats);
+  return check_launch("ln_fwd_kernel");
+}
+
+extern "C" int carel_layernorm_bwd_blocks(int64_t rows) { return (int)((rows + LNB_ROWS - 1) / LNB_ROWS); }
+
+// partials: f32 scratch of carel_layernorm_bwd_blocks(rows) * 3 * hidden floats
+extern "C" int carel_layernorm_bwd(const void* dy, const void* h, const void* stats, const void* gamma, int64_t rows,
+                                   int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset,
+                                   float drop_p, void* dh_f32, void* dy_bf16, void* dgamma, void* dbeta, void* dbias,
+                                   void* partials, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hidden != H) return set_error(CAREL_ERR_SHAPE, "carel_layernorm_bwd: hidden must be %d", H);
+  if (!dy || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_bwd: bad arguments");
+  const int nblk = carel_layernorm_bwd_blocks(rows);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
+                     (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
+                     (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials);
+  int rc = check_launch("ln_bwd_kernel");
+  if (rc) return rc;
+  SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dbias; so.p[3] = nullptr;
+  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((3 * H + 63) / 64), dim3(256), 0, stream, (const float*)partials, so,
+                     H, 3 * H, nblk);
+  return check_launch("partial_reduce_seg_kernel");
+}
+
+extern "C" int carel_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t n, void* out_f32, int32_t accumulate,
+                                 void* partials, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out_f32 || !partials || rows <= 0 || n <= 0 || (n & 7) || (ld & 7))
+    return set_error(CAREL_ERR_ARG, "carel_colsum_bf16: bad arguments (n, ld multiples of 8)");
+  const int chunks = (int)((rows + 255) / 256);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((n + 255) / 256, chunks), dim3(256), 0, stream, (const bf16_t*)x, (long)ld,
+                     (long)rows, n, (float*)partials);
+  int rc = check_launch("colsum_bf16_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partials, (float*)out_f32, n,
+                     chunks, accumulate);
+  return check_launch("partial_reduce_kernel");
+}

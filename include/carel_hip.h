@@ -84,6 +84,77 @@ int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
 int carel_slab_reduce_f32(const void* slabs, void* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Embeddings + LayerNorm (HF BertEmbeddings / RobertaEmbeddings.forward) and its backward.
+ *   x0 = dropout(LN(word[ids] + pos[position_ids] + type[token_type_ids])), dropout site 0.
+ * position_ids: arange(S) for BERT; cumsum(ids != pad) * (ids != pad) + pad for RoBERTa (roberta = 1).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_embed_args {
+  const void* input_ids;       /* int64 [B, S] */
+  const void* token_type_ids;  /* int64 [B, S] or NULL (= 0) */
+  const void* word_emb;        /* f32 [vocab, 768]   */
+  const void* pos_emb;         /* f32 [max_pos, 768] */
+  const void* type_emb;        /* f32 [type_vocab, 768] */
+  const void* ln_gamma;        /* f32 [768] */
+  const void* ln_beta;         /* f32 [768] */
+  float ln_eps;
+  int32_t batch, seq_len, hidden;        /* hidden must be 768 */
+  int32_t vocab_size, max_pos, type_vocab; /* type_vocab 1 or 2 */
+  int32_t roberta, pad_id;
+  uint32_t drop_seed, drop_idx_offset;
+  float drop_p;
+  void* x_f32;                 /* out f32  [B*S, 768] */
+  void* x_bf16;                /* out bf16 [B*S, 768] */
+  void* stats;                 /* out f32  [B*S, 2] (mean, rstd); input of the backward */
+} carel_embed_args;
+
+int carel_embed_ln_fwd(const carel_embed_args* args, void* stream);
+/* number of row blocks of the backward kernels: partial buffers need blocks * slots * 768 floats */
+int carel_embed_ln_bwd_blocks(int64_t rows);
+/* dword [vocab,768] and dpos [max_pos,768] are ACCUMULATED into with float atomics (zero them first);
+ * dtype [type_vocab,768], dgamma, dbeta [768] are overwritten.
+ * partials: f32 scratch, carel_embed_ln_bwd_blocks(B*S) * (2 + type_vocab) * 768 floats. */
+int carel_embed_ln_bwd(const carel_embed_args* args, const void* dx0_f32, void* dword, void* dpos, void* dtype,
+                       void* dgamma, void* dbeta, void* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over 768-wide rows (BertSelfOutput.LayerNorm / BertOutput.LayerNorm) and its backward with
+ * the sub-layer dropout backward fused:  dh = LN'(dy) ; dy_bf16 = dh * dropout_mask(site) ;
+ * dgamma, dbeta, dbias (= column sum of dy_bf16 before rounding) are overwritten.
+ * ---------------------------------------------------------------------------------------------- */
+int carel_layernorm_fwd(const void* h_f32, const void* gamma, const void* beta, float eps, int64_t rows, int32_t hidden,
+                        void* x_f32, void* x_bf16, void* stats, void* stream);
+int carel_layernorm_bwd_blocks(int64_t rows);
+/* partials: f32 scratch of carel_layernorm_bwd_blocks(rows) * 3 * 768 floats */
+int carel_layernorm_bwd(const void* dy_f32, const void* h_f32, const void* stats, const void* gamma, int64_t rows,
+                        int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p,
+                        void* dh_f32, void* dy_bf16, void* dgamma, void* dbeta, void* dbias, void* partials, void* stream);
+/* out[n] (+)= column sums of a bf16 matrix [rows, n] (bias gradients); partials: ceil(rows/256)*n floats */
+int carel_colsum_bf16(const void* x_bf16, int64_t ld, int64_t rows, int32_t n, void* out_f32, int32_t accumulate,
+                      void* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention of one encoder layer, all (sample, head) pairs; S in {32,64,96,128}, 12 heads x 64.
+ * Replaces transformers BertSelfAttention.forward after the q/k/v projections (eager attention:
+ * softmax(QK^T/8 + (1-mask)*finfo.min) -> dropout -> PV) and its backward.
+ * qkv / dqkv: bf16 [B*S, 2304] = q | k | v.  ctx / dctx: bf16 [B*S, 768].  lse: f32 [B, 12, S].
+ * dropout element index = ((b*12 + h)*S + q)*S + k.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_attn_args {
+  const void* qkv;
+  const void* attention_mask;  /* int64 [B, S], 1 = attend; NULL = all ones */
+  void* ctx;                   /* fwd: out; bwd: in */
+  void* lse;                   /* fwd: out; bwd: in */
+  const void* dctx;            /* bwd in  */
+  void* dqkv;                  /* bwd out */
+  int32_t batch, seq_len, heads, head_dim;
+  uint32_t drop_seed, drop_site, drop_idx_offset;
+  float drop_p;
+} carel_attn_args;
+
+int carel_attention_fwd(const carel_attn_args* args, void* stream);
+int carel_attention_bwd(const carel_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RBF-MMD statistic.  Replaces MMDStatistic.__call__ (ref :547-569) + pdist (ref :580-589) and
  * their autograd backward.  mmd = 2*a01*sum(K12) + a00*(sum(K11)-tr K11) + a11*(sum(K22)-tr K22),
  * K = sum_alpha exp(-alpha * (eps + |d2|)), a00 = 1/(n1(n1-1)), a11 = 1/(n2(n2-1)), a01 = -1/(n1 n2).

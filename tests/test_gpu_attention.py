@@ -1,0 +1,89 @@
+"""Self-attention forward/backward kernels vs torch fp64 eager attention on the same bf16 inputs
+(padding masks, dropout with the shared counter-based masks, S in {32, 64, 128})."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from carel_vae_amd import _lib as L
+from oracle import carel_oracle as O
+from tests.gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+NH, HD, H = 12, 64, 768
+
+
+def run_attn(qkv, mask, B, S, drop=(0, 0, 0, 0.0), dctx=None):
+    lib = L.load()
+    a = L.AttnArgs()
+    ctx = torch.empty((B * S, H), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty((B, NH, S), device="cuda")
+    a.qkv, a.attention_mask, a.ctx, a.lse = qkv.data_ptr(), (None if mask is None else mask.data_ptr()), ctx.data_ptr(), lse.data_ptr()
+    a.batch, a.seq_len, a.heads, a.head_dim = B, S, NH, HD
+    a.drop_seed, a.drop_site, a.drop_idx_offset, a.drop_p = drop
+    L.check(lib.carel_attention_fwd(C.byref(a), L.current_stream()), "attn fwd")
+    dqkv = None
+    if dctx is not None:
+        dqkv = torch.empty((B * S, 3 * H), device="cuda", dtype=torch.bfloat16)
+        a.dctx, a.dqkv = dctx.data_ptr(), dqkv.data_ptr()
+        L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd")
+    torch.cuda.synchronize()
+    return ctx, lse, dqkv
+
+
+def ref_attn(qkv, mask, B, S, drop):
+    x = qkv.double().view(B, S, 3, NH, HD).requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))            # [B,NH,S,HD]
+    s = q @ k.transpose(-1, -2) / math.sqrt(HD)
+    if mask is not None:
+        s = s + (1.0 - mask.double())[:, None, None, :] * torch.finfo(torch.float32).min
+    lse = torch.logsumexp(s, dim=-1)
+    pr = torch.softmax(s, dim=-1)
+    seed, site, off, p = drop
+    if p > 0:
+        idx = (np.arange(B * NH * S * S, dtype=np.uint64) + np.uint64(off)).astype(np.uint32)
+        m = torch.from_numpy(O.dropout_keep(seed, site, idx, p).astype(np.float64) / (1 - p)).cuda().view(B, NH, S, S)
+        pr = pr * m
+    ctx = (pr @ v).transpose(1, 2).reshape(B * S, H)
+    return x, ctx, lse
+
+
+@pytest.mark.parametrize("B,S,masked,p", [(3, 128, False, 0.0), (4, 128, True, 0.0), (2, 128, True, 0.1),
+                                           (5, 64, True, 0.1), (3, 32, False, 0.0), (2, 96, True, 0.0)])
+def test_attention_fwd_bwd(B, S, masked, p):
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    qkv = (torch.randn((B * S, 3 * H), generator=g) * 1.5).cuda().bfloat16()
+    mask = None
+    if masked:
+        mask = torch.ones((B, S), dtype=torch.int64)
+        for b in range(B):
+            ln = int(torch.randint(3, S + 1, (1,), generator=g))
+            mask[b, ln:] = 0
+        mask = mask.cuda()
+    dctx = (torch.randn((B * S, H), generator=g)).cuda().bfloat16()
+    drop = (77, O.site_attn_probs(4), 11 * NH * S * S, p)
+    ctx, lse, dqkv = run_attn(qkv, mask, B, S, drop, dctx)
+    x, rctx, rlse = ref_attn(qkv, mask, B, S, drop)
+    assert rel_err(ctx, rctx.detach()) < 8e-3          # bf16 probabilities + bf16 output
+    np.testing.assert_allclose(lse.cpu().numpy(), rlse.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    rctx.backward(dctx.double())
+    rg = x.grad.reshape(B * S, 3 * H)
+    got = dqkv.double()
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        e = rel_err(got[:, sl], rg[:, sl])
+        assert e < 1.5e-2, (name, e)                   # bf16 P, dS, dO operands
+    if masked:   # padded keys get exactly zero dK / dV; padded queries still produce finite values
+        for b in range(B):
+            pad = (mask[b] == 0).nonzero().flatten()
+            if len(pad):
+                rows = b * S + pad
+                assert float(got[rows, H:].abs().max()) == 0.0
+    assert torch.isfinite(got).all()
+
+
+def test_attention_rejects_bad_shapes():
+    qkv = torch.zeros((100, 3 * H), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(L.CarelError):
+        run_attn(qkv, None, 1, 100)
