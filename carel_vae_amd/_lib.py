@@ -53,6 +53,29 @@ class AttnArgs(C.Structure):
                 ("drop_p", C.c_float)]
 
 
+class TailArgs(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("seq_len", C.c_int32), ("hidden", C.c_int32), ("ec_dim", C.c_int32),
+                ("e_classes", C.c_int32), ("bow_dim", C.c_int32),
+                ("x_last_f32", C.c_void_p), ("pooler_w", C.c_void_p), ("pooler_b", C.c_void_p),
+                ("head_w", C.c_void_p * 4), ("head_b", C.c_void_p * 4),
+                ("emo_w", C.c_void_p), ("emo_b", C.c_void_p), ("cau_w", C.c_void_p), ("cau_b", C.c_void_p),
+                ("pair_w", C.c_void_p), ("pair_b", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p),
+                ("emo_labels", C.c_void_p), ("cau_labels", C.c_void_p), ("pair_labels", C.c_void_p),
+                ("bow", C.c_void_p), ("eps_e", C.c_void_p), ("eps_c", C.c_void_p),
+                ("w_mmd", C.c_float), ("w_emo", C.c_float), ("w_cau", C.c_float), ("w_pair", C.c_float),
+                ("kl_weight", C.c_float), ("label_smoothing", C.c_float),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_row_offset", C.c_uint32),
+                ("mmd_alpha", C.c_float), ("mmd_eps", C.c_float),
+                ("global_label_sum", C.c_void_p), ("global_n", C.c_int32), ("global_row_offset", C.c_int32),
+                ("z_global", C.c_void_p), ("mmd_grad_scale", C.c_float),
+                ("pooled", C.c_void_p), ("lat", C.c_void_p), ("z", C.c_void_p), ("terms", C.c_void_p),
+                ("work", C.c_void_p),
+                ("d_emo_w", C.c_void_p), ("d_emo_b", C.c_void_p), ("d_cau_w", C.c_void_p), ("d_cau_b", C.c_void_p),
+                ("d_pair_w", C.c_void_p), ("d_pair_b", C.c_void_p), ("d_dec_w", C.c_void_p), ("d_dec_b", C.c_void_p),
+                ("d_head_w", C.c_void_p * 4), ("d_head_b", C.c_void_p * 4),
+                ("d_pooler_w", C.c_void_p), ("d_pooler_b", C.c_void_p), ("dx_last_f32", C.c_void_p)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
 
@@ -76,6 +99,11 @@ SIGNATURES = {
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_float] + [C.c_void_p] * 7),
     "carel_colsum_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p]),
+    "carel_tail_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "carel_tail_latents": (C.c_int, [C.POINTER(TailArgs), C.c_void_p]),
+    "carel_tail_losses": (C.c_int, [C.POINTER(TailArgs), C.c_void_p]),
+    "carel_tail_backward": (C.c_int, [C.POINTER(TailArgs), C.c_float, C.c_void_p]),
+    "carel_pair_probs": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "carel_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
 }

@@ -1,0 +1,638 @@
+// VAE tail of DrlClassifier.forward (drl_classifier_ec_mmd_final_mul.py:202-261) and its backward:
+//   pooler (HF BertPooler: tanh(W_p x[:,0] + b_p)) -> 4 latent heads (:312-336) -> reparameterised sample
+//   (:345-351, one eps vector shared by the batch, std = exp(log_var)) -> emotion CE (:461-476), cause BCE
+//   (:478-492), pair BCE-with-logits + pos_weight (:494-513, replaced by 0 when infinite), RBF-MMD
+//   (:231-233), annealed KL (:515-534), decoder softmax + BCE reconstruction (:253-254, :381-387),
+//   weighted sum (:256-261).
+// Everything is fp32.  The scalar loss and the gradients w.r.t. every tail tensor are produced together
+// (the loss is the root of the graph, so backward only rescales them by grad_output).
+#include "carel_hip_internal.h"
+#include "mmd_device.h"
+
+namespace carel {
+
+constexpr int TH = 768;
+constexpr int TNV = TH / 256;
+
+// ------------------------------------------------------------------------------------------
+// out[b][n] = act( sum_k in[b*in_stride + k] * W_n[k] + bias_n )   one wave per output column n,
+// W_n = w[n / seg] + (n % seg) * K ; bias likewise (lets the 4 latent heads share one launch)
+// ------------------------------------------------------------------------------------------
+struct PtrSet4 { const float* w[4]; const float* b[4]; };
+
+template <int ACT>   // 0 none, 1 tanh
+__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ in, long in_stride, int B, int N,
+                                                            int seg, PtrSet4 ps, float* __restrict__ out, long out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* w = ps.w[n / seg] + (long)(n % seg) * TH;
+  const float bias = ps.b[n / seg] ? ps.b[n / seg][n % seg] : 0.f;
+  float4 wv[TNV];
+#pragma unroll
+  for (int i = 0; i < TNV; ++i) wv[i] = *(const float4*)(w + (i * 64 + lane) * 4);
+  for (int b = 0; b < B; ++b) {
+    const float* x = in + (long)b * in_stride;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TNV; ++i) {
+      const float4 xv = *(const float4*)(x + (i * 64 + lane) * 4);
+      s += (xv.x * wv[i].x + xv.y * wv[i].y) + (xv.z * wv[i].z + xv.w * wv[i].w);
+    }
+    s = wave_sum(s) + bias;
+    if (ACT == 1) s = tanhf(s);
+    if (lane == 0) out[(long)b * out_stride + n] = s;
+  }
+}
+
+// dW_n[k] = sum_b dY[b][n] * X[b*x_stride + k] ; db_n = sum_b dY[b][n]   (one wave per n)
+struct OutSet4 { float* w[4]; float* b[4]; };
+__global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* __restrict__ dY, long dy_stride, const float* __restrict__ X,
+                                                           long x_stride, int B, int N, int seg, OutSet4 os) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float4 acc[TNV];
+#pragma unroll
+  for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = dY[(long)b * dy_stride + n];
+    sb += g;
+    const float* x = X + (long)b * x_stride;
+#pragma unroll
+    for (int i = 0; i < TNV; ++i) {
+      const float4 xv = *(const float4*)(x + (i * 64 + lane) * 4);
+      acc[i].x = fmaf(g, xv.x, acc[i].x); acc[i].y = fmaf(g, xv.y, acc[i].y);
+      acc[i].z = fmaf(g, xv.z, acc[i].z); acc[i].w = fmaf(g, xv.w, acc[i].w);
+    }
+  }
+  float* w = os.w[n / seg] + (long)(n % seg) * TH;
+#pragma unroll
+  for (int i = 0; i < TNV; ++i) *(float4*)(w + (i * 64 + lane) * 4) = acc[i];
+  if (lane == 0 && os.b[n / seg]) os.b[n / seg][n % seg] = sb;
+}
+
+// dX[b][k] = sum_n dY[b][n] * W_n[k]  (one wave per sample b);  MODE 1: dY is multiplied by (1 - y^2) of
+// the tanh output y (pooler) first and the product is also written to dpre (for the pooler wgrad)
+template <int MODE>
+__global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restrict__ dY, long dy_stride, int B, int N, int seg,
+                                                           PtrSet4 ps, const float* __restrict__ y, float* __restrict__ dpre,
+                                                           float* __restrict__ dX, long dx_stride) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float4 acc[TNV];
+#pragma unroll
+  for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < N; ++n) {
+    float g = dY[(long)b * dy_stride + n];
+    if (MODE == 1) {
+      const float yy = y[(long)b * N + n];
+      g *= (1.0f - yy * yy);
+      if (lane == 0) dpre[(long)b * N + n] = g;
+    }
+    const float* w = ps.w[n / seg] + (long)(n % seg) * TH;
+#pragma unroll
+    for (int i = 0; i < TNV; ++i) {
+      const float4 wv = *(const float4*)(w + (i * 64 + lane) * 4);
+      acc[i].x = fmaf(g, wv.x, acc[i].x); acc[i].y = fmaf(g, wv.y, acc[i].y);
+      acc[i].z = fmaf(g, wv.z, acc[i].z); acc[i].w = fmaf(g, wv.w, acc[i].w);
+    }
+  }
+  float* o = dX + (long)b * dx_stride;
+#pragma unroll
+  for (int i = 0; i < TNV; ++i) *(float4*)(o + (i * 64 + lane) * 4) = acc[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Tail core: one workgroup.  lat = [mu_e | lv_e | mu_c | lv_c] (B x 4D).
+// ------------------------------------------------------------------------------------------
+struct TailCore {
+  int B, D, EC;                 // batch, ec_dim (<= 32), emotion classes (<= 8)
+  const float* lat;             // [B, 4D]
+  const float* eps_e; const float* eps_c;
+  const float* emo_w; const float* emo_b;      // [EC, D], [EC]
+  const float* cau_w; const float* cau_b;      // [1, D], [1]
+  const float* pair_w; const float* pair_b;    // [1, 2D], [1]
+  const long* emo_labels; const float* cau_labels; const float* pair_labels;
+  float w_mmd, w_emo, w_cau, w_pair, kl_w, ls;
+  Dropout d_emo, d_cau, d_pair;                // element index b*D + k (pair: b*2D + k)
+  float alpha, mmd_eps;
+  const float* label_sum_override; float n_override;   // global-batch pos_weight (DP); null/0 = local
+  const float* z_global; int n_global, row_offset; float mmd_grad_scale;  // global-batch MMD (DP)
+  // outputs
+  float* z;                     // [B, 2D]
+  float* terms;                 // [16]: 0 partial loss (everything but rec), 1 mmd, 2 emo, 3 cau, 4 pair, 5 kl_e, 6 kl_c
+  float* dz;                    // [B, 2D]  d(loss)/dz (without reconstruction)
+  float* dlat_direct;           // [B, 4D]  KL part of d(loss)/d lat
+  float* d_emo_w; float* d_emo_b; float* d_cau_w; float* d_cau_b; float* d_pair_w; float* d_pair_b;
+  float* pair_dead;             // [1]: 1.0 if the pair loss was replaced by 0 (ref :510-511)
+};
+
+__global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;                 // 64
+  float* sc = red + 64;                          // 64 scalars
+  const int B = a.B, D = a.D, D2 = 2 * a.D;
+  float* zl = sc + 64;                           // [B][2D] sampled latents
+  float* dzl = zl + B * D2;                      // [B][2D] gradient accumulator
+  float* elog = dzl + B * D2;                    // [B][8] emotion dlogits
+  float* gx = elog + B * 8;                      // [B][2]  cause / pair dlogit
+  const int nm = a.z_global ? a.n_global : B;    // samples per side in the MMD
+  float* nrm = gx + B * 2;                       // [2 nm]
+  float* Z = nrm + ((2 * nm + 3) & ~3);          // MMD samples [2 nm][D|1]
+  const int zs = D | 1;
+  const int t = threadIdx.x;
+
+  for (int e = t; e < B * D2; e += blockDim.x) {
+    const int b = e / D2, k = e - b * D2;
+    const float* row = a.lat + (long)b * 4 * D;
+    const float z = (k < D) ? row[k] + a.eps_e[k] * expf(row[D + k]) : row[2 * D + (k - D)] + a.eps_c[k - D] * expf(row[3 * D + (k - D)]);
+    zl[e] = z; dzl[e] = 0.f; a.z[e] = z;
+  }
+  __syncthreads();
+  // ---- MMD samples: rows [0,nm) emotion, [nm,2nm) cause
+  for (int e = t; e < 2 * nm * D; e += blockDim.x) {
+    const int i = e / D, k = e - i * D;
+    const int s = i < nm ? i : i - nm, off = i < nm ? 0 : D;
+    Z[i * zs + k] = a.z_global ? a.z_global[(long)s * D2 + off + k] : zl[s * D2 + off + k];
+  }
+  __syncthreads();
+  MmdCfg mc; mc.n1 = nm; mc.n2 = nm; mc.d = D; mc.zs = zs; mc.n_alphas = 1; mc.alphas[0] = a.alpha; mc.eps = a.mmd_eps;
+  const float mmd = mmd_forward_block(mc, Z, nrm, red, nullptr);
+  {   // d(-w_mmd * mmd)/dz for the local rows: 8 threads per row
+    const int rows = 2 * B;
+    const int grp = t & 7;
+    for (int base = 0; base < rows; base += blockDim.x / 8) {
+      const int rloc = base + (t >> 3);
+      float g[32];
+      const bool live = rloc < rows;
+      if (live) {
+        const int side = rloc >= B, bl = rloc - side * B;
+        const int i = side * nm + a.row_offset * (a.z_global ? 1 : 0) + bl;
+        mmd_backward_row(mc, Z, nrm, i, -a.w_mmd * a.mmd_grad_scale, g, grp, 8);
+      } else {
+        for (int k = 0; k < D; ++k) g[k] = 0.f;
+      }
+      for (int k = 0; k < D; ++k) {
+        float v = g[k];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (live && grp == 0) { const int side = rloc >= B, bl = rloc - side * B; dzl[bl * D2 + side * D + k] += v; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- classifier heads: one thread per sample
+  float l_emo = 0.f, l_cau = 0.f, l_pair = 0.f, ysum = 0.f;
+  if (t < B) ysum = a.pair_labels[t];
+  ysum = block_sum(t < B ? ysum : 0.f, red);
+  const float ntot = a.label_sum_override ? a.n_override : (float)B;
+  const float ytot = a.label_sum_override ? a.label_sum_override[0] : ysum;
+  const float pw = (ntot - ytot) / ytot;        // inf when there is no positive in the batch
+  float xp = 0.f, tp = 0.f;
+  if (t < B) {
+    const int b = t;
+    // emotion: CE(W (z_e * m) + b, label)
+    float lg[8]; float mx = -INFINITY;
+    for (int c = 0; c < a.EC; ++c) {
+      float s = a.emo_b[c];
+      for (int k = 0; k < D; ++k) s = fmaf(a.emo_w[c * D + k], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), s);
+      lg[c] = s; mx = fmaxf(mx, s);
+    }
+    float se = 0.f;
+    for (int c = 0; c < a.EC; ++c) se += expf(lg[c] - mx);
+    const float lse = mx + logf(se);
+    long lab = a.emo_labels[b]; lab = lab < 0 ? 0 : (lab >= a.EC ? a.EC - 1 : lab);
+    l_emo = lse - lg[lab];
+    for (int c = 0; c < a.EC; ++c) elog[b * 8 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * (a.w_emo / B);
+    // cause: BCE(sigmoid(w (z_c * m) + b), smoothed)
+    float s = a.cau_b[0];
+    for (int k = 0; k < D; ++k) s = fmaf(a.cau_w[k], zl[b * D2 + D + k] * dropout_mult(a.d_cau, b * D + k), s);
+    const float pc = 1.0f / (1.0f + expf(-s));
+    const float tc = a.cau_labels[b] * (1.f - a.ls) + a.ls;
+    l_cau = -(tc * fmaxf(logf(pc), -100.f) + (1.f - tc) * fmaxf(logf(1.f - pc), -100.f));
+    const float gp = (pc - tc) / fmaxf((1.f - pc) * pc, 1e-12f);
+    gx[b * 2] = gp * pc * (1.f - pc) * (a.w_cau / B);
+    // pair: BCEWithLogits(w (z * m) + b, smoothed, pos_weight)
+    xp = a.pair_b[0];
+    for (int k = 0; k < D2; ++k) xp = fmaf(a.pair_w[k], zl[b * D2 + k] * dropout_mult(a.d_pair, b * D2 + k), xp);
+    tp = a.pair_labels[b] * (1.f - a.ls) + a.ls;
+    const float lw = (pw - 1.f) * tp + 1.f;
+    l_pair = (1.f - tp) * xp + lw * (log1pf(expf(-fabsf(xp))) + fmaxf(-xp, 0.f));
+  }
+  l_emo = block_sum(l_emo, red) / B;
+  l_cau = block_sum(l_cau, red) / B;
+  l_pair = block_sum(l_pair, red) / B;
+  const bool dead = isinf(l_pair);
+  if (dead) l_pair = 0.f;
+  if (t < B) {
+    const float lw = (pw - 1.f) * tp + 1.f;
+    const float sg = 1.0f / (1.0f + expf(-xp));
+    gx[t * 2 + 1] = dead ? 0.f : ((1.f - tp) - lw * (1.f - sg)) * (a.w_pair / B);
+  }
+  __syncthreads();
+  // ---- KL (:525-534) and its direct gradient on lat
+  float kle = 0.f, klc = 0.f;
+  for (int e = t; e < B * D; e += blockDim.x) {
+    const int b = e / D, k = e - b * D;
+    const float* row = a.lat + (long)b * 4 * D;
+    const float mue = row[k], lve = row[D + k], muc = row[2 * D + k], lvc = row[3 * D + k];
+    kle += -0.5f * (1.f + lve - expf(lve) - mue * mue);
+    klc += -0.5f * (1.f + lvc - expf(lvc) - muc * muc);
+    float* dl = a.dlat_direct + (long)b * 4 * D;
+    dl[k] = a.kl_w * mue / B; dl[D + k] = a.kl_w * (-0.5f) * (1.f - expf(lve)) / B;
+    dl[2 * D + k] = a.kl_w * muc / B; dl[3 * D + k] = a.kl_w * (-0.5f) * (1.f - expf(lvc)) / B;
+  }
+  kle = block_sum(kle, red) / B * a.kl_w;
+  klc = block_sum(klc, red) / B * a.kl_w;
+  // ---- dz from the three heads, and the head parameter gradients
+  for (int e = t; e < B * D2; e += blockDim.x) {
+    const int b = e / D2, k = e - b * D2;
+    float g = a.pair_w[k] * gx[b * 2 + 1] * dropout_mult(a.d_pair, b * D2 + k);
+    if (k < D) {
+      float s = 0.f;
+      for (int c = 0; c < a.EC; ++c) s = fmaf(a.emo_w[c * D + k], elog[b * 8 + c], s);
+      g += s * dropout_mult(a.d_emo, b * D + k);
+    } else {
+      g += a.cau_w[k - D] * gx[b * 2] * dropout_mult(a.d_cau, b * D + (k - D));
+    }
+    dzl[e] += g;
+  }
+  // parameter gradients: thread per parameter element, loop over the batch (fixed order)
+  const int n_emo = a.EC * D;
+  for (int e = t; e < n_emo + a.EC + D + 1 + D2 + 1; e += blockDim.x) {
+    float s = 0.f;
+    if (e < n_emo) {
+      const int c = e / D, k = e - c * D;
+      for (int b = 0; b < B; ++b) s = fmaf(elog[b * 8 + c], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), s);
+      a.d_emo_w[e] = s;
+    } else if (e < n_emo + a.EC) {
+      const int c = e - n_emo;
+      for (int b = 0; b < B; ++b) s += elog[b * 8 + c];
+      a.d_emo_b[c] = s;
+    } else if (e < n_emo + a.EC + D) {
+      const int k = e - n_emo - a.EC;
+      for (int b = 0; b < B; ++b) s = fmaf(gx[b * 2], zl[b * D2 + D + k] * dropout_mult(a.d_cau, b * D + k), s);
+      a.d_cau_w[k] = s;
+    } else if (e == n_emo + a.EC + D) {
+      for (int b = 0; b < B; ++b) s += gx[b * 2];
+      a.d_cau_b[0] = s;
+    } else if (e < n_emo + a.EC + D + 1 + D2) {
+      const int k = e - (n_emo + a.EC + D + 1);
+      for (int b = 0; b < B; ++b) s = fmaf(gx[b * 2 + 1], zl[b * D2 + k] * dropout_mult(a.d_pair, b * D2 + k), s);
+      a.d_pair_w[k] = s;
+    } else {
+      for (int b = 0; b < B; ++b) s += gx[b * 2 + 1];
+      a.d_pair_b[0] = s;
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < B * D2; e += blockDim.x) a.dz[e] = dzl[e];
+  if (t == 0) {
+    a.terms[1] = mmd; a.terms[2] = l_emo; a.terms[3] = l_cau; a.terms[4] = l_pair; a.terms[5] = kle; a.terms[6] = klc;
+    a.terms[0] = a.w_mmd * (-mmd) + a.w_emo * l_emo + a.w_cau * l_cau + a.w_pair * l_pair + kle + klc;
+    a.pair_dead[0] = dead ? 1.f : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decoder: logits[b][j] = z[b] . Wd[j] + bd[j] ; p = softmax_j ; rec = mean_{b,j} BCE(p, 0.9 bow + 0.1/V)
+// Work is split over chunks of DEC_J vocabulary entries (one thread per entry holding its 2D weights in
+// registers, the batch's latents in LDS).  Three passes (row max/sum, loss + softmax-backward dot,
+// gradients); partial results are combined in fixed order so the result is run-to-run reproducible.
+// ------------------------------------------------------------------------------------------
+constexpr int DEC_J = 128;
+constexpr int DEC_MAXD2 = 64;
+
+struct DecArgs {
+  int B, D2, V;
+  const float* z;          // [B, D2]
+  const float* w; const float* b;          // [V, D2], [V]
+  const float* bow;        // [B, V]
+  float ls;
+  float* part;             // pass1: [chunks][B][2] (max, sumexp) ; pass2: [chunks][B][2] (loss, dot)
+  float* rowstat;          // [B][4]: M, log L, dot, loss-sum
+  float* dz_part;          // [chunks][B][D2]
+  float* dw; float* db;    // [V, D2], [V]
+  float gscale;            // 1/(B V)
+};
+
+template <int CD2>
+__device__ __forceinline__ float dec_logit(const float* wr, const float* zrow, int D2rt, float bias) {
+  const int D2 = CD2 ? CD2 : D2rt;
+  float s = bias;
+#pragma unroll
+  for (int k = 0; k < D2; ++k) s = fmaf(wr[k], zrow[k], s);
+  return s;
+}
+
+// CD2 > 0: 2*ec_dim known at compile time (weights stay in registers); CD2 == 0: generic run-time width
+template <int PASS, int CD2>
+__global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
+  const int D2 = CD2 ? CD2 : a.D2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* zl = (float*)smem_raw;                       // [B][D2]
+  float* red = zl + a.B * D2;                       // 16
+  float* dl = red + 16;                               // PASS 3: [B][DEC_J] dlogits
+  float* wl = dl + (PASS == 3 ? a.B * DEC_J : 0);     // PASS 3: [DEC_J][D2+1]
+  const int t = threadIdx.x, j = blockIdx.x * DEC_J + t;
+  const bool live = j < a.V;
+  for (int e = t; e < a.B * D2; e += DEC_J) zl[e] = a.z[e];
+  float wr[CD2 ? CD2 : DEC_MAXD2];
+  _Pragma("unroll") for (int k = 0; k < D2; ++k) wr[k] = live ? a.w[(long)j * D2 + k] : 0.f;
+  const float bias = live ? a.b[j] : 0.f;
+  __syncthreads();
+  if (PASS == 1) {
+    for (int b = 0; b < a.B; ++b) {
+      const float lg = live ? dec_logit<CD2>(wr, zl + b * D2, D2, bias) : -INFINITY;
+      const float m = block_max(lg, red);
+      const float s = block_sum(live ? expf(lg - m) : 0.f, red);
+      if (t == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = m; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = s; }
+    }
+  } else if (PASS == 2) {
+    for (int b = 0; b < a.B; ++b) {
+      float le = 0.f, dt = 0.f;
+      if (live) {
+        const float lp = dec_logit<CD2>(wr, zl + b * D2, D2, bias) - a.rowstat[b * 4] - a.rowstat[b * 4 + 1];
+        const float p = expf(lp);
+        const float tg = a.bow[(long)b * a.V + j] * (1.f - a.ls) + a.ls / a.V;
+        le = -(tg * fmaxf(lp, -100.f) + (1.f - tg) * fmaxf(log1pf(-p), -100.f));
+        dt = p * ((p - tg) / fmaxf((1.f - p) * p, 1e-12f));
+      }
+      le = block_sum(le, red);
+      dt = block_sum(dt, red);
+      if (t == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = le; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = dt; }
+    }
+  } else {
+    float dwr[CD2 ? CD2 : DEC_MAXD2];
+    _Pragma("unroll") for (int k = 0; k < D2; ++k) dwr[k] = 0.f;
+    float dbj = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+      float g = 0.f;
+      if (live) {
+        const float lp = dec_logit<CD2>(wr, zl + b * D2, D2, bias) - a.rowstat[b * 4] - a.rowstat[b * 4 + 1];
+        const float p = expf(lp);
+        const float tg = a.bow[(long)b * a.V + j] * (1.f - a.ls) + a.ls / a.V;
+        const float gp = (p - tg) / fmaxf((1.f - p) * p, 1e-12f);
+        g = p * (gp - a.rowstat[b * 4 + 2]) * a.gscale;
+        _Pragma("unroll") for (int k = 0; k < D2; ++k) dwr[k] = fmaf(g, zl[b * D2 + k], dwr[k]);
+        dbj += g;
+      }
+      dl[b * DEC_J + t] = g;
+    }
+    const int ws = D2 + 1;
+    _Pragma("unroll") for (int k = 0; k < D2; ++k) wl[t * ws + k] = wr[k];
+    if (live) {
+      _Pragma("unroll") for (int k = 0; k < D2; ++k) a.dw[(long)j * D2 + k] = dwr[k];
+      a.db[j] = dbj;
+    }
+    __syncthreads();
+    // dz_part[chunk][b][k] = sum_{j in chunk} dl[b][j] * W[j][k]
+    for (int e = t; e < a.B * D2; e += DEC_J) {
+      const int b = e / D2, k = e - b * D2;
+      float s = 0.f;
+      for (int jj = 0; jj < DEC_J; ++jj) s = fmaf(dl[b * DEC_J + jj], wl[jj * ws + k], s);
+      a.dz_part[(long)blockIdx.x * a.B * D2 + e] = s;
+    }
+  }
+}
+
+// combine pass-1 partials -> rowstat[b] = {M, log L}; pass-2 partials -> rowstat[b][2] = dot, terms
+__global__ __launch_bounds__(256) void decoder_combine_kernel(const float* __restrict__ part, int chunks, int B, int pass,
+                                                              float* __restrict__ rowstat, float* __restrict__ terms, float inv_bv) {
+  __shared__ float red[16];
+  float tot = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    if (pass == 1) {
+      float m = -INFINITY;
+      for (int c = 0; c < chunks; ++c) m = fmaxf(m, part[((long)c * B + b) * 2]);
+      float s = 0.f;
+      for (int c = 0; c < chunks; ++c) s += part[((long)c * B + b) * 2 + 1] * expf(part[((long)c * B + b) * 2] - m);
+      rowstat[b * 4] = m; rowstat[b * 4 + 1] = logf(s);
+    } else {
+      float le = 0.f, dt = 0.f;
+      for (int c = 0; c < chunks; ++c) { le += part[((long)c * B + b) * 2]; dt += part[((long)c * B + b) * 2 + 1]; }
+      rowstat[b * 4 + 2] = dt; rowstat[b * 4 + 3] = le;
+      tot += le;
+    }
+  }
+  if (pass == 2) {
+    tot = block_sum(tot, red);
+    if (threadIdx.x == 0) { terms[7] = tot * inv_bv; terms[8] = terms[0] + tot * inv_bv; }
+  }
+}
+
+// dlat = dlat_direct + [dz_e, dz_e*eps_e*exp(lv_e), dz_c, dz_c*eps_c*exp(lv_c)], dz = dz_core + sum_chunks dz_part
+__global__ __launch_bounds__(256) void tail_dlat_kernel(const float* __restrict__ dz_core, const float* __restrict__ dz_part, int chunks,
+                                                        const float* __restrict__ dlat_direct, const float* __restrict__ lat,
+                                                        const float* __restrict__ eps_e, const float* __restrict__ eps_c, int B, int D,
+                                                        float gout, float* __restrict__ dlat) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * 2 * D) return;
+  const int b = e / (2 * D), k = e - b * 2 * D;
+  float g = dz_core[e];
+  for (int c = 0; c < chunks; ++c) g += dz_part[(long)c * B * 2 * D + e];
+  const int side = k >= D, kk = k - side * D;
+  const float* row = lat + (long)b * 4 * D;
+  const float ep = side ? eps_c[kk] : eps_e[kk];
+  const float lv = row[(2 * side + 1) * D + kk];
+  dlat[(long)b * 4 * D + 2 * side * D + kk] = (dlat_direct[(long)b * 4 * D + 2 * side * D + kk] + g) * gout;
+  dlat[(long)b * 4 * D + (2 * side + 1) * D + kk] = (dlat_direct[(long)b * 4 * D + (2 * side + 1) * D + kk] + g * ep * expf(lv)) * gout;
+}
+
+// eval-mode pair probabilities (get_pair_preds :265-282): sigmoid(w . [mu_e + eps_e e^lv_e, mu_c + eps_c e^lv_c] + b)
+__global__ __launch_bounds__(256) void pair_prob_kernel(const float* __restrict__ lat, const float* __restrict__ eps_e,
+                                                        const float* __restrict__ eps_c, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int B, int D, float* __restrict__ prob) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* row = lat + (long)b * 4 * D;
+  float s = bias[0];
+  for (int k = 0; k < D; ++k) {
+    s = fmaf(w[k], row[k] + eps_e[k] * expf(row[D + k]), s);
+    s = fmaf(w[D + k], row[2 * D + k] + eps_c[k] * expf(row[3 * D + k]), s);
+  }
+  prob[b] = 1.0f / (1.0f + expf(-s));
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * s;
+}
+// scatter the CLS-row gradients into the [T, 768] gradient of the last encoder output (zeroed first)
+__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ dcls, int B, int S, float* __restrict__ dx) {
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < TH; k += 256) dx[(long)b * S * TH + k] = dcls[(long)b * TH + k];
+}
+
+}  // namespace carel
+
+using namespace carel;
+
+static size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
+
+struct TailWork {     // carve-up of the caller's f32 workspace
+  float* dz_core; float* dlat_direct; float* dlat; float* dpooled; float* dpre; float* part; float* rowstat; float* dz_part;
+  float* dcls; float* pair_dead;
+  size_t total;
+};
+static TailWork carve(float* base, int B, int D, int V) {
+  TailWork w; size_t o = 0;
+  const int chunks = (V + DEC_J - 1) / DEC_J;
+  auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += align_up(n); return p; };
+  w.dz_core = take((size_t)B * 2 * D); w.dlat_direct = take((size_t)B * 4 * D); w.dlat = take((size_t)B * 4 * D);
+  w.dpooled = take((size_t)B * TH); w.dpre = take((size_t)B * TH); w.part = take((size_t)chunks * B * 2);
+  w.rowstat = take((size_t)B * 4); w.dz_part = take((size_t)chunks * B * 2 * D); w.dcls = take((size_t)B * TH);
+  w.pair_dead = take(16);
+  w.total = o;
+  return w;
+}
+
+extern "C" int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim) {
+  return (int64_t)carve(nullptr, batch, ec_dim, bow_dim).total;
+}
+
+static int tail_check(const carel_tail_args* a, const char* who) {
+  if (!a) return set_error(CAREL_ERR_ARG, "%s: null args", who);
+  if (a->hidden != TH) return set_error(CAREL_ERR_SHAPE, "%s: hidden must be %d", who, TH);
+  if (a->batch < 1 || a->seq_len < 1) return set_error(CAREL_ERR_SHAPE, "%s: bad batch/seq_len", who);
+  if (a->ec_dim < 1 || a->ec_dim > 32 || a->e_classes < 1 || a->e_classes > 8)
+    return set_error(CAREL_ERR_SHAPE, "%s: ec_dim must be <= 32 and e_num_class <= 8", who);
+  if (!a->x_last_f32 || !a->pooler_w || !a->pooler_b || !a->pooled || !a->lat)
+    return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  for (int i = 0; i < 4; ++i) if (!a->head_w[i] || !a->head_b[i]) return set_error(CAREL_ERR_ARG, "%s: null latent head", who);
+  return CAREL_OK;
+}
+
+// pooler + latent heads:  pooled [B,768], lat [B,4D]
+extern "C" int carel_tail_latents(const carel_tail_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = tail_check(a, "carel_tail_latents");
+  if (rc) return rc;
+  PtrSet4 pp; for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; }
+  pp.w[0] = (const float*)a->pooler_w; pp.b[0] = (const float*)a->pooler_b;
+  hipLaunchKernelGGL(rowvec_linear_kernel<1>, dim3(TH / 4), dim3(256), 0, stream, (const float*)a->x_last_f32,
+                     (long)a->seq_len * TH, a->batch, TH, TH, pp, (float*)a->pooled, (long)TH);
+  PtrSet4 hp; for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = (const float*)a->head_b[i]; }
+  const int N = 4 * a->ec_dim;
+  hipLaunchKernelGGL(rowvec_linear_kernel<0>, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)a->pooled, (long)TH,
+                     a->batch, N, a->ec_dim, hp, (float*)a->lat, (long)N);
+  return check_launch("tail latents");
+}
+
+extern "C" int carel_pair_probs(const void* lat, const void* eps_e, const void* eps_c, const void* pair_w, const void* pair_b,
+                                int32_t batch, int32_t ec_dim, void* prob, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!lat || !eps_e || !eps_c || !pair_w || !pair_b || !prob || batch < 1) return set_error(CAREL_ERR_ARG, "carel_pair_probs: bad arguments");
+  hipLaunchKernelGGL(pair_prob_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, (const float*)lat, (const float*)eps_e,
+                     (const float*)eps_c, (const float*)pair_w, (const float*)pair_b, batch, ec_dim, (float*)prob);
+  return check_launch("pair_prob_kernel");
+}
+
+// losses + gradients of everything after the latents.  Needs carel_tail_latents() first.
+extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = tail_check(a, "carel_tail_losses");
+  if (rc) return rc;
+  const int B = a->batch, D = a->ec_dim, V = a->bow_dim;
+  if (V < 1) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: bow_dim must be positive");
+  if (2 * D > DEC_MAXD2) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: 2*ec_dim must be <= %d", DEC_MAXD2);
+  if (B > 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch must be <= 1024 per rank");
+  if (B < 2 && !a->z_global) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch must be >= 2 (MMD divides by n(n-1))");
+  if (!a->emo_w || !a->emo_b || !a->cau_w || !a->cau_b || !a->pair_w || !a->pair_b || !a->dec_w || !a->dec_b ||
+      !a->emo_labels || !a->cau_labels || !a->pair_labels || !a->bow || !a->eps_e || !a->eps_c || !a->z || !a->terms ||
+      !a->work || !a->d_emo_w || !a->d_emo_b || !a->d_cau_w || !a->d_cau_b || !a->d_pair_w || !a->d_pair_b || !a->d_dec_w ||
+      !a->d_dec_b)
+    return set_error(CAREL_ERR_ARG, "carel_tail_losses: null tensor");
+  TailWork w = carve((float*)a->work, B, D, V);
+  TailCore c;
+  c.B = B; c.D = D; c.EC = a->e_classes; c.lat = (const float*)a->lat; c.eps_e = (const float*)a->eps_e; c.eps_c = (const float*)a->eps_c;
+  c.emo_w = (const float*)a->emo_w; c.emo_b = (const float*)a->emo_b; c.cau_w = (const float*)a->cau_w; c.cau_b = (const float*)a->cau_b;
+  c.pair_w = (const float*)a->pair_w; c.pair_b = (const float*)a->pair_b;
+  c.emo_labels = (const long*)a->emo_labels; c.cau_labels = (const float*)a->cau_labels; c.pair_labels = (const float*)a->pair_labels;
+  c.w_mmd = a->w_mmd; c.w_emo = a->w_emo; c.w_cau = a->w_cau; c.w_pair = a->w_pair; c.kl_w = a->kl_weight; c.ls = a->label_smoothing;
+  c.d_emo = make_dropout(a->drop_seed, 100u, a->drop_p, a->drop_row_offset * (uint32_t)D);
+  c.d_cau = make_dropout(a->drop_seed, 101u, a->drop_p, a->drop_row_offset * (uint32_t)D);
+  c.d_pair = make_dropout(a->drop_seed, 102u, a->drop_p, a->drop_row_offset * (uint32_t)(2 * D));
+  c.alpha = a->mmd_alpha; c.mmd_eps = a->mmd_eps;
+  c.label_sum_override = (const float*)a->global_label_sum; c.n_override = (float)a->global_n;
+  c.z_global = (const float*)a->z_global; c.n_global = a->global_n; c.row_offset = a->global_row_offset;
+  c.mmd_grad_scale = a->mmd_grad_scale > 0.f ? a->mmd_grad_scale : 1.f;
+  if (c.z_global && (c.n_global < 2 || c.row_offset < 0 || c.row_offset + B > c.n_global))
+    return set_error(CAREL_ERR_ARG, "carel_tail_losses: inconsistent global batch description");
+  c.z = (float*)a->z; c.terms = (float*)a->terms; c.dz = w.dz_core; c.dlat_direct = w.dlat_direct;
+  c.d_emo_w = (float*)a->d_emo_w; c.d_emo_b = (float*)a->d_emo_b; c.d_cau_w = (float*)a->d_cau_w; c.d_cau_b = (float*)a->d_cau_b;
+  c.d_pair_w = (float*)a->d_pair_w; c.d_pair_b = (float*)a->d_pair_b; c.pair_dead = w.pair_dead;
+  const int nm = c.z_global ? c.n_global : B;
+  const size_t lds = sizeof(float) * (64 + 64 + (size_t)2 * B * 2 * D + (size_t)B * 8 + (size_t)B * 2 + ((2 * nm + 3) & ~3) + (size_t)2 * nm * (D | 1));
+  if (lds > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the single-workgroup tail (%zu B LDS)", lds);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)tail_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(tail_core_kernel, dim3(1), dim3(1024), lds, stream, c);
+  if ((rc = check_launch("tail_core_kernel"))) return rc;
+
+  DecArgs d;
+  d.B = B; d.D2 = 2 * D; d.V = V; d.z = (const float*)a->z; d.w = (const float*)a->dec_w; d.b = (const float*)a->dec_b;
+  d.bow = (const float*)a->bow; d.ls = a->label_smoothing; d.part = w.part; d.rowstat = w.rowstat; d.dz_part = w.dz_part;
+  d.dw = (float*)a->d_dec_w; d.db = (float*)a->d_dec_b; d.gscale = 1.0f / ((float)B * (float)V);
+  const int chunks = (V + DEC_J - 1) / DEC_J;
+  const size_t lds12 = sizeof(float) * ((size_t)B * 2 * D + 16);
+  const size_t lds3 = lds12 + sizeof(float) * ((size_t)B * DEC_J + (size_t)DEC_J * (2 * D + 1));
+  if (lds3 > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the decoder kernel");
+  if (lds3 > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)decoder_kernel<3, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decoder_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+#define DEC_LAUNCH(PASS, LDS)                                                                              \
+  do {                                                                                                  \
+    if (2 * D == 48) hipLaunchKernelGGL((decoder_kernel<PASS, 48>), dim3(chunks), dim3(DEC_J), LDS, stream, d); \
+    else hipLaunchKernelGGL((decoder_kernel<PASS, 0>), dim3(chunks), dim3(DEC_J), LDS, stream, d);      \
+  } while (0)
+  DEC_LAUNCH(1, lds12);
+  hipLaunchKernelGGL(decoder_combine_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.part, chunks, B, 1, w.rowstat, (float*)a->terms, 0.f);
+  DEC_LAUNCH(2, lds12);
+  hipLaunchKernelGGL(decoder_combine_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.part, chunks, B, 2, w.rowstat, (float*)a->terms, d.gscale);
+  DEC_LAUNCH(3, lds3);
+#undef DEC_LAUNCH
+  if ((rc = check_launch("decoder kernels"))) return rc;
+  // d(loss)/d lat, unscaled (grad_output is applied in carel_tail_backward)
+  hipLaunchKernelGGL(tail_dlat_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, stream, (const float*)w.dz_core, (const float*)w.dz_part,
+                     chunks, (const float*)w.dlat_direct, (const float*)a->lat, (const float*)a->eps_e, (const float*)a->eps_c, B, D, 1.0f, w.dlat);
+  return check_launch("tail_dlat_kernel");
+}
+
+// Back-propagate d(loss)/d lat through the latent heads and the pooler into the encoder output.
+// grad_out scales every gradient produced by carel_tail_losses for the non-head parameters on the host
+// side (they are linear in it); here it scales dlat.
+extern "C" int carel_tail_backward(const carel_tail_args* a, float grad_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = tail_check(a, "carel_tail_backward");
+  if (rc) return rc;
+  if (!a->work || !a->dx_last_f32 || !a->d_pooler_w || !a->d_pooler_b) return set_error(CAREL_ERR_ARG, "carel_tail_backward: null tensor");
+  const int B = a->batch, D = a->ec_dim, N = 4 * D;
+  TailWork w = carve((float*)a->work, B, D, a->bow_dim);
+  if (grad_out != 1.0f) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, (const float*)w.dlat, w.dlat, (long)B * N, grad_out);
+  }
+  PtrSet4 hp; OutSet4 ho;
+  for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = nullptr; ho.w[i] = (float*)a->d_head_w[i]; ho.b[i] = (float*)a->d_head_b[i]; }
+  if (ho.w[0] && ho.w[1] && ho.w[2] && ho.w[3])
+    hipLaunchKernelGGL(rowvec_wgrad_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)w.dlat, (long)N, (const float*)a->pooled,
+                       (long)TH, B, N, D, ho);
+  hipLaunchKernelGGL(rowvec_dgrad_kernel<0>, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.dlat, (long)N, B, N, D, hp,
+                     (const float*)nullptr, (float*)nullptr, w.dpooled, (long)TH);
+  PtrSet4 pp; OutSet4 po;
+  for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; po.w[i] = nullptr; po.b[i] = nullptr; }
+  pp.w[0] = (const float*)a->pooler_w; po.w[0] = (float*)a->d_pooler_w; po.b[0] = (float*)a->d_pooler_b;
+  hipLaunchKernelGGL(rowvec_dgrad_kernel<1>, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.dpooled, (long)TH, B, TH, TH, pp,
+                     (const float*)a->pooled, w.dpre, w.dcls, (long)TH);
+  hipLaunchKernelGGL(rowvec_wgrad_kernel, dim3(TH / 4), dim3(256), 0, stream, (const float*)w.dpre, (long)TH, (const float*)a->x_last_f32,
+                     (long)a->seq_len * TH, B, TH, TH, po);
+  hipMemsetAsync(a->dx_last_f32, 0, (size_t)B * a->seq_len * TH * sizeof(float), stream);
+  hipLaunchKernelGGL(scatter_cls_kernel, dim3(B), dim3(256), 0, stream, (const float*)w.dcls, B, a->seq_len, (float*)a->dx_last_f32);
+  return check_launch("tail backward");
+}

@@ -155,6 +155,66 @@ int carel_attention_fwd(const carel_attn_args* args, void* stream);
 int carel_attention_bwd(const carel_attn_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * VAE tail of DrlClassifier.forward (ref :202-261): pooler -> latent heads -> sample -> emotion CE,
+ * cause BCE, pair BCE-with-logits(pos_weight), RBF-MMD, annealed KL, decoder softmax + BCE; and the
+ * backward of all of it.  fp32 throughout.
+ *
+ *   carel_tail_latents : pooled = tanh(W_p x_last[:,0] + b_p) (HF BertPooler); lat = [mu_e|lv_e|mu_c|lv_c]
+ *                        (ref :312-336).  Also the front half of get_pair_preds (ref :266-275).
+ *   carel_tail_losses  : z, terms[0..8] and d(loss)/d(parameter) for the classifier heads + decoder,
+ *                        d(loss)/d lat kept in `work`.   terms = {partial, mmd, emo, cau, pair, kl_e,
+ *                        kl_c, rec, loss}; loss = w_mmd*(-mmd) + w_emo*emo + w_cau*cau + w_pair*pair +
+ *                        kl_e + kl_c + rec (ref :256-261); kl_* already multiplied by kl_weight.
+ *   carel_tail_backward: latent heads + pooler backward -> d_head_*, d_pooler_*, dx_last (zero except
+ *                        the CLS rows), all scaled by grad_out.
+ *   carel_pair_probs   : sigmoid(pair_classifier([mu_e + eps_e e^lv_e, mu_c + eps_c e^lv_c])) (ref :277-282)
+ * Data-parallel hooks (all optional): global_label_sum/global_n give the pos_weight of the GLOBAL batch;
+ * z_global [global_n, 2*ec_dim] (all-gathered samples) + global_row_offset make the MMD the global-batch
+ * statistic, differentiated for the local rows and scaled by mmd_grad_scale (= world size when gradients
+ * are averaged over ranks).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_tail_args {
+  int32_t batch, seq_len, hidden, ec_dim, e_classes, bow_dim;
+  const void* x_last_f32;            /* f32 [B*S, 768] last encoder LayerNorm output */
+  const void* pooler_w; const void* pooler_b;
+  const void* head_w[4]; const void* head_b[4];   /* emotion_mu, emotion_log_var, cause_mu, cause_log_var */
+  const void* emo_w; const void* emo_b;
+  const void* cau_w; const void* cau_b;
+  const void* pair_w; const void* pair_b;
+  const void* dec_w; const void* dec_b;
+  const void* emo_labels;            /* int64 [B] */
+  const void* cau_labels;            /* f32 [B] */
+  const void* pair_labels;           /* f32 [B] */
+  const void* bow;                   /* f32 [B, bow_dim] */
+  const void* eps_e; const void* eps_c; /* f32 [ec_dim] */
+  float w_mmd, w_emo, w_cau, w_pair, kl_weight, label_smoothing;
+  float drop_p; uint32_t drop_seed, drop_row_offset;
+  float mmd_alpha, mmd_eps;
+  const void* global_label_sum;      /* f32 [1] or NULL */
+  int32_t global_n, global_row_offset;
+  const void* z_global;              /* f32 [global_n, 2*ec_dim] or NULL */
+  float mmd_grad_scale;
+  /* outputs */
+  void* pooled;                      /* f32 [B, 768] */
+  void* lat;                         /* f32 [B, 4*ec_dim] */
+  void* z;                           /* f32 [B, 2*ec_dim] */
+  void* terms;                       /* f32 [16] */
+  void* work;                        /* f32 [carel_tail_workspace_floats(...)] */
+  void* d_emo_w; void* d_emo_b; void* d_cau_w; void* d_cau_b; void* d_pair_w; void* d_pair_b;
+  void* d_dec_w; void* d_dec_b;
+  void* d_head_w[4]; void* d_head_b[4];   /* may be NULL (heads are not optimised, ref :292-295) */
+  void* d_pooler_w; void* d_pooler_b;
+  void* dx_last_f32;                 /* f32 [B*S, 768] */
+} carel_tail_args;
+
+int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim);
+int carel_tail_latents(const carel_tail_args* args, void* stream);
+int carel_tail_losses(const carel_tail_args* args, void* stream);
+int carel_tail_backward(const carel_tail_args* args, float grad_out, void* stream);
+int carel_pair_probs(const void* lat, const void* eps_e, const void* eps_c, const void* pair_w, const void* pair_b,
+                     int32_t batch, int32_t ec_dim, void* prob, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RBF-MMD statistic.  Replaces MMDStatistic.__call__ (ref :547-569) + pdist (ref :580-589) and
  * their autograd backward.  mmd = 2*a01*sum(K12) + a00*(sum(K11)-tr K11) + a11*(sum(K22)-tr K22),
  * K = sum_alpha exp(-alpha * (eps + |d2|)), a00 = 1/(n1(n1-1)), a11 = 1/(n2(n2-1)), a01 = -1/(n1 n2).
