@@ -76,6 +76,38 @@ class TailArgs(C.Structure):
                 ("d_pooler_w", C.c_void_p), ("d_pooler_b", C.c_void_p), ("dx_last_f32", C.c_void_p)]
 
 
+class AdamArgs(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("shadow_bf16", C.c_void_p), ("n", C.c_int64), ("step", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("grad_scale", C.c_float), ("skip_lo", C.c_int64), ("skip_hi", C.c_int64), ("skip_flag", C.c_void_p)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_b", "out_w", "out_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b",
+                                          "ffn2_w", "ffn2_b", "ln2_g", "ln2_b")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = LayerParams._fields_
+
+
+class EncoderArgs(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("seq_len", C.c_int32), ("n_layers", C.c_int32), ("hidden", C.c_int32),
+                ("heads", C.c_int32), ("intermediate", C.c_int32),
+                ("vocab_size", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32), ("roberta", C.c_int32),
+                ("pad_id", C.c_int32), ("inference", C.c_int32),
+                ("ln_eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float),
+                ("drop_seed", C.c_uint32), ("drop_row_offset", C.c_uint32),
+                ("input_ids", C.c_void_p), ("attention_mask", C.c_void_p), ("token_type_ids", C.c_void_p),
+                ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p),
+                ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p),
+                ("layers", C.POINTER(LayerParams)), ("act", C.c_void_p), ("scratch", C.c_void_p),
+                ("layer_grads", C.POINTER(LayerGrads)),
+                ("d_word_emb", C.c_void_p), ("d_pos_emb", C.c_void_p), ("d_type_emb", C.c_void_p),
+                ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
 
@@ -102,8 +134,18 @@ SIGNATURES = {
     "carel_tail_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "carel_tail_latents": (C.c_int, [C.POINTER(TailArgs), C.c_void_p]),
     "carel_tail_losses": (C.c_int, [C.POINTER(TailArgs), C.c_void_p]),
-    "carel_tail_backward": (C.c_int, [C.POINTER(TailArgs), C.c_float, C.c_void_p]),
+    "carel_tail_backward": (C.c_int, [C.POINTER(TailArgs), C.c_void_p, C.c_void_p]),
+    "carel_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "carel_tail_pair_dead_offset": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "carel_pair_probs": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "carel_adam_step": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
+    "carel_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "carel_encoder_act_bytes": (C.c_int64, [C.c_int32] * 4),
+    "carel_encoder_scratch_bytes": (C.c_int64, [C.c_int32] * 2),
+    "carel_encoder_x_last": (C.c_void_p, [C.POINTER(EncoderArgs)]),
+    "carel_encoder_forward": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),
+    "carel_encoder_backward_layer": (C.c_int, [C.POINTER(EncoderArgs), C.c_int32, C.c_void_p]),
+    "carel_encoder_backward_embeddings": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),
     "carel_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "carel_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
 }

@@ -1,0 +1,99 @@
+// Fused Adam over a flat fp32 parameter buffer + bf16 shadow refresh.  Replaces
+// torch.optim.Adam(model.get_params(), lr).step() (drl_classifier_ec_mmd_final_mul.py:936, :842): defaults
+// betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad, dense (rows with zero gradient still move).
+// HBM-bound: 16 B read + 12 B written per parameter (+2 B for the bf16 copy the MFMA GEMMs consume).
+#include "carel_hip_internal.h"
+
+namespace carel {
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; bf16_t* shadow;
+  long n;
+  float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, grad_scale;
+  long skip_lo, skip_hi; const float* skip_flag;     // [skip_lo, skip_hi) untouched when *skip_flag != 0
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a) {
+  g *= a.grad_scale;
+  m = m + (1.0f - a.b1) * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.b2 + (1.0f - a.b2) * g * g;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;  // (sqrt(v) / sqrt(bc2)).add_(eps)
+  p = p - a.lr_over_bc1 * (m / denom);                   // param.addcdiv_(exp_avg, denom, value=-lr/bc1)
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  const bool skipping = a.skip_flag && a.skip_flag[0] != 0.f;
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < a.n; i += stride) {
+    if (i + 4 <= a.n) {
+      float4 p = *(float4*)(a.p + i);
+      const float4 g = *(const float4*)(a.g + i);
+      float4 m = *(float4*)(a.m + i), v = *(float4*)(a.v + i);
+      const bool s0 = skipping && i + 0 >= a.skip_lo && i + 0 < a.skip_hi, s1 = skipping && i + 1 >= a.skip_lo && i + 1 < a.skip_hi;
+      const bool s2 = skipping && i + 2 >= a.skip_lo && i + 2 < a.skip_hi, s3 = skipping && i + 3 >= a.skip_lo && i + 3 < a.skip_hi;
+      if (!s0) adam1(p.x, g.x, m.x, v.x, a);
+      if (!s1) adam1(p.y, g.y, m.y, v.y, a);
+      if (!s2) adam1(p.z, g.z, m.z, v.z, a);
+      if (!s3) adam1(p.w, g.w, m.w, v.w, a);
+      *(float4*)(a.p + i) = p; *(float4*)(a.m + i) = m; *(float4*)(a.v + i) = v;
+      if (a.shadow) { uint2 o = {pack2bf(p.x, p.y), pack2bf(p.z, p.w)}; *(uint2*)(a.shadow + i) = o; }
+    } else {
+      for (long j = i; j < a.n; ++j) {
+        if (skipping && j >= a.skip_lo && j < a.skip_hi) continue;
+        float p = a.p[j], m = a.m[j], v = a.v[j];
+        adam1(p, a.g[j], m, v, a);
+        a.p[j] = p; a.m[j] = m; a.v[j] = v;
+        if (a.shadow) a.shadow[j] = f2bf(p);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 p = *(const float4*)(src + i);
+      uint2 o = {pack2bf(p.x, p.y), pack2bf(p.z, p.w)};
+      *(uint2*)(dst + i) = o;
+    } else {
+      for (long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+    }
+  }
+}
+
+}  // namespace carel
+
+using namespace carel;
+
+static unsigned grid_for(long n) {
+  long blocks = (n / 4 + 255) / 256;
+  return (unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+}
+
+extern "C" int carel_adam_step(const carel_adam_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || a->n <= 0) return set_error(CAREL_ERR_ARG, "carel_adam_step: bad arguments");
+  if (a->step < 1) return set_error(CAREL_ERR_ARG, "carel_adam_step: step must be >= 1");
+  if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->exp_avg | (uintptr_t)a->exp_avg_sq) & 15)
+    return set_error(CAREL_ERR_ARG, "carel_adam_step: buffers must be 16-byte aligned");
+  AdamArgs k;
+  k.p = (float*)a->param; k.g = (const float*)a->grad; k.m = (float*)a->exp_avg; k.v = (float*)a->exp_avg_sq;
+  k.shadow = (bf16_t*)a->shadow_bf16; k.n = a->n;
+  const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+  k.lr_over_bc1 = (float)((double)a->lr / bc1); k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  k.b1 = a->beta1; k.b2 = a->beta2; k.eps = a->eps; k.grad_scale = a->grad_scale == 0.f ? 1.f : a->grad_scale;
+  k.skip_lo = a->skip_lo; k.skip_hi = a->skip_hi; k.skip_flag = (const float*)a->skip_flag;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(k.n)), dim3(256), 0, stream, k);
+  return check_launch("adam_kernel");
+}
+
+extern "C" int carel_cast_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !dst || n <= 0) return set_error(CAREL_ERR_ARG, "carel_cast_f32_to_bf16: bad arguments");
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return set_error(CAREL_ERR_ARG, "carel_cast_f32_to_bf16: misaligned buffers");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float*)src, (bf16_t*)dst, (long)n);
+  return check_launch("cast_bf16_kernel");
+}

@@ -1,0 +1,249 @@
+// Host-side orchestration of the BERT-base encoder forward / backward (12 x {QKV GEMM, attention,
+// out-proj GEMM + dropout + residual, LayerNorm, FFN1 GEMM + GELU, FFN2 GEMM + dropout + residual,
+// LayerNorm}) over caller-owned activation and scratch buffers.  Replaces
+// `self.encoder(input_ids, attention_mask, token_type_ids)` (drl_classifier_ec_mmd_final_mul.py:202-206,
+// transformers BertModel.forward) and the encoder part of `loss.backward()` (:841).
+// Nothing is allocated here; every call only enqueues kernels on the caller's stream.
+#include "carel_hip_internal.h"
+
+using namespace carel;
+
+namespace {
+
+constexpr int EH = 768, EI = 3072, ENH = 12;
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct LayerAct {
+  char* xin_bf16; char* qkv; char* lse; char* ctx; char* h1; char* st1; char* x1_bf16; char* u; char* g; char* h2; char* st2;
+};
+struct ActLayout {
+  size_t per_layer, total;
+  size_t o_xin, o_qkv, o_lse, o_ctx, o_h1, o_st1, o_x1, o_u, o_g, o_h2, o_st2;
+  size_t o_embst, o_xa, o_xb, o_layers;
+};
+
+ActLayout act_layout(long B, long S, int L, int inference) {
+  const size_t T = (size_t)B * S;
+  ActLayout a; size_t o = 0;
+  a.o_xin = o; o += al(T * EH * 2);
+  a.o_qkv = o; o += al(T * 3 * EH * 2);
+  a.o_lse = o; o += al((size_t)B * ENH * S * 4);
+  a.o_ctx = o; o += al(T * EH * 2);
+  a.o_h1 = o; o += al(T * EH * 4);
+  a.o_st1 = o; o += al(T * 2 * 4);
+  a.o_x1 = o; o += al(T * EH * 2);
+  a.o_u = o; o += al(T * EI * 2);
+  a.o_g = o; o += al(T * EI * 2);
+  a.o_h2 = o; o += al(T * EH * 4);
+  a.o_st2 = o; o += al(T * 2 * 4);
+  a.per_layer = o;
+  size_t g = 0;
+  a.o_embst = g; g += al(T * 2 * 4);
+  a.o_xa = g; g += al(T * EH * 4);
+  a.o_xb = g; g += al(T * EH * 4);
+  a.o_layers = g;
+  a.total = g + a.per_layer * (inference ? 1 : (size_t)L);
+  return a;
+}
+
+LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
+  char* p = base + a.o_layers + (inference ? 0 : (size_t)l * a.per_layer);
+  LayerAct r;
+  r.xin_bf16 = p + a.o_xin; r.qkv = p + a.o_qkv; r.lse = p + a.o_lse; r.ctx = p + a.o_ctx; r.h1 = p + a.o_h1; r.st1 = p + a.o_st1;
+  r.x1_bf16 = p + a.o_x1; r.u = p + a.o_u; r.g = p + a.o_g; r.h2 = p + a.o_h2; r.st2 = p + a.o_st2;
+  return r;
+}
+
+struct Scratch { char* dy; char* dyb; char* du; char* dctx; char* dqkv; char* slabs; char* part; };
+struct ScratchLayout { size_t o_dy, o_dyb, o_du, o_dctx, o_dqkv, o_slabs, o_part, total; };
+
+int wgrad_splits(long T, int M, int N) {
+  const int tiles = (M / 128) * (N / 128);
+  int s = 1;
+  while (tiles * s < 512 && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
+  return s;
+}
+
+ScratchLayout scratch_layout(long B, long S) {
+  const size_t T = (size_t)B * S;
+  ScratchLayout s; size_t o = 0;
+  s.o_dy = o; o += al(T * EH * 4);
+  s.o_dyb = o; o += al(T * EH * 2);
+  s.o_du = o; o += al(T * EI * 2);
+  s.o_dctx = o; o += al(T * EH * 2);
+  s.o_dqkv = o; o += al(T * 3 * EH * 2);
+  size_t slab = 0;
+  const int shapes[4][2] = {{EH, EI}, {EI, EH}, {EH, EH}, {3 * EH, EH}};
+  for (auto& sh : shapes) { size_t n = (size_t)wgrad_splits((long)T, sh[0], sh[1]) * sh[0] * sh[1] * 4; slab = n > slab ? n : slab; }
+  s.o_slabs = o; o += al(slab);
+  size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;
+  const size_t cs = ((T + 255) / 256) * EI * 4;
+  part = part > cs ? part : cs;
+  s.o_part = o; o += al(part);
+  s.total = o;
+  return s;
+}
+
+Scratch scratch_of(const ScratchLayout& l, char* b) {
+  Scratch s; s.dy = b + l.o_dy; s.dyb = b + l.o_dyb; s.du = b + l.o_du; s.dctx = b + l.o_dctx; s.dqkv = b + l.o_dqkv;
+  s.slabs = b + l.o_slabs; s.part = b + l.o_part;
+  return s;
+}
+
+int enc_check(const carel_encoder_args* a, const char* who) {
+  if (!a) return set_error(CAREL_ERR_ARG, "%s: null args", who);
+  if (a->hidden != EH || a->heads != ENH || a->intermediate != EI)
+    return set_error(CAREL_ERR_SHAPE, "%s: only the BERT-base geometry (768/12/3072) is supported", who);
+  if (a->batch < 1 || a->n_layers < 1) return set_error(CAREL_ERR_SHAPE, "%s: bad batch / n_layers", who);
+  if (a->seq_len < 32 || a->seq_len > 128 || (a->seq_len & 31)) return set_error(CAREL_ERR_SHAPE, "%s: seq_len must be 32/64/96/128", who);
+  if (((long)a->batch * a->seq_len) % 128) return set_error(CAREL_ERR_SHAPE, "%s: batch*seq_len must be a multiple of 128 (pad the batch)", who);
+  if (!a->input_ids || !a->layers || !a->act) return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  return CAREL_OK;
+}
+
+int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
+              void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
+              uint32_t off, float p, void* stream) {
+  carel_gemm_args g;
+  g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
+  g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
+  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p;
+  return carel_gemm_bf16(&g, stream);
+}
+
+// dW[M,N] = A^T[M x T] * B[T x N]  (A = dY [T,M], B = X [T,N])  via split-K slabs
+int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs, void* dW, void* stream) {
+  const int splits = wgrad_splits(T, M, N);
+  int rc = gemm_call(dY, X, M, N, M, N, (int)T, CAREL_GEMM_TN, CAREL_EPI_SLAB_F32, splits, nullptr, nullptr, slabs, nullptr, nullptr,
+                     nullptr, 0, 0, 0, 0.f, stream);
+  if (rc) return rc;
+  return carel_slab_reduce_f32(slabs, dW, (int64_t)M * N, splits, 0, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t carel_encoder_act_bytes(int32_t batch, int32_t seq_len, int32_t n_layers, int32_t inference) {
+  return (int64_t)act_layout(batch, seq_len, n_layers, inference).total;
+}
+extern "C" int64_t carel_encoder_scratch_bytes(int32_t batch, int32_t seq_len) {
+  return (int64_t)scratch_layout(batch, seq_len).total;
+}
+extern "C" void* carel_encoder_x_last(const carel_encoder_args* a) {
+  if (!a || !a->act) return nullptr;
+  const ActLayout l = act_layout(a->batch, a->seq_len, a->n_layers, a->inference);
+  return (char*)a->act + l.o_xa;
+}
+
+static carel_embed_args embed_args_of(const carel_encoder_args* a, const ActLayout& l, const LayerAct& first) {
+  carel_embed_args e;
+  e.input_ids = a->input_ids; e.token_type_ids = a->token_type_ids; e.word_emb = a->word_emb; e.pos_emb = a->pos_emb;
+  e.type_emb = a->type_emb; e.ln_gamma = a->emb_ln_g; e.ln_beta = a->emb_ln_b; e.ln_eps = a->ln_eps;
+  e.batch = a->batch; e.seq_len = a->seq_len; e.hidden = EH; e.vocab_size = a->vocab_size; e.max_pos = a->max_pos;
+  e.type_vocab = a->type_vocab; e.roberta = a->roberta; e.pad_id = a->pad_id;
+  e.drop_seed = a->drop_seed; e.drop_idx_offset = a->drop_row_offset * (uint32_t)(a->seq_len * EH); e.drop_p = a->hidden_dropout;
+  e.x_f32 = (char*)a->act + l.o_xa; e.x_bf16 = first.xin_bf16; e.stats = (char*)a->act + l.o_embst;
+  return e;
+}
+
+extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) {
+  int rc = enc_check(a, "carel_encoder_forward");
+  if (rc) return rc;
+  if (!a->word_emb || !a->pos_emb || !a->type_emb || !a->emb_ln_g || !a->emb_ln_b) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: null embedding tensor");
+  const long B = a->batch, S = a->seq_len, T = B * S;
+  const ActLayout l = act_layout(B, S, a->n_layers, a->inference);
+  char* base = (char*)a->act;
+  char* xa = base + l.o_xa;
+  char* xb = base + l.o_xb;
+  const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
+  LayerAct la = layer_act(l, base, 0, a->inference);
+  carel_embed_args e = embed_args_of(a, l, la);
+  if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
+  for (int i = 0; i < a->n_layers; ++i) {
+    const carel_layer_params& w = a->layers[i];
+    la = layer_act(l, base, i, a->inference);
+    if ((rc = gemm_call(la.xin_bf16, w.qkv_w, EH, EH, (int)T, 3 * EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_BF16, 1, la.qkv, nullptr, nullptr,
+                        w.qkv_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+    carel_attn_args at;
+    at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
+    at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
+    at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
+    if ((rc = carel_attention_fwd(&at, stream))) return rc;
+    if ((rc = gemm_call(la.ctx, w.out_w, EH, EH, (int)T, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
+                        w.out_b, xa, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream))) return rc;
+    if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, T, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
+    if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)T, EI, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_GELU, 1, la.u, la.g, nullptr,
+                        w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+    if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)T, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream))) return rc;
+    void* next_bf16 = nullptr;
+    if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16;
+    if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, T, EH, xa, next_bf16, la.st2, stream))) return rc;
+  }
+  return CAREL_OK;
+}
+
+// Backward of encoder layer `layer`.  a->dx holds d(loss)/d(layer output) on entry and d(loss)/d(layer
+// input) on return.  Writes every gradient of a->layer_grads[layer].
+extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t layer, void* stream) {
+  int rc = enc_check(a, "carel_encoder_backward_layer");
+  if (rc) return rc;
+  if (a->inference) return set_error(CAREL_ERR_ARG, "carel_encoder_backward_layer: forward ran in inference mode (no saved activations)");
+  if (layer < 0 || layer >= a->n_layers || !a->layer_grads || !a->scratch || !a->dx)
+    return set_error(CAREL_ERR_ARG, "carel_encoder_backward_layer: bad layer index or null buffer");
+  const long B = a->batch, S = a->seq_len, T = B * S;
+  const ActLayout l = act_layout(B, S, a->n_layers, 0);
+  const LayerAct la = layer_act(l, (char*)a->act, layer, 0);
+  const Scratch s = scratch_of(scratch_layout(B, S), (char*)a->scratch);
+  const carel_layer_params& w = a->layers[layer];
+  const carel_layer_grads& g = a->layer_grads[layer];
+  const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
+  // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
+  if ((rc = carel_layernorm_bwd(a->dx, la.h2, la.st2, w.ln2_g, T, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, s.dy, s.dyb,
+                                g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
+  // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
+  if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)T, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
+                      nullptr, la.u, 0, 0, 0, 0.f, stream))) return rc;
+  if ((rc = wgrad_call(s.dyb, la.g, T, EH, EI, s.slabs, g.ffn2_w, stream))) return rc;
+  if ((rc = carel_colsum_bf16(s.du, EI, T, EI, g.ffn1_b, 0, s.part, stream))) return rc;
+  // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
+  if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)T, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
+                      nullptr, 0, 0, 0, 0.f, stream))) return rc;
+  if ((rc = wgrad_call(s.du, la.x1_bf16, T, EI, EH, s.slabs, g.ffn1_w, stream))) return rc;
+  // LN1 backward
+  if ((rc = carel_layernorm_bwd(a->dx, la.h1, la.st1, w.ln1_g, T, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, s.dy, s.dyb,
+                                g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
+  // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
+  if ((rc = gemm_call(s.dyb, w.out_w, EH, EH, (int)T, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, s.dctx, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+  if ((rc = wgrad_call(s.dyb, la.ctx, T, EH, EH, s.slabs, g.out_w, stream))) return rc;
+  // attention backward
+  carel_attn_args at;
+  at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = s.dctx; at.dqkv = s.dqkv;
+  at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
+  at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * layer; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
+  if ((rc = carel_attention_bwd(&at, stream))) return rc;
+  if ((rc = carel_colsum_bf16(s.dqkv, 3 * EH, T, 3 * EH, g.qkv_b, 0, s.part, stream))) return rc;
+  // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
+  if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
+                      s.dy, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+  return wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, stream);
+}
+
+// Backward of the embedding block: a->dx = d(loss)/d(embedding output).  d_word_emb / d_pos_emb are
+// zeroed here and then accumulated with float atomics.
+extern "C" int carel_encoder_backward_embeddings(const carel_encoder_args* a, void* stream) {
+  int rc = enc_check(a, "carel_encoder_backward_embeddings");
+  if (rc) return rc;
+  if (a->inference || !a->scratch || !a->dx || !a->d_word_emb || !a->d_pos_emb || !a->d_type_emb || !a->d_emb_ln_g || !a->d_emb_ln_b)
+    return set_error(CAREL_ERR_ARG, "carel_encoder_backward_embeddings: null buffer or inference-mode forward");
+  const long B = a->batch, S = a->seq_len;
+  const ActLayout l = act_layout(B, S, a->n_layers, 0);
+  const LayerAct la = layer_act(l, (char*)a->act, 0, 0);
+  const Scratch s = scratch_of(scratch_layout(B, S), (char*)a->scratch);
+  carel_embed_args e = embed_args_of(a, l, la);
+  hipError_t he = hipMemsetAsync(a->d_word_emb, 0, (size_t)a->vocab_size * EH * 4, (hipStream_t)stream);
+  if (he == hipSuccess) he = hipMemsetAsync(a->d_pos_emb, 0, (size_t)a->max_pos * EH * 4, (hipStream_t)stream);
+  if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_embeddings: memset: %s", hipGetErrorString(he));
+  return carel_embed_ln_bwd(&e, a->dx, a->d_word_emb, a->d_pos_emb, a->d_type_emb, a->d_emb_ln_g, a->d_emb_ln_b, s.part, stream);
+}

@@ -456,9 +456,12 @@ __global__ __launch_bounds__(256) void pair_prob_kernel(const float* __restrict_
   prob[b] = 1.0f / (1.0f + expf(-s));
 }
 
-__global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float s) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[i] * s;
+// x[i] *= *scale (device scalar: the grad_output of loss.backward(), no host sync needed)
+__global__ void scale_inplace_kernel(float* __restrict__ x, long n, const float* __restrict__ scale) {
+  const float s = scale[0];
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) x[i] *= s;
 }
 // scatter the CLS-row gradients into the [T, 768] gradient of the last encoder output (zeroed first)
 __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ dcls, int B, int S, float* __restrict__ dx) {
@@ -606,17 +609,31 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
 }
 
 // Back-propagate d(loss)/d lat through the latent heads and the pooler into the encoder output.
-// grad_out scales every gradient produced by carel_tail_losses for the non-head parameters on the host
-// side (they are linear in it); here it scales dlat.
-extern "C" int carel_tail_backward(const carel_tail_args* a, float grad_out, void* stream_) {
+// grad_out_dev (device f32 scalar, or NULL for 1.0) is the upstream gradient of the loss: it scales dlat
+// here; the classifier / decoder gradients written by carel_tail_losses are scaled by the caller with
+// carel_scale_f32 (they are linear in it).
+extern "C" int carel_scale_f32(void* x, int64_t n, const void* scale_dev, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !scale_dev || n <= 0) return set_error(CAREL_ERR_ARG, "carel_scale_f32: bad arguments");
+  long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (float*)x, (long)n, (const float*)scale_dev);
+  return check_launch("scale_inplace_kernel");
+}
+
+extern "C" int64_t carel_tail_pair_dead_offset(int32_t batch, int32_t ec_dim, int32_t bow_dim) {
+  TailWork w = carve((float*)nullptr + 1, batch, ec_dim, bow_dim);   // offsets relative to a fake base
+  return (int64_t)(w.pair_dead - ((float*)nullptr + 1));
+}
+
+extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_out_dev, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = tail_check(a, "carel_tail_backward");
   if (rc) return rc;
   if (!a->work || !a->dx_last_f32 || !a->d_pooler_w || !a->d_pooler_b) return set_error(CAREL_ERR_ARG, "carel_tail_backward: null tensor");
   const int B = a->batch, D = a->ec_dim, N = 4 * D;
   TailWork w = carve((float*)a->work, B, D, a->bow_dim);
-  if (grad_out != 1.0f) {
-    hipLaunchKernelGGL(scale_copy_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, (const float*)w.dlat, w.dlat, (long)B * N, grad_out);
+  if (grad_out_dev) {
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, w.dlat, (long)B * N, (const float*)grad_out_dev);
   }
   PtrSet4 hp; OutSet4 ho;
   for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = nullptr; ho.w[i] = (float*)a->d_head_w[i]; ho.b[i] = (float*)a->d_head_b[i]; }

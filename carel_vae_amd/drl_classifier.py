@@ -1,0 +1,668 @@
+"""`DrlClassifier`, `MMDStatistic`, `pdist` with the module surface of the reference's
+drl_classifier_ec_mmd_final_mul.py (:149-596), executed by the HIP kernels of libcarel_hip.so.
+
+PyTorch's role here is autograd *glue* and memory: one `torch.autograd.Function` spans the whole training
+forward (encoder + VAE tail -> scalar loss); its backward enqueues the HIP backward and leaves the
+gradients in a flat fp32 buffer that every `Parameter.grad` aliases.  There is no eager/CPU fallback:
+calling the model with CPU tensors raises.
+"""
+import ctypes as C
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+H, I_FF, NH = 768, 3072, 12
+
+DEFAULT_OPT = dict(language="zh", max_len=128, e_num_class=6, c_num_class=1, pair_num_class=1, ec_dim=24, bert_dim=768,
+                   kl_ann_iterations=20000, epochs=20, batch_size=64, ec_kl_lambda=0.03, label_smoothing=0.1,
+                   mmd_loss_weight=30.0, emo_mul_loss_weight=10.0, cau_mul_loss_weight=10.0, pair_mul_loss_weight=30.0,
+                   dropout=0.5, epsilon=1e-8, vae_lr=1e-5, pair_bow_dim=23771, self_iteration=50, self_epochs=10,
+                   self_strategy="random", best_model_path="ECPE_model/best_cause_pair_model", model_id="carel")
+
+
+def make_opt(**kw):
+    """The reference's argparse namespace (:30-61) with its defaults."""
+    d = dict(DEFAULT_OPT)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def encoder_config(language="zh", **kw):
+    """BERT-base geometry of `hfl/chinese-roberta-wwm-ext` (:159) or `roberta-base` (:162)."""
+    if language == "en":
+        cfg = dict(vocab_size=50265, max_pos=514, type_vocab=1, ln_eps=1e-5, roberta=1, pad_id=1)
+    else:
+        cfg = dict(vocab_size=21128, max_pos=512, type_vocab=2, ln_eps=1e-12, roberta=0, pad_id=0)
+    cfg.update(layers=12, hidden_dropout=0.1, attn_dropout=0.1)
+    cfg.update(kw)
+    return SimpleNamespace(**cfg)
+
+
+# ----------------------------------------------------------------------------------------------
+# module tree that reproduces the reference's state_dict key names
+# ----------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    """A parameter holder named like the HF / nn.Linear module it stands for (weight [, bias])."""
+
+    def __init__(self, wshape, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(wshape))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(wshape[0]))
+
+
+class _Self(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.query, self.key, self.value = _Holder((H, H)), _Holder((H, H)), _Holder((H, H))
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.dense = _Holder((H, k))
+        self.LayerNorm = _Holder((H,))
+
+
+class _Attention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.self = _Self()
+        self.output = _SelfOutput(H)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.dense = _Holder((I_FF, H))
+
+
+class _Layer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.attention = _Attention()
+        self.intermediate = _Intermediate()
+        self.output = _SelfOutput(I_FF)
+
+
+class _Stack(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer() for _ in range(n)])
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.word_embeddings = _Holder((cfg.vocab_size, H), bias=False)
+        self.position_embeddings = _Holder((cfg.max_pos, H), bias=False)
+        self.token_type_embeddings = _Holder((cfg.type_vocab, H), bias=False)
+        self.LayerNorm = _Holder((H,))
+
+
+class _Pooler(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.dense = _Holder((H, H))
+
+
+class CarelEncoder(nn.Module):
+    """Parameter container with the key names of transformers BertModel / RobertaModel."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = _Embeddings(cfg)
+        self.encoder = _Stack(cfg.layers)
+        self.pooler = _Pooler()
+
+
+def _init_like_reference(model, gen=None):
+    """HF init for the encoder (normal(0, 0.02), LayerNorm 1/0, zero biases) and nn.Linear default init
+    for the heads; pretrained checkpoints are loaded with load_state_dict (same key names)."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.startswith("encoder."):
+                if "LayerNorm.weight" in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(0.0, 0.02, generator=gen)
+            elif name.endswith(".weight"):
+                bound = 1.0 / math.sqrt(p.shape[1])
+                p.uniform_(-bound, bound, generator=gen)
+            else:
+                w = dict(model.named_parameters())[name[:-5] + ".weight"]
+                bound = 1.0 / math.sqrt(w.shape[1])
+                p.uniform_(-bound, bound, generator=gen)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd glue
+# ----------------------------------------------------------------------------------------------
+class _TrainLoss(torch.autograd.Function):
+    """Whole-step forward; `anchor` is a dummy requires-grad tensor that makes autograd call backward.
+    Gradients are written by the kernels straight into model._flat_grad (aliased by every .grad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, call):
+        ctx.model, ctx.call = model, call
+        model._run_forward(call, training=True)
+        return call.buf.terms[8].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._run_backward(ctx.call, grad_out)
+        return None, None, None
+
+
+class _MMDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s1, s2, alphas, ret_matrix):
+        s1c, s2c = s1.contiguous().float(), s2.contiguous().float()
+        out, kern = ops.rbf_mmd(s1c, s2c, alphas, ret_matrix=ret_matrix)
+        ctx.save_for_backward(s1c, s2c)
+        ctx.alphas = alphas
+        if ret_matrix:
+            ctx.mark_non_differentiable(kern)
+            return out.reshape(()), kern
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        s1, s2 = ctx.saved_tensors
+        g1, g2 = ops.rbf_mmd_backward(s1, s2, ctx.alphas, g.reshape(1).float())
+        return g1, g2, None, None
+
+
+class MMDStatistic:
+    """Drop-in for the reference's `MMDStatistic` (:537-577); `__call__` runs the HIP RBF-MMD kernel."""
+
+    def __init__(self, n_1, n_2):
+        self.n_1, self.n_2 = n_1, n_2
+        self.a00 = 1. / (n_1 * (n_1 - 1))
+        self.a11 = 1. / (n_2 * (n_2 - 1))
+        self.a01 = - 1. / (n_1 * n_2)
+
+    def __call__(self, sample_1, sample_2, alphas, ret_matrix=False):
+        if sample_1.shape[0] != self.n_1 or sample_2.shape[0] != self.n_2:
+            raise ValueError("sample sizes differ from the constructor's n_1/n_2")
+        ops._chk_cuda(sample_1, sample_2)
+        return _MMDFn.apply(sample_1, sample_2, [float(a) for a in alphas], bool(ret_matrix))
+
+    def pval(self, distances, n_permutations=1000):   # dead in the reference too (:571-577 calls a stub)
+        return permutation_test_mat(distances, self.n_1, self.n_2, n_permutations, a00=self.a00, a11=self.a11, a01=self.a01)
+
+
+def permutation_test_mat(*args, **kwargs):  # the reference's stub (:599-600)
+    pass
+
+
+def pdist(sample_1, sample_2, norm=2, eps=1e-5):
+    """Reference `pdist` (:580-596), L2 only (the only live branch): sqrt(eps + |d2|), from the Gram matrix
+    the MMD kernel computes for alpha = 1 (K = exp(-(eps + |d2|)))."""
+    if float(norm) != 2.:
+        raise NotImplementedError("only norm=2 is on the hot path (:583)")
+    ops._chk_cuda(sample_1, sample_2)
+    n1 = sample_1.shape[0]
+    _, kern = ops.rbf_mmd(sample_1.contiguous().float(), sample_2.contiguous().float(), [1.0], eps=eps, ret_matrix=True)
+    return torch.sqrt(-torch.log(kern[:n1, n1:]))
+
+
+# ----------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------
+class _Call:
+    """Everything one forward/backward pair shares."""
+    pass
+
+
+class DrlClassifier(nn.Module):
+    """Reference `DrlClassifier` (:149-534).  Same constructor argument, attribute names, `forward`,
+    `get_pair_preds`, `get_params`, state_dict keys."""
+
+    TERM_NAMES = ("partial", "mmd", "emo", "cau", "pair", "kl_e", "kl_c", "rec", "loss")
+
+    def __init__(self, opt, encoder_cfg=None, seed=None):
+        super().__init__()
+        self.opt = opt
+        self.cfg = encoder_cfg if encoder_cfg is not None else encoder_config(getattr(opt, "language", "zh"))
+        if opt.bert_dim != H:
+            raise L.CarelError("bert_dim must be 768 (BERT-base kernels)")
+        self.encoder = CarelEncoder(self.cfg)
+        self.emotion_mu = _Holder((opt.ec_dim, H))
+        self.emotion_log_var = _Holder((opt.ec_dim, H))
+        self.cause_mu = _Holder((opt.ec_dim, H))
+        self.cause_log_var = _Holder((opt.ec_dim, H))
+        self.emotion_classifier = _Holder((opt.e_num_class, opt.ec_dim))
+        self.cause_classifier = _Holder((opt.c_num_class, opt.ec_dim))
+        self.pair_classifier = _Holder((opt.pair_num_class, opt.ec_dim * 2))
+        self.decoder = _Holder((opt.pair_bow_dim, opt.ec_dim * 2))
+        self.dropout = nn.Dropout(opt.dropout)       # probability holder; the mask is drawn in-kernel
+        gen = None
+        if seed is not None:
+            gen = torch.Generator().manual_seed(seed)
+        _init_like_reference(self, gen)
+        self.dropout_base_seed = 0x5EED
+        self._fwd_count = 0
+        self._noise = None
+        self._ws = {}
+        self._dp = None                     # set by carel_vae_amd.dp.DataParallel
+        self._flat = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _param_order(self):
+        """Flat layout: optimised tensors first (so fused Adam is one contiguous range), the four latent
+        heads (never optimised, ref :292-295) last; q/k/v weights and biases adjacent (fused QKV GEMM)."""
+        named = dict(self.named_parameters())
+        order = []
+        e = "encoder.embeddings."
+        order += [e + "word_embeddings.weight", e + "position_embeddings.weight", e + "token_type_embeddings.weight",
+                  e + "LayerNorm.weight", e + "LayerNorm.bias"]
+        for l in range(self.cfg.layers):
+            p = f"encoder.encoder.layer.{l}."
+            order += [p + "attention.self.query.weight", p + "attention.self.key.weight", p + "attention.self.value.weight",
+                      p + "attention.self.query.bias", p + "attention.self.key.bias", p + "attention.self.value.bias",
+                      p + "attention.output.dense.weight", p + "attention.output.dense.bias",
+                      p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
+                      p + "intermediate.dense.weight", p + "intermediate.dense.bias",
+                      p + "output.dense.weight", p + "output.dense.bias", p + "output.LayerNorm.weight", p + "output.LayerNorm.bias"]
+        order += ["encoder.pooler.dense.weight", "encoder.pooler.dense.bias", "decoder.weight", "decoder.bias",
+                  "emotion_classifier.weight", "emotion_classifier.bias", "cause_classifier.weight", "cause_classifier.bias"]
+        self._pair_range_names = ["pair_classifier.weight", "pair_classifier.bias"]
+        order += self._pair_range_names
+        n_opt_names = len(order)
+        order += ["emotion_mu.weight", "emotion_mu.bias", "emotion_log_var.weight", "emotion_log_var.bias",
+                  "cause_mu.weight", "cause_mu.bias", "cause_log_var.weight", "cause_log_var.bias"]
+        assert set(order) == set(named), "parameter inventory mismatch"
+        return order, n_opt_names, named
+
+    def _flatten(self):
+        order, n_opt_names, named = self._param_order()
+        dev = next(iter(named.values())).device
+        offs, o = {}, 0
+        for i, k in enumerate(order):
+            if i == n_opt_names:
+                self._n_opt = o
+            offs[k] = o
+            o += (named[k].numel() + 63) & ~63        # 256-byte aligned segments
+        flat = torch.empty(o, device=dev, dtype=torch.float32)
+        flat.zero_()
+        with torch.no_grad():
+            for k in order:
+                p = named[k]
+                seg = flat[offs[k]:offs[k] + p.numel()].view(p.shape)
+                seg.copy_(p.data.to(torch.float32))
+                p.data = seg
+        self._flat, self._offs, self._order = flat, offs, order
+        self._named = named
+        self._flat_grad = torch.zeros_like(flat) if dev.type == "cuda" else None
+        self._shadow = torch.empty(o, device=dev, dtype=torch.bfloat16) if dev.type == "cuda" else None
+        self._shadow_versions = None
+        self._grad_views = None
+        self._layer_structs = None
+        self._ws = {}
+        self._pair_lo = offs[self._pair_range_names[0]]
+        self._pair_hi = offs[self._pair_range_names[1]] + named[self._pair_range_names[1]].numel()
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._flatten()
+        return r
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # buffers such as HF's `encoder.embeddings.position_ids` are not parameters here
+        sd = {k: v for k, v in state_dict.items() if not k.endswith(("position_ids", "token_type_ids"))}
+        with torch.no_grad():
+            r = super().load_state_dict(sd, strict=strict, **kw)
+        self._shadow_versions = None
+        return r
+
+    def get_params(self):
+        """Reference order (:292-295): encoder, decoder, emotion / cause / pair classifiers.  The four latent
+        heads are deliberately absent (they are never updated in the reference)."""
+        return (list(self.encoder.parameters()) + list(self.decoder.parameters()) +
+                list(self.emotion_classifier.parameters()) + list(self.cause_classifier.parameters()) +
+                list(self.pair_classifier.parameters()))
+
+    # ------------------------------------------------------------------ helpers
+    def _require_cuda(self):
+        if self._flat is None or self._flat.device.type != "cuda":
+            raise L.CarelError("DrlClassifier parameters are on %s; call .to('cuda') first -- the HIP kernels are the only "
+                               "implementation of the step path (no CPU fallback)." % (None if self._flat is None else self._flat.device))
+
+    def _refresh_shadow(self):
+        vers = sum(p._version for p in self._named.values())
+        if self._shadow_versions != vers:
+            L.check(L.load().carel_cast_f32_to_bf16(self._flat.data_ptr(), self._shadow.data_ptr(), self._flat.numel(),
+                                                    L.current_stream()), "carel_cast_f32_to_bf16")
+            self._shadow_versions = vers
+
+    def mark_shadow_fresh(self):
+        """Called by the fused optimiser, which rewrites the bf16 shadow itself."""
+        self._shadow_versions = sum(p._version for p in self._named.values())
+
+    def _w(self, key, bf16=False):
+        off = self._offs[key]
+        base = self._shadow if bf16 else self._flat
+        return base.data_ptr() + off * (2 if bf16 else 4)
+
+    def _g(self, key):
+        return self._flat_grad.data_ptr() + self._offs[key] * 4
+
+    def _layer_arrays(self):
+        if self._layer_structs is not None:
+            return self._layer_structs
+        n = self.cfg.layers
+        P, G = (L.LayerParams * n)(), (L.LayerGrads * n)()
+        for l in range(n):
+            p = f"encoder.encoder.layer.{l}."
+            m = dict(qkv_w=p + "attention.self.query.weight", qkv_b=p + "attention.self.query.bias",
+                     out_w=p + "attention.output.dense.weight", out_b=p + "attention.output.dense.bias",
+                     ln1_g=p + "attention.output.LayerNorm.weight", ln1_b=p + "attention.output.LayerNorm.bias",
+                     ffn1_w=p + "intermediate.dense.weight", ffn1_b=p + "intermediate.dense.bias",
+                     ffn2_w=p + "output.dense.weight", ffn2_b=p + "output.dense.bias",
+                     ln2_g=p + "output.LayerNorm.weight", ln2_b=p + "output.LayerNorm.bias")
+            for f, k in m.items():
+                setattr(P[l], f, self._w(k, bf16=f.endswith("_w")))
+                setattr(G[l], f, self._g(k))
+        self._layer_structs = (P, G)
+        return self._layer_structs
+
+    def _workspace(self, B, S, inference):
+        key = (B, S, bool(inference))
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 3:
+                self._ws.clear()
+            lib = L.load()
+            dev = self._flat.device
+            ws = SimpleNamespace()
+            ws.act = torch.empty(lib.carel_encoder_act_bytes(B, S, self.cfg.layers, int(inference)), device=dev, dtype=torch.uint8)
+            ws.scratch = None if inference else torch.empty(lib.carel_encoder_scratch_bytes(B, S), device=dev, dtype=torch.uint8)
+            self._ws[key] = ws
+        return ws
+
+    def _encoder_args(self, ids, att, tt, ws, B, S, inference, train, seed, row_offset):
+        a = L.EncoderArgs()
+        c = self.cfg
+        a.batch, a.seq_len, a.n_layers, a.hidden, a.heads, a.intermediate = B, S, c.layers, H, NH, I_FF
+        a.vocab_size, a.max_pos, a.type_vocab, a.roberta, a.pad_id, a.inference = (c.vocab_size, c.max_pos, c.type_vocab,
+                                                                                      c.roberta, c.pad_id, int(inference))
+        a.ln_eps = c.ln_eps
+        a.hidden_dropout = c.hidden_dropout if train else 0.0
+        a.attn_dropout = c.attn_dropout if train else 0.0
+        a.drop_seed, a.drop_row_offset = seed, row_offset
+        a.input_ids, a.attention_mask = ids.data_ptr(), (None if att is None else att.data_ptr())
+        a.token_type_ids = None if tt is None else tt.data_ptr()
+        e = "encoder.embeddings."
+        a.word_emb, a.pos_emb, a.type_emb = self._w(e + "word_embeddings.weight"), self._w(e + "position_embeddings.weight"), self._w(e + "token_type_embeddings.weight")
+        a.emb_ln_g, a.emb_ln_b = self._w(e + "LayerNorm.weight"), self._w(e + "LayerNorm.bias")
+        P, G = self._layer_arrays()
+        a.layers = C.cast(P, C.POINTER(L.LayerParams))
+        a.layer_grads = C.cast(G, C.POINTER(L.LayerGrads))
+        a.act = ws.act.data_ptr()
+        a.scratch = None if ws.scratch is None else ws.scratch.data_ptr()
+        a.d_word_emb, a.d_pos_emb, a.d_type_emb = self._g(e + "word_embeddings.weight"), self._g(e + "position_embeddings.weight"), self._g(e + "token_type_embeddings.weight")
+        a.d_emb_ln_g, a.d_emb_ln_b = self._g(e + "LayerNorm.weight"), self._g(e + "LayerNorm.bias")
+        return a
+
+    @staticmethod
+    def _prep_ids(t, Bp):
+        t = t.to(torch.long).contiguous()
+        if t.shape[0] != Bp:
+            pad = torch.zeros((Bp - t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+            t = torch.cat((t, pad), dim=0)
+        return t
+
+    @staticmethod
+    def _padded_batch(B, S):
+        if S < 32 or S > 128 or S % 32:
+            raise L.CarelError("sequence length must be 32, 64, 96 or 128 (--max_len); got %d" % S)
+        Bp = B
+        while (Bp * S) % 128:
+            Bp += 1
+        return Bp
+
+    def set_noise(self, eps_e, eps_c):
+        """Test hook: use these two [ec_dim] vectors as the next call's reparameterisation noise (ref :350)."""
+        self._noise = None if eps_e is None else (eps_e, eps_c)
+
+    def _draw_noise(self, dev):
+        if self._noise is not None:
+            e, c = self._noise
+            self._noise = None
+            return e.to(dev, torch.float32).contiguous(), c.to(dev, torch.float32).contiguous()
+        D = self.opt.ec_dim
+        eps_e = torch.randn(D, device=dev)           # emotion first, then cause (ref :215-216)
+        eps_c = torch.randn(D, device=dev)
+        if self._dp is not None:
+            eps_e, eps_c = self._dp.broadcast_noise(eps_e, eps_c)
+        return eps_e, eps_c
+
+    # ------------------------------------------------------------------ forward / backward bodies
+    def _make_call(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration, training):
+        self._require_cuda()
+        ops._chk_cuda(input_ids, att_masks, token_type_ids, content_bow)
+        B, S = input_ids.shape
+        Bp = self._padded_batch(B, S)
+        c = _Call()
+        c.B, c.S, c.Bp = B, S, Bp
+        c.ids, c.att = self._prep_ids(input_ids, Bp), self._prep_ids(att_masks, Bp)
+        c.tt = None if token_type_ids is None else self._prep_ids(token_type_ids, Bp)
+        dev = input_ids.device
+        f32 = torch.float32
+        c.labels = dict(emo=emotion_labels.to(dev, torch.long).reshape(-1).contiguous(), cau=cause_labels.to(dev, f32).reshape(-1).contiguous(),
+                        pair=pair_labels.to(dev, f32).reshape(-1).contiguous(), bow=content_bow.to(dev, f32).contiguous())
+        if c.labels["bow"].shape != (B, self.opt.pair_bow_dim):
+            raise L.CarelError("content_bow must be [batch, pair_bow_dim]")
+        c.iteration = int(iteration)
+        c.training = training
+        c.eps_e, c.eps_c = self._draw_noise(dev)
+        self._fwd_count += 1
+        c.seed = (self.dropout_base_seed * 1000003 + self._fwd_count) & 0xFFFFFFFF
+        c.row_offset = 0 if self._dp is None else self._dp.row_offset(B)
+        key = ("tail", B, S)
+        buf = self._ws.get(key)
+        if buf is None:
+            buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev)
+            self._ws[key] = buf
+        c.buf = buf
+        return c
+
+    def _tail_weights(self):
+        keys = ["encoder.pooler.dense.weight", "encoder.pooler.dense.bias", "decoder.weight", "decoder.bias"]
+        for n in ("emotion_mu", "emotion_log_var", "cause_mu", "cause_log_var", "emotion_classifier", "cause_classifier", "pair_classifier"):
+            keys += [n + ".weight", n + ".bias"]
+        return {k: self._named[k].data for k in keys}, {k: self._grad_view(k) for k in keys}
+
+    def _grad_view(self, k):
+        p = self._named[k]
+        o = self._offs[k]
+        return self._flat_grad[o:o + p.numel()].view(p.shape)
+
+    def _run_forward(self, c, training):
+        self._refresh_shadow()
+        train_drop = self.training          # dropout follows module mode (model.train() / .eval()), like nn.Dropout
+        ws = self._workspace(c.Bp, c.S, inference=not training)
+        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset)
+        lib = L.load()
+        st = L.current_stream()
+        L.check(lib.carel_encoder_forward(C.byref(ea), st), "carel_encoder_forward")
+        x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
+        W, G = self._tail_weights()
+        xl = SimpleNamespace(data_ptr=lambda: x_last_ptr)
+        klw = ops.kl_anneal_weight(c.iteration, self.opt)
+        drop = (self.opt.dropout if train_drop else 0.0, c.seed, c.row_offset)
+        ta = ops.tail_args(c.buf, xl, W, c.labels, c.eps_e, c.eps_c, self.opt, klw, grads=G, drop=drop)
+        ops.tail_latents(ta)
+        if self._dp is not None:
+            self._dp.fill_global(ta, c)                  # all-gather z, all-reduce label sum
+        ops.tail_losses(ta)
+        c.ea, c.ta, c.ws = ea, ta, ws
+        c.keep = (W, G, xl)
+
+    def _run_backward(self, c, grad_out):
+        lib = L.load()
+        st = L.current_stream()
+        named = self._named
+        first = named[self._order[0]]
+        accumulate = first.grad is not None
+        prev = self._flat_grad.clone() if accumulate else None
+        go = grad_out.to(torch.float32).reshape(1).contiguous()      # device scalar, never read on the host
+        c.ta.dx_last_f32 = c.buf.dx_last.data_ptr()
+        ea = c.ea
+        if c.Bp == c.B:
+            ea.dx = c.buf.dx_last.data_ptr()
+            dxbuf = None
+        else:
+            dxbuf = torch.zeros((c.Bp * c.S, H), device=self._flat.device, dtype=torch.float32)
+            ea.dx = dxbuf.data_ptr()
+        ops.tail_backward(c.ta, go)
+        if dxbuf is not None:
+            dxbuf[:c.B * c.S].copy_(c.buf.dx_last)
+        # classifier / decoder gradients were produced for grad_output = 1: one contiguous range of the flat buffer
+        lo = self._offs["decoder.weight"]
+        ops.scale_(self._flat_grad[lo:self._pair_hi], go)
+        if self._dp is not None:
+            self._dp.tail_done()
+        for l in range(self.cfg.layers - 1, -1, -1):
+            L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
+            if self._dp is not None:
+                self._dp.layer_done(l)
+        L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
+        if self._dp is not None:
+            self._dp.backward_done()
+        if accumulate:
+            self._flat_grad.add_(prev)
+        self._bind_grads()
+
+    def _bind_grads(self):
+        if self._grad_views is None:
+            self._grad_views = {k: self._grad_view(k) for k in self._order}
+        for k, p in self._named.items():
+            p.grad = self._grad_views[k]
+
+    # ------------------------------------------------------------------ public API (reference surface)
+    def forward(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration):
+        """Reference `forward` (:184-263): returns the scalar `vae_and_classifier_loss`."""
+        c = self._make_call(input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration,
+                            training=torch.is_grad_enabled())
+        self._last_call = c
+        if torch.is_grad_enabled():
+            anchor = self._flat.new_zeros((), requires_grad=True)
+            return _TrainLoss.apply(anchor, self, c)
+        self._run_forward(c, training=False)
+        return c.buf.terms[8].clone()
+
+    def forward_terms(self, *args, **kw):
+        """Added introspection entry point: the loss plus every term and the latent means (no autograd)."""
+        with torch.no_grad():
+            self.forward(*args, **kw)
+        c = self._last_call
+        t = c.buf.terms.clone()
+        D = self.opt.ec_dim
+        lat = c.buf.lat.clone()
+        out = {n: t[i] for i, n in enumerate(self.TERM_NAMES)}
+        out.update(mu_e=lat[:, :D], lv_e=lat[:, D:2 * D], mu_c=lat[:, 2 * D:3 * D], lv_c=lat[:, 3 * D:], pooled=c.buf.pooled.clone(),
+                   z=c.buf.z.clone())
+        return out
+
+    def last_terms(self):
+        """Terms of the most recent forward (device tensor, no sync)."""
+        return {n: self._last_call.buf.terms[i] for i, n in enumerate(self.TERM_NAMES)}
+
+    def pair_probabilities(self, input_ids, att_masks, token_type_ids, chunk=256):
+        """sigmoid(pair_classifier([z_e, z_c])) with fresh noise even in eval mode (ref :277-282, quirk Q6)."""
+        self._require_cuda()
+        ops._chk_cuda(input_ids, att_masks, token_type_ids)
+        dev = input_ids.device
+        eps_e, eps_c = self._draw_noise(dev)
+        N, S = input_ids.shape
+        out = torch.empty(N, device=dev, dtype=torch.float32)
+        self._refresh_shadow()
+        lib = L.load()
+        for s in range(0, N, chunk):
+            ids = input_ids[s:s + chunk]
+            B = ids.shape[0]
+            Bp = self._padded_batch(B, S)
+            ids = self._prep_ids(ids, Bp)
+            att = self._prep_ids(att_masks[s:s + chunk], Bp)
+            tt = None if token_type_ids is None else self._prep_ids(token_type_ids[s:s + chunk], Bp)
+            ws = self._workspace(Bp, S, inference=True)
+            ea = self._encoder_args(ids, att, tt, ws, Bp, S, True, False, 0, 0)
+            L.check(lib.carel_encoder_forward(C.byref(ea), L.current_stream()), "carel_encoder_forward")
+            x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
+            key = ("tail", B, S)
+            buf = self._ws.get(key)
+            if buf is None:
+                buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev)
+                self._ws[key] = buf
+            W, _ = self._tail_weights()
+            ta = ops.tail_args(buf, SimpleNamespace(data_ptr=lambda: x_last_ptr), W, None, None, None, self.opt, 1.0)
+            ops.tail_latents(ta)
+            out[s:s + B] = ops.pair_probs(buf.lat, eps_e, eps_c, W["pair_classifier.weight"], W["pair_classifier.bias"], self.opt.ec_dim)
+        return out
+
+    def get_pair_preds(self, input_ids, att_masks, token_type_ids):
+        """Reference `get_pair_preds` (:265-282): nested python list [[0.|1.], ...]."""
+        prob = self.pair_probabilities(input_ids, att_masks, token_type_ids)
+        return prob.reshape(-1, 1).cpu().detach().numpy().round().tolist()
+
+    # reference helper kept for callers that use it directly (:515-523)
+    def get_annealed_weight(self, iteration, lambda_weight):
+        return (math.tanh((iteration - self.opt.kl_ann_iterations * 1.5) / (self.opt.kl_ann_iterations / 3)) + 1) * lambda_weight
+
+
+class FusedAdam:
+    """`torch.optim.Adam(model.get_params(), lr)` (ref :936) as ONE HIP kernel over the flat buffer.
+    Same defaults and update order; also rewrites the bf16 shadow weights the GEMMs read.  The reference's
+    optimiser object is only used through zero_grad()/step() (:840-842), which this class provides."""
+
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8):
+        model._require_cuda()
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.step_count = 0
+        n = model._n_opt
+        self.exp_avg = torch.zeros(n, device=model._flat.device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.grad_scale = 1.0
+        self.param_groups = [dict(params=model.get_params(), lr=lr, betas=betas, eps=eps)]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model._named.values():
+            p.grad = None
+
+    def step(self):
+        m = self.model
+        self.step_count += 1
+        a = L.AdamArgs()
+        a.param, a.grad = m._flat.data_ptr(), m._flat_grad.data_ptr()
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.shadow_bf16 = m._shadow.data_ptr()
+        a.n, a.step = m._n_opt, self.step_count
+        a.lr, a.beta1, a.beta2, a.eps = self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps
+        a.grad_scale = self.grad_scale
+        call = getattr(m, "_last_call", None)
+        a.skip_lo, a.skip_hi = m._pair_lo, m._pair_hi
+        a.skip_flag = None
+        if call is not None:      # the pair head keeps its weights/moments when its loss term was replaced by 0
+            off = L.load().carel_tail_pair_dead_offset(call.B, m.opt.ec_dim, m.opt.pair_bow_dim)
+            a.skip_flag = call.buf.work.data_ptr() + off * 4
+        L.check(L.load().carel_adam_step(C.byref(a), L.current_stream()), "carel_adam_step")
+        m.mark_shadow_fresh()
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr)
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])

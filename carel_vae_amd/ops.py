@@ -147,8 +147,14 @@ def tail_losses(a):
     L.check(L.load().carel_tail_losses(C.byref(a), L.current_stream()), "carel_tail_losses")
 
 
-def tail_backward(a, grad_out=1.0):
-    L.check(L.load().carel_tail_backward(C.byref(a), float(grad_out), L.current_stream()), "carel_tail_backward")
+def tail_backward(a, grad_out=None):
+    """grad_out: device f32 scalar tensor (upstream gradient of the loss) or None for 1."""
+    L.check(L.load().carel_tail_backward(C.byref(a), None if grad_out is None else grad_out.data_ptr(), L.current_stream()),
+            "carel_tail_backward")
+
+
+def scale_(x, scale_dev):
+    L.check(L.load().carel_scale_f32(x.data_ptr(), x.numel(), scale_dev.data_ptr(), L.current_stream()), "carel_scale_f32")
 
 
 def pair_probs(lat, eps_e, eps_c, pair_w, pair_b, D):

@@ -155,6 +155,54 @@ int carel_attention_fwd(const carel_attn_args* args, void* stream);
 int carel_attention_bwd(const carel_attn_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Whole-encoder orchestration over caller-owned buffers.  Replaces `self.encoder(...)` (ref :202-206;
+ * transformers BertModel / RobertaModel forward) and the encoder part of `loss.backward()` (ref :841).
+ * Weights are read as bf16 (the shadow copy maintained by carel_adam_step / carel_cast_f32_to_bf16),
+ * biases / LayerNorm parameters / embeddings as f32.  The q/k/v projections are one fused [2304,768]
+ * matrix (query rows, then key, then value).
+ *   act     : carel_encoder_act_bytes(B, S, L, inference) bytes; holds every activation the backward
+ *             needs (inference = 1: one layer's worth, re-used by every layer; no backward possible)
+ *   scratch : carel_encoder_scratch_bytes(B, S) bytes of backward workspace
+ *   dx      : f32 [B*S, 768]; in: d(loss)/d(last hidden state); carried down through the layers
+ * Constraints: hidden 768, 12 heads, intermediate 3072, seq_len in {32,64,96,128}, B*S % 128 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_layer_params {
+  const void* qkv_w; const void* qkv_b;     /* bf16 [2304,768], f32 [2304] */
+  const void* out_w; const void* out_b;     /* bf16 [768,768],  f32 [768]  */
+  const void* ln1_g; const void* ln1_b;     /* f32 [768] */
+  const void* ffn1_w; const void* ffn1_b;   /* bf16 [3072,768], f32 [3072] */
+  const void* ffn2_w; const void* ffn2_b;   /* bf16 [768,3072], f32 [768]  */
+  const void* ln2_g; const void* ln2_b;     /* f32 [768] */
+} carel_layer_params;
+
+typedef struct carel_layer_grads {          /* all f32, shapes as above */
+  void* qkv_w; void* qkv_b; void* out_w; void* out_b; void* ln1_g; void* ln1_b;
+  void* ffn1_w; void* ffn1_b; void* ffn2_w; void* ffn2_b; void* ln2_g; void* ln2_b;
+} carel_layer_grads;
+
+typedef struct carel_encoder_args {
+  int32_t batch, seq_len, n_layers, hidden, heads, intermediate;
+  int32_t vocab_size, max_pos, type_vocab, roberta, pad_id, inference;
+  float ln_eps, hidden_dropout, attn_dropout;
+  uint32_t drop_seed, drop_row_offset;      /* row offset = global index of this shard's first sample */
+  const void* input_ids; const void* attention_mask; const void* token_type_ids;   /* int64 [B,S] */
+  const void* word_emb; const void* pos_emb; const void* type_emb; const void* emb_ln_g; const void* emb_ln_b; /* f32 */
+  const carel_layer_params* layers;         /* HOST array [n_layers] of device pointers */
+  void* act; void* scratch;
+  const carel_layer_grads* layer_grads;     /* HOST array [n_layers] */
+  void* d_word_emb; void* d_pos_emb; void* d_type_emb; void* d_emb_ln_g; void* d_emb_ln_b;
+  void* dx;
+} carel_encoder_args;
+
+int64_t carel_encoder_act_bytes(int32_t batch, int32_t seq_len, int32_t n_layers, int32_t inference);
+int64_t carel_encoder_scratch_bytes(int32_t batch, int32_t seq_len);
+/* device pointer (inside act) of the final hidden states, f32 [B*S, 768] */
+void* carel_encoder_x_last(const carel_encoder_args* args);
+int carel_encoder_forward(const carel_encoder_args* args, void* stream);
+int carel_encoder_backward_layer(const carel_encoder_args* args, int32_t layer, void* stream);
+int carel_encoder_backward_embeddings(const carel_encoder_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * VAE tail of DrlClassifier.forward (ref :202-261): pooler -> latent heads -> sample -> emotion CE,
  * cause BCE, pair BCE-with-logits(pos_weight), RBF-MMD, annealed KL, decoder softmax + BCE; and the
  * backward of all of it.  fp32 throughout.
@@ -166,7 +214,7 @@ int carel_attention_bwd(const carel_attn_args* args, void* stream);
  *                        kl_c, rec, loss}; loss = w_mmd*(-mmd) + w_emo*emo + w_cau*cau + w_pair*pair +
  *                        kl_e + kl_c + rec (ref :256-261); kl_* already multiplied by kl_weight.
  *   carel_tail_backward: latent heads + pooler backward -> d_head_*, d_pooler_*, dx_last (zero except
- *                        the CLS rows), all scaled by grad_out.
+ *                        the CLS rows), all scaled by *grad_out_dev (NULL = 1).
  *   carel_pair_probs   : sigmoid(pair_classifier([mu_e + eps_e e^lv_e, mu_c + eps_c e^lv_c])) (ref :277-282)
  * Data-parallel hooks (all optional): global_label_sum/global_n give the pos_weight of the GLOBAL batch;
  * z_global [global_n, 2*ec_dim] (all-gathered samples) + global_row_offset make the MMD the global-batch
@@ -210,9 +258,32 @@ typedef struct carel_tail_args {
 int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim);
 int carel_tail_latents(const carel_tail_args* args, void* stream);
 int carel_tail_losses(const carel_tail_args* args, void* stream);
-int carel_tail_backward(const carel_tail_args* args, float grad_out, void* stream);
+int carel_tail_backward(const carel_tail_args* args, const void* grad_out_dev_f32, void* stream);
+/* x[i] *= *scale_dev  (device scalar; used to apply loss.backward()'s grad_output without a host sync) */
+int carel_scale_f32(void* x_f32, int64_t n, const void* scale_dev_f32, void* stream);
+/* offset (in floats, inside `work`) of the flag carel_tail_losses sets to 1.0 when the pair loss was
+ * replaced by 0 (ref :510-511); carel_adam_step's skip_flag points at it */
+int64_t carel_tail_pair_dead_offset(int32_t batch, int32_t ec_dim, int32_t bow_dim);
 int carel_pair_probs(const void* lat, const void* eps_e, const void* eps_c, const void* pair_w, const void* pair_b,
                      int32_t batch, int32_t ec_dim, void* prob, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused Adam over a flat parameter buffer.  Replaces torch.optim.Adam(...).step() (ref :936, :842) with
+ * torch's defaults and update order (lerp for exp_avg; sqrt(v)/sqrt(bc2) + eps).  Optionally refreshes
+ * the bf16 shadow copy the GEMMs read.  [skip_lo, skip_hi) is left untouched when *skip_flag != 0
+ * (the pair head when its loss term was replaced by 0, ref :510-511, has grad None in the reference).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_adam_args {
+  void* param; const void* grad; void* exp_avg; void* exp_avg_sq;   /* f32 [n], 16-byte aligned */
+  void* shadow_bf16;                                                 /* bf16 [n] or NULL */
+  int64_t n;
+  int64_t step;                       /* 1-based step count (bias correction) */
+  float lr, beta1, beta2, eps;
+  float grad_scale;                   /* multiplies the gradient first (0 = 1.0) */
+  int64_t skip_lo, skip_hi; const void* skip_flag;
+} carel_adam_args;
+int carel_adam_step(const carel_adam_args* args, void* stream);
+int carel_cast_f32_to_bf16(const void* src_f32, void* dst_bf16, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RBF-MMD statistic.  Replaces MMDStatistic.__call__ (ref :547-569) + pdist (ref :580-589) and

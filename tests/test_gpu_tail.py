@@ -53,7 +53,7 @@ def hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, drop, **kw):
     a._keep = (W, G, labels, xl)
     ops.tail_latents(a)
     ops.tail_losses(a)
-    ops.tail_backward(a, 1.0)
+    ops.tail_backward(a, None)
     torch.cuda.synchronize()
     return buf, G
 
