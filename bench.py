@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""CAREL-VAE training-step benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (drl_classifier_ec_mmd_final_mul.py:823-845) over one resident batch:
+forward (BERT-base encoder -> VAE tail -> loss) + backward + Adam (+ RCCL gradient all-reduce when N > 1).
+Workload = BASELINE.json configs[1]: zh ECPE-shaped batch, 64 clause pairs per GPU, S = 128, vocabulary
+21 128, bag-of-words width 23 771, bf16 MFMA / fp32 accumulate, dropout active (model.train()).
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+def log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.time()
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_PAIR = 67.05e9       # fwd+bwd algorithmic FLOPs per clause pair
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clause pairs per GPU")
+    ap.add_argument("--shape", default="A", choices=["A", "B"], help="A dense (roofline headline), B ECPE-shaped lengths")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
+    """The CPU restatement of the same step (oracle/, kind "port") on the host cores: B = 8, 12 layers, fp32,
+    one warm-up + timed steps bounded to ~20 s.  Also returns the ELBO agreement of the HIP path on that batch."""
+    from oracle import carel_oracle as O
+    # the GPU box gives one job a 16-CPU share of a much larger host: os.cpu_count() over-reports
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d threads (os.cpu_count() = %s)" % (cores, os.cpu_count()))
+    cfg, opt = O.EncoderConfig(**cfg_kw), O.Opt(**opt_kw)
+    P = O.init_params(cfg, opt, seed=0)
+    batch = O.synthetic_batch(8, 128, cfg, opt.pair_bow_dim, seed=1, shape="A")
+    g = torch.Generator().manual_seed(3)
+    eps_e, eps_c = torch.randn(opt.ec_dim, generator=g), torch.randn(opt.ec_dim, generator=g)
+    st = O.AdamState()
+    P0 = {k: v.clone() for k, v in P.items()}
+    t_all, n = [], 0
+    out0 = None
+    t_begin = time.time()
+    while n < 4 and (n < 2 or time.time() - t_begin < 20.0):
+        t0 = time.time()
+        with torch.autograd.set_detect_anomaly(True):          # as the reference does (:837)
+            P, out, _ = O.train_step(P, batch, 3, cfg, opt, st, eps_e, eps_c)
+        t_all.append(time.time() - t0)
+        log("cpu_baseline: step %d took %.2f s" % (n, t_all[-1]))
+        if out0 is None:
+            out0 = {k: float(v) for k, v in out.items() if v.numel() == 1}
+        n += 1
+    timed = t_all[1:] if len(t_all) > 1 else t_all
+    rate = 8.0 / (sum(timed) / len(timed))
+    hip = hip_loss_fn(P0, batch, eps_e, eps_c, cfg, opt)
+    scale = abs(30 * out0["mmd"]) + abs(10 * out0["emo"]) + abs(10 * out0["cau"]) + abs(30 * out0["pair"])
+    parity = {"loss_cpu_fp32": out0["loss"], "loss_hip_bf16": hip["loss"],
+              "abs_err_over_term_scale": abs(hip["loss"] - out0["loss"]) / scale,
+              "max_term_rel_err": max(abs(hip[k] - out0[k]) / max(abs(out0[k]), 1e-6) for k in ("mmd", "emo", "cau", "pair", "rec"))}
+    return {"value": rate, "unit": "clause-pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle train_step (fwd+bwd+Adam, set_detect_anomaly as ref :837), B=8 S=128 12 layers fp32, %d timed steps" % len(timed)}, parity
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from carel_vae_amd import _lib as L
+    from carel_vae_amd import drl_classifier as M
+    lib = L.load()
+    L.check(lib.carel_init(local_rank), "carel_init")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from oracle import carel_oracle as O          # synthetic batch generator only (test infrastructure helper)
+    opt = M.make_opt()
+    cfg = M.encoder_config("zh")
+    torch.manual_seed(0)
+    model = M.DrlClassifier(opt, cfg, seed=0).to(dev)
+    model.train()
+    dp = None
+    if world > 1:
+        from carel_vae_amd.dp import DataParallel
+        dp = DataParallel(model)
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr)
+
+    ocfg = O.EncoderConfig()
+    batches = []
+    for i in range(4):
+        b = O.synthetic_batch(a.batch, 128, ocfg, opt.pair_bow_dim, seed=1 + 10 * rank + i, shape=a.shape)
+        batches.append({k: v.to(dev) for k, v in b.items()})
+
+    def step(i):
+        b = batches[i % len(batches)]
+        loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"],
+                     b["bow_reps"], i % 41)
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("model ready on %s; warm-up" % dev)
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    log("timing %d steps" % a.steps)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.detach())
+    log("timed region done: %.3f ms/step; roofline leg" % (1e3 * dt / a.steps))
+    pairs_per_s = world * a.batch * a.steps / dt
+
+    # ---- roofline leg: HIP events around every GEMM launch of a few more steps (same stream) ----
+    roof = None
+    L.check(lib.carel_profile_gemm(1, 4096))
+    nprof = 3
+    for i in range(nprof):
+        step(i)
+    torch.cuda.synchronize()
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+    L.check(lib.carel_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(n)))
+    L.check(lib.carel_profile_gemm(0, 0))
+    log("roofline leg done (%d GEMM launches)" % n.value)
+    if n.value:
+        ach = fl.value / (ms.value * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "carel::gemm_kernel (all instantiations: fwd NT, dgrad NN, wgrad TN)",
+                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                "launches_per_step": n.value / nprof, "avg_launch_us": 1e3 * ms.value / n.value,
+                "alg_gflop_per_launch": fl.value / n.value / 1e9, "gemm_ms_per_step": ms.value / nprof,
+                "whole_step_frac_of_peak": (world * a.batch * FLOP_PER_PAIR * a.steps / dt) / (world * PEAK_BF16_TFLOPS * 1e12)}
+
+    out = {"metric": "clause-pairs/sec (training step)", "value": pairs_per_s, "unit": "clause-pairs/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "zh ECPE training step (fwd+bwd+Adam), BERT-base vocab 21128, S=128 shape-%s, B=%d/GPU, "
+                                  "bow V=23771, dropout on, random-init weights" % (a.shape, a.batch),
+                      "global_batch": world * a.batch, "seq_len": 128, "parallelism": "dp%d" % world,
+                      "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam"},
+           "roofline": roof, "final_loss": final_loss}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):
+            m2 = M.DrlClassifier(M.make_opt(**vars(oopt)), M.encoder_config("zh", hidden_dropout=0.0, attn_dropout=0.0), seed=0)
+            m2.load_state_dict(P0)
+            m2.to(dev).train()
+            m2.opt.dropout = 0.0
+            m2.set_noise(eps_e, eps_c)
+            b = {k: v.to(dev) for k, v in batch.items()}
+            t = m2.forward_terms(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"],
+                                 b["labels"], b["bow_reps"], 3)
+            return {k: float(v) for k, v in t.items() if v.numel() == 1}
+        base, parity = cpu_baseline({}, {"dropout": 0.0}, hip_loss)
+        out["cpu_baseline"] = base
+        out["elbo_parity"] = parity
+        out["speedup_vs_cpu_baseline"] = pairs_per_s / base["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

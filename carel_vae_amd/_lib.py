@@ -117,6 +117,8 @@ SIGNATURES = {
     "carel_init": (C.c_int, [C.c_int]),
     "carel_last_error": (C.c_char_p, []),
     "carel_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "carel_profile_gemm": (C.c_int, [C.c_int32, C.c_int32]),
+    "carel_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
@@ -158,6 +160,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (libamdhip64); it must be the one already loaded when our library's
+    # dependency is resolved, otherwise two runtimes coexist and torch sees no GPU.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CarelError(
             "libcarel_hip.so not found at %s -- build it with `python -m carel_vae_amd.build` "

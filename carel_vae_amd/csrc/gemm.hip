@@ -180,6 +180,58 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 
 using namespace carel;
 
+// ---- optional per-launch HIP-event timing of the GEMM kernel (bench.py's roofline leg) -------------
+#include <vector>
+namespace {
+struct GemmProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;      // start/stop pairs
+  std::vector<double> flops;
+  size_t used = 0;
+} g_prof;
+struct ProfScope {
+  hipStream_t s; bool active;
+  ProfScope(hipStream_t st, double fl) : s(st), active(false) {
+    if (!g_prof.on || g_prof.used + 2 > g_prof.ev.size()) return;
+    active = true;
+    g_prof.flops.push_back(fl);
+    (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+  }
+  ~ProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+    g_prof.used += 2;
+  }
+};
+}  // namespace
+
+extern "C" int carel_profile_gemm(int enable, int max_launches) {
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear(); g_prof.flops.clear(); g_prof.used = 0; g_prof.on = false;
+  if (!enable) return CAREL_OK;
+  if (max_launches < 1) return set_error(CAREL_ERR_ARG, "carel_profile_gemm: max_launches must be positive");
+  g_prof.ev.resize((size_t)max_launches * 2);
+  for (auto& e : g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm: hipEventCreate failed");
+  g_prof.on = true;
+  return CAREL_OK;
+}
+
+// Host-synchronising read-out: sums the recorded launches (ms, algorithmic flops 2*M*N*K, count).
+extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches) {
+  if (!total_ms || !total_flops || !launches) return set_error(CAREL_ERR_ARG, "carel_profile_gemm_read: null output");
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm_read: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm_read: elapsed failed");
+    ms += t; fl += g_prof.flops[i / 2];
+  }
+  *total_ms = ms; *total_flops = fl; *launches = (int64_t)(g_prof.used / 2);
+  g_prof.used = 0; g_prof.flops.clear();
+  return CAREL_OK;
+}
+
 static int gemm_shape_ok(int M, int N, int K, int splits) {
   if (M <= 0 || N <= 0 || K <= 0 || splits <= 0) return 0;
   if (M % 128 || N % 128) return 0;
@@ -217,6 +269,7 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
     default: return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: unknown epilogue %d", epi);
   }
 #undef NEED
+  ProfScope prof_scope(stream, 2.0 * (double)a->M * (double)a->N * (double)a->K);
   if (form == CAREL_GEMM_NT) {
     switch (epi) {
       case EPI_BIAS_BF16: return launch<false, false, EPI_BIAS_BF16>(p, 1, stream);

@@ -1,0 +1,113 @@
+"""Data-parallel training of DrlClassifier: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm, over xGMI).  The reference has no distributed code at all; this is
+the MI355X-native scaling path asked for by BASELINE.json.
+
+What is exchanged per step
+  * gradients: one all-reduce (average) per bucket, issued as soon as the bucket's gradients exist --
+    after the tail backward (pooler + heads + decoder), after each encoder layer's backward (7.09 M
+    elements each, contiguous in the flat gradient buffer), and after the embedding backward -- so that
+    all but the last bucket overlap with the remaining backward kernels (RCCL runs on its own stream);
+  * the three batch-coupled quantities of the loss, so that N ranks x B samples
+    reproduce a single-process step on the N*B batch exactly: the sampled latents z (all-gather,
+    N*B x 48 floats) for the global-batch RBF-MMD, the label sum (one float) for `pos_weight`, and the two
+    reparameterisation noise vectors (broadcast from rank 0, 48 floats).
+Dropout masks are already shard-consistent: the kernels hash the GLOBAL element index (row offset =
+rank * B).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradReducer:
+    """Bucketed, asynchronous gradient averaging over named contiguous ranges of one flat tensor.
+    Device-agnostic (gloo on CPU in the tests, RCCL on the GPUs)."""
+
+    def __init__(self, flat_grad, buckets, group=None):
+        self.flat, self.buckets, self.group = flat_grad, dict(buckets), group
+        self.world = dist.get_world_size(group)
+        backend = dist.get_backend(group)
+        self.use_avg = backend == "nccl"
+        self.pending = []
+
+    def reduce(self, name):
+        lo, hi = self.buckets[name]
+        if hi <= lo or self.world == 1:
+            return
+        view = self.flat[lo:hi]
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        work = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        self.pending.append((work, view))
+
+    def wait(self):
+        for work, view in self.pending:
+            work.wait()
+            if not self.use_avg:
+                view.div_(self.world)
+        self.pending = []
+
+
+class DataParallel:
+    """Attach to a DrlClassifier: `dp = DataParallel(model)`; then train as usual (same forward / backward /
+    optimiser calls).  Every rank must call forward with the same local batch size."""
+
+    def __init__(self, model, group=None, global_batch_terms=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised (init_process_group) before DataParallel")
+        self.model, self.group = model, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.global_batch_terms = global_batch_terms
+        model._dp = self
+        dist.broadcast(model._flat, src=0, group=group)        # identical replicas
+        model._shadow_versions = None
+        self.reducer = FlatGradReducer(model._flat_grad, self._buckets(model), group)
+
+    @staticmethod
+    def _buckets(model):
+        offs, n_layers = model._offs, model.cfg.layers
+        starts = [offs[f"encoder.encoder.layer.{l}.attention.self.query.weight"] for l in range(n_layers)]
+        pooler = offs["encoder.pooler.dense.weight"]
+        b = {"embeddings": (0, starts[0]), "tail": (pooler, model._flat.numel())}
+        for l in range(n_layers):
+            b[f"layer{l}"] = (starts[l], starts[l + 1] if l + 1 < n_layers else pooler)
+        return b
+
+    # ---- hooks called by DrlClassifier -------------------------------------------------------
+    def row_offset(self, local_batch):
+        return self.rank * local_batch
+
+    def broadcast_noise(self, eps_e, eps_c):
+        both = torch.cat((eps_e, eps_c))
+        dist.broadcast(both, src=0, group=self.group)
+        n = eps_e.numel()
+        return both[:n].contiguous(), both[n:].contiguous()
+
+    def fill_global(self, ta, call):
+        """All-gather the sampled latents and all-reduce the label sum; point the tail at them."""
+        if not self.global_batch_terms or self.world == 1:
+            return
+        z = call.buf.z
+        z_all = torch.empty((self.world * z.shape[0], z.shape[1]), device=z.device, dtype=z.dtype)
+        dist.all_gather_into_tensor(z_all, z, group=self.group)
+        ysum = call.labels["pair"].sum().reshape(1)
+        dist.all_reduce(ysum, op=dist.ReduceOp.SUM, group=self.group)
+        ta.z_global, ta.global_n = z_all.data_ptr(), z_all.shape[0]
+        ta.global_row_offset = self.rank * z.shape[0]
+        ta.global_label_sum = ysum.data_ptr()
+        ta.mmd_grad_scale = float(self.world)       # gradients are averaged over ranks afterwards
+        call.dp_keep = (z_all, ysum)
+
+    def tail_done(self):
+        self.reducer.reduce("tail")
+
+    def layer_done(self, layer):
+        self.reducer.reduce(f"layer{layer}")
+
+    def backward_done(self):
+        self.reducer.reduce("embeddings")
+        self.reducer.wait()
+
+    def reduce_scalar_mean(self, t):
+        """Average a scalar (e.g. the loss for logging) over ranks."""
+        t = t.detach().clone().reshape(1)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t / self.world

@@ -80,6 +80,11 @@ typedef struct carel_gemm_args {
 } carel_gemm_args;
 
 int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
+/* Measurement aid (bench.py roofline leg): while enabled, every carel_gemm_bf16 launch is bracketed by
+ * HIP events on its stream.  carel_profile_gemm_read() synchronises and returns the summed kernel time
+ * (ms), the summed algorithmic flops (2*M*N*K) and the launch count, then resets the log. */
+int carel_profile_gemm(int32_t enable, int32_t max_launches);
+int carel_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches);
 /* out[n] (+)= sum_z slabs[z][n];  n multiple of 4 */
 int carel_slab_reduce_f32(const void* slabs, void* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
 
