@@ -25,7 +25,7 @@ __device__ __forceinline__ int att_off(int row, int chunk) { return row * 128 + 
 
 // fill an image of `rows` x 64 bf16 from a row-major global matrix (row stride ld elements); 256 threads
 __device__ __forceinline__ void stage_att(const bf16_t* __restrict__ g, long ld, int rows, char* img) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int q = wave; q < (rows >> 3); q += 4) {
     const int r = q * 8 + (lane >> 3);
     const int c = (lane & 7) ^ f_att(r);

@@ -107,7 +107,7 @@ __device__ __forceinline__ int col_img_off(int krow, int chunk) { return krow * 
 template <int ROWS>
 __device__ __forceinline__ void stage_row_image(const bf16_t* __restrict__ g, long ld, long row0, long k0,
                                                 char* lds_tile) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NINSTR = ROWS / 8;            // 1 KiB pieces (8 rows each)
 #pragma unroll
   for (int i = 0; i < NINSTR / 4; ++i) {
@@ -121,7 +121,7 @@ __device__ __forceinline__ void stage_row_image(const bf16_t* __restrict__ g, lo
 // COL image: 64 k-rows x 128 columns, global matrix is [k][x] row-major.
 __device__ __forceinline__ void stage_col_image(const bf16_t* __restrict__ g, long ld, long krow0, long x0,
                                                 char* lds_tile) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = wave * 4 + i;               // 16 pieces of 4 k-rows

@@ -58,10 +58,14 @@ LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
 struct Scratch { char* dy; char* dyb; char* du; char* dctx; char* dqkv; char* slabs; char* part; };
 struct ScratchLayout { size_t o_dy, o_dyb, o_du, o_dctx, o_dqkv, o_slabs, o_part, total; };
 
+// split-K factor of the weight-gradient GEMMs (K = tokens).  Measured at T = 8192 (tools/bench_gemm.py):
+// 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 4 (8 is ~10 % faster in the GEMM but the
+// slab reduction reads twice the bytes).
 int wgrad_splits(long T, int M, int N) {
   const int tiles = (M / 128) * (N / 128);
+  const int want = tiles < 64 ? 8 : 4;
   int s = 1;
-  while (tiles * s < 512 && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
+  while (s < want && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
   return s;
 }
 

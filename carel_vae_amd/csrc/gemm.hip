@@ -39,6 +39,57 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue for 4 consecutive columns (col..col+3) of C row `row`, accumulator values v.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
+  const long off = row * p.ldc + col;
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
+    if (p.bias) {
+      const float4 b = *(const float4*)(p.bias + col);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+  }
+  if (EPI == EPI_BIAS_BF16) {
+    uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(p.out0 + off) = o;
+  } else if (EPI == EPI_BIAS_GELU) {
+    uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(p.out0 + off) = o;
+    // GELU is evaluated on the bf16-rounded pre-activation that backward will read back
+    float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
+    uint2 g = {pack2bf(gelu_erf(u0), gelu_erf(u1)), pack2bf(gelu_erf(u2), gelu_erf(u3))};
+    *(uint2*)(p.out1 + off) = g;
+  } else if (EPI == EPI_BIAS_DROP_RESID) {
+    const float4 r = *(const float4*)(p.resid + off);
+    const uint32_t e = (uint32_t)off;
+    float4 o;
+    o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
+    o.y = v[1] * dropout_mult(p.drop, e + 1) + r.y;
+    o.z = v[2] * dropout_mult(p.drop, e + 2) + r.z;
+    o.w = v[3] * dropout_mult(p.drop, e + 3) + r.w;
+    *(float4*)(p.outf + off) = o;
+  } else if (EPI == EPI_DGELU_BF16) {
+    const uint2 a = *(const uint2*)(p.aux + off);
+    const float u0 = bf2f((bf16_t)(a.x & 0xffff)), u1 = bf2f((bf16_t)(a.x >> 16));
+    const float u2 = bf2f((bf16_t)(a.y & 0xffff)), u3 = bf2f((bf16_t)(a.y >> 16));
+    uint2 o = {pack2bf(v[0] * gelu_erf_grad(u0), v[1] * gelu_erf_grad(u1)),
+               pack2bf(v[2] * gelu_erf_grad(u2), v[3] * gelu_erf_grad(u3))};
+    *(uint2*)(p.out0 + off) = o;
+  } else if (EPI == EPI_ADD_F32) {
+    float4 o = {v[0], v[1], v[2], v[3]};
+    if (p.resid) {
+      const float4 r = *(const float4*)(p.resid + off);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *(float4*)(p.outf + off) = o;
+  } else {  // EPI_SLAB_F32
+    float4 o = {v[0], v[1], v[2], v[3]};
+    *(float4*)(p.outf + (long)blockIdx.z * p.M * p.ldc + off) = o;
+  }
+}
+
 template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[65536];
@@ -99,59 +150,143 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   for (int i = 0; i < 4; ++i) {
     const long row = m0 + wr * 64 + i * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-      f32x4 v = acc[i][j];
-      const long off = row * p.ldc + col;
-      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
-        if (p.bias) {
-          const float4 b = *(const float4*)(p.bias + col);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-      }
-      if (EPI == EPI_BIAS_BF16) {
-        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *(uint2*)(p.out0 + off) = o;
-      } else if (EPI == EPI_BIAS_GELU) {
-        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *(uint2*)(p.out0 + off) = o;
-        // GELU is evaluated on the bf16-rounded pre-activation that backward will read back
-        float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
-        uint2 g = {pack2bf(gelu_erf(u0), gelu_erf(u1)), pack2bf(gelu_erf(u2), gelu_erf(u3))};
-        *(uint2*)(p.out1 + off) = g;
-      } else if (EPI == EPI_BIAS_DROP_RESID) {
-        const float4 r = *(const float4*)(p.resid + off);
-        const uint32_t e = (uint32_t)off;
-        float4 o;
-        o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
-        o.y = v[1] * dropout_mult(p.drop, e + 1) + r.y;
-        o.z = v[2] * dropout_mult(p.drop, e + 2) + r.z;
-        o.w = v[3] * dropout_mult(p.drop, e + 3) + r.w;
-        *(float4*)(p.outf + off) = o;
-      } else if (EPI == EPI_DGELU_BF16) {
-        const uint2 a = *(const uint2*)(p.aux + off);
-        const float u0 = bf2f((bf16_t)(a.x & 0xffff)), u1 = bf2f((bf16_t)(a.x >> 16));
-        const float u2 = bf2f((bf16_t)(a.y & 0xffff)), u3 = bf2f((bf16_t)(a.y >> 16));
-        uint2 o = {pack2bf(v[0] * gelu_erf_grad(u0), v[1] * gelu_erf_grad(u1)),
-                   pack2bf(v[2] * gelu_erf_grad(u2), v[3] * gelu_erf_grad(u3))};
-        *(uint2*)(p.out0 + off) = o;
-      } else if (EPI == EPI_ADD_F32) {
-        float4 o = {v[0], v[1], v[2], v[3]};
-        if (p.resid) {
-          const float4 r = *(const float4*)(p.resid + off);
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
-        *(float4*)(p.outf + off) = o;
-      } else {  // EPI_SLAB_F32
-        float4 o = {v[0], v[1], v[2], v[3]};
-        *(float4*)(p.outf + (long)blockIdx.z * p.M * p.ldc + off) = o;
-      }
-    }
+    for (int j = 0; j < 4; ++j) epi_store<EPI>(p, acc[i][j], row, n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
+  }
+}
+
+// =============================================================================================
+// v2: 256 x 96 x 64 block tile, 512 threads = 8 waves (4 x 2), each wave 64 x 48 = 4 x 3 MFMA tiles.
+// Three LDS stages (3 x 48 KiB, one workgroup per CU); the LDS-DMA loads of tile t+2 are issued right
+// after the single per-K-step barrier and stay in flight across the next barrier: the wait that retires
+// tile t is a COUNTED s_waitcnt vmcnt(G) (G = this wave's LDS-DMA instructions per tile), never 0 inside
+// the loop, and the barrier is a raw s_barrier (a __syncthreads() would drain vmcnt).
+// 96-wide N tiles make every encoder GEMM at M = 8192 an exact multiple of 256 workgroups
+// (N = 768 -> 256, 2304 -> 768, 3072 -> 1024).
+// =============================================================================================
+constexpr int V2_STAGE = 49152;            // A 32 KiB + B 16 KiB
+constexpr int V2_LDS = 3 * V2_STAGE;
+
+template <int ROWS>
+__device__ __forceinline__ void stage_row_image8(const bf16_t* __restrict__ g, long ld, long row0, long k0, char* lds_tile) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int q = wave; q < ROWS / 8; q += 8) {
+    const int r = q * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    __builtin_amdgcn_global_load_lds(g + (row0 + r) * ld + k0 + c * 8, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
+  }
+}
+// one [64 k][128 x] COL image of which the first NCH 16-byte chunks per row are used
+template <int NCH>
+__device__ __forceinline__ void stage_col_image8(const bf16_t* __restrict__ g, long ld, long krow0, long x0, char* lds_tile) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int q = wave; q < 16; q += 8) {
+    const int r = q * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ swz_col(r);
+    if (NCH == 16 || c < NCH)
+      __builtin_amdgcn_global_load_lds(g + (krow0 + r) * ld + x0 + c * 8, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
   }
 }
 
 template <bool AT, bool BT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v2(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  const long m0 = (long)tm * 256, n0 = (long)tn * 96;
+  const long kbase = (long)blockIdx.z * p.K;
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int kt, int buf) {
+    char* ta = smem + buf * V2_STAGE;
+    char* tb = ta + 32768;
+    const long k0 = kbase + (long)kt * 64;
+    if (AT) {
+      for (int q = wave; q < 32; q += 8) {           // two [64][128] COL images side by side
+        const int img = q >> 4, qi = q & 15;
+        const int r = qi * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ swz_col(r);
+        __builtin_amdgcn_global_load_lds(p.A + (k0 + r) * p.lda + m0 + img * 128 + c * 8,
+                                         (CAREL_LDS void*)(ta + img * 16384 + qi * 1024), 16, 0, 0);
+      }
+    } else {
+      stage_row_image8<256>(p.A, p.lda, m0, k0, ta);
+    }
+    if (BT) stage_col_image8<12>(p.B, p.ldb, k0, n0, tb); else stage_row_image8<96>(p.B, p.ldb, n0, k0, tb);
+  };
+  // LDS-DMA instructions per tile issued by THIS wave: A 4; B 2 (COL image) or 2/1 (96-row ROW image: 12 pieces)
+  const bool six = BT || wave < 4;
+
+  const int nk = p.K >> 6;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if (six) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
+    const char* ta = smem + (kt % 3) * V2_STAGE;
+    const char* tb = ta + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 64; ks += 32) {
+      bf16x8 fa[4], fb[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = AT ? frag16_col(ta + (wr >> 1) * 16384, (wr & 1) * 64 + i * 16, ks) : frag16_row(ta, wr * 64 + i * 16, ks);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fb[j] = BT ? frag16_col(tb, wc * 48 + j * 16, ks) : frag16_row(tb, wc * 48 + j * 16, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long row = m0 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) epi_store<EPI>(p, acc[i][j], row, n0 + wc * 48 + j * 16 + (lane >> 4) * 4);
+  }
+}
+
+template <bool AT, bool BT, int EPI>
+static int launch_v2(GemmParams p, int splits, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_v2<AT, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_kernel_v2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = true;
+  }
+  p.tiles_m = p.M / 256; p.tiles_n = p.N / 96;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  hipLaunchKernelGGL((gemm_kernel_v2<AT, BT, EPI>), grid, dim3(512), V2_LDS, s, p);
+  return check_launch("gemm_kernel_v2");
+}
+
+static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x96 kernel
+
+template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
+  const bool v2_ok = (p.M % 256 == 0) && (p.N % 96 == 0);
+  const bool v1_ok = (p.M % 128 == 0) && (p.N % 128 == 0);
+  // measured on MI355X (tools/bench_gemm.py, T = 8192): the 128x128 tile at 2 workgroups/CU wins or ties on every
+  // encoder shape (the second resident workgroup hides the other's prologue/epilogue; K is only 12-48 steps), so
+  // the 256x96 three-stage kernel is used only when asked for or when the shape does not fit 128x128.
+  if (v2_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && !v1_ok))) return launch_v2<AT, BT, EPI>(p, splits, s);
+  if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
   hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI>), grid, dim3(256), 0, s, p);
   return check_launch("gemm_kernel");
@@ -234,17 +369,19 @@ extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, in
 
 static int gemm_shape_ok(int M, int N, int K, int splits) {
   if (M <= 0 || N <= 0 || K <= 0 || splits <= 0) return 0;
-  if (M % 128 || N % 128) return 0;
+  if (!((M % 128 == 0 && N % 128 == 0) || (M % 256 == 0 && N % 96 == 0))) return 0;
   if (K % (64 * splits)) return 0;
   return 1;
 }
+
+extern "C" int carel_gemm_set_variant(int32_t v) { g_gemm_variant = v; return CAREL_OK; }
 
 extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null args");
   const int splits = a->splits > 0 ? a->splits : 1;
   if (!gemm_shape_ok(a->M, a->N, a->K, splits))
-    return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: M,N must be multiples of 128 and K of 64*splits (M=%d N=%d K=%d splits=%d)",
+    return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: (M,N) must be multiples of (128,128) or (256,96) and K of 64*splits (M=%d N=%d K=%d splits=%d)",
                      a->M, a->N, a->K, splits);
   if (!a->A || !a->B) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null operand");
   if (((uintptr_t)a->A | (uintptr_t)a->B) & 15 || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3))

@@ -279,19 +279,28 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
   if (a.type_vocab > 1) write_partials(lds, accT1, dst + 3 * H, lane, wave);
 }
 
-// out[c] (+)= sum_p partials[p][c]   (c < n, p < nparts): 64 columns per block, 4 row-lanes, fixed order
+// out[c] (+)= sum_p partials[p][c]   (c < n, p < nparts): 16 columns x 16 row-lanes per block, fixed order
+__device__ __forceinline__ float partial_colsum16(const float* __restrict__ partials, int n, int nparts, float* lds, int& c) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < n) for (int p = rl; p < nparts; p += 16) s += partials[(long)p * n + c];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (rl == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += lds[r * 16 + cl];
+  }
+  return t;
+}
+
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
                                                              int n, int nparts, int accumulate) {
   __shared__ float lds[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < n) for (int p = rl; p < nparts; p += 4) s += partials[(long)p * n + c];
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  if (rl == 0 && c < n) {
-    const float t = (lds[threadIdx.x] + lds[64 + threadIdx.x]) + (lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
-    out[c] = accumulate ? out[c] + t : t;
-  }
+  int c;
+  const float t = partial_colsum16(partials, n, nparts, lds, c);
+  if ((threadIdx.x >> 4) == 0 && c < n) out[c] = accumulate ? out[c] + t : t;
 }
 
 // same reduction, but column c goes to outs.p[c / seg][c % seg] (null pointers are skipped)
@@ -299,13 +308,9 @@ struct SegOuts { float* p[4]; };
 __global__ __launch_bounds__(256) void partial_reduce_seg_kernel(const float* __restrict__ partials, SegOuts outs, int seg,
                                                                  int n, int nparts) {
   __shared__ float lds[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < n) for (int p = rl; p < nparts; p += 4) s += partials[(long)p * n + c];
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  if (rl == 0 && c < n) {
-    const float t = (lds[threadIdx.x] + lds[64 + threadIdx.x]) + (lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+  int c;
+  const float t = partial_colsum16(partials, n, nparts, lds, c);
+  if ((threadIdx.x >> 4) == 0 && c < n) {
     float* o = outs.p[c / seg];
     if (o) o[c % seg] = t;
   }
@@ -394,7 +399,7 @@ extern "C" int carel_embed_ln_bwd(const carel_embed_args* a, const void* dx0, vo
   if (rc) return rc;
   SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dtype_;
   so.p[3] = e.type_vocab > 1 ? (float*)dtype_ + H : nullptr;
-  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((slots * H + 63) / 64), dim3(256), 0, stream, (const float*)partials,
+  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((slots * H + 15) / 16), dim3(256), 0, stream, (const float*)partials,
                      so, H, slots * H, nblk);
   return check_launch("partial_reduce_seg_kernel");
 }
@@ -426,7 +431,7 @@ extern "C" int carel_layernorm_bwd(const void* dy, const void* h, const void* st
   int rc = check_launch("ln_bwd_kernel");
   if (rc) return rc;
   SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dbias; so.p[3] = nullptr;
-  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((3 * H + 63) / 64), dim3(256), 0, stream, (const float*)partials, so,
+  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((3 * H + 15) / 16), dim3(256), 0, stream, (const float*)partials, so,
                      H, 3 * H, nblk);
   return check_launch("partial_reduce_seg_kernel");
 }
@@ -441,7 +446,7 @@ extern "C" int carel_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_
                      (long)rows, n, (float*)partials);
   int rc = check_launch("colsum_bf16_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, (const float*)partials, (float*)out_f32, n,
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, (const float*)partials, (float*)out_f32, n,
                      chunks, accumulate);
   return check_launch("partial_reduce_kernel");
 }

@@ -73,19 +73,22 @@ __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* __restri
   if (lane == 0 && os.b[n / seg]) os.b[n / seg][n % seg] = sb;
 }
 
-// dX[b][k] = sum_n dY[b][n] * W_n[k]  (one wave per sample b);  MODE 1: dY is multiplied by (1 - y^2) of
-// the tanh output y (pooler) first and the product is also written to dpre (for the pooler wgrad)
+// part[c][b][k] = sum_{n in chunk c} dY[b][n] * W_n[k]  (one wave per (sample b, chunk of 64 outputs n));
+// MODE 1: dY is first multiplied by (1 - y^2) of the tanh output y (pooler) and the product is also written
+// to dpre (for the pooler wgrad).  The chunks are summed by sum_parts_kernel (fixed order).
+constexpr int DG_CHUNK = 64;
 template <int MODE>
 __global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restrict__ dY, long dy_stride, int B, int N, int seg,
                                                            PtrSet4 ps, const float* __restrict__ y, float* __restrict__ dpre,
-                                                           float* __restrict__ dX, long dx_stride) {
+                                                           float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   float4 acc[TNV];
 #pragma unroll
   for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
-  for (int n = 0; n < N; ++n) {
+  const int n0 = blockIdx.y * DG_CHUNK, n1 = min(N, n0 + DG_CHUNK);
+  for (int n = n0; n < n1; ++n) {
     float g = dY[(long)b * dy_stride + n];
     if (MODE == 1) {
       const float yy = y[(long)b * N + n];
@@ -100,9 +103,20 @@ __global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restri
       acc[i].z = fmaf(g, wv.z, acc[i].z); acc[i].w = fmaf(g, wv.w, acc[i].w);
     }
   }
-  float* o = dX + (long)b * dx_stride;
+  float* o = part + ((long)blockIdx.y * B + b) * TH;
 #pragma unroll
   for (int i = 0; i < TNV; ++i) *(float4*)(o + (i * 64 + lane) * 4) = acc[i];
+}
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = *(const float4*)(part + i);
+  for (int p = 1; p < nparts; ++p) {
+    const float4 b = *(const float4*)(part + (long)p * n + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  *(float4*)(out + i) = a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -398,29 +412,35 @@ __global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
   }
 }
 
-// combine pass-1 partials -> rowstat[b] = {M, log L}; pass-2 partials -> rowstat[b][2] = dot, terms
+// combine pass-1 partials -> rowstat[b] = {M, log L}; pass-2 partials -> rowstat[b][2] = dot, [3] = row loss.
+// One wave per sample (lanes over chunks).
 __global__ __launch_bounds__(256) void decoder_combine_kernel(const float* __restrict__ part, int chunks, int B, int pass,
-                                                              float* __restrict__ rowstat, float* __restrict__ terms, float inv_bv) {
+                                                              float* __restrict__ rowstat) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  if (pass == 1) {
+    float m = -INFINITY;
+    for (int c = lane; c < chunks; c += 64) m = fmaxf(m, part[((long)c * B + b) * 2]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < chunks; c += 64) s += part[((long)c * B + b) * 2 + 1] * expf(part[((long)c * B + b) * 2] - m);
+    s = wave_sum(s);
+    if (lane == 0) { rowstat[b * 4] = m; rowstat[b * 4 + 1] = logf(s); }
+  } else {
+    float le = 0.f, dt = 0.f;
+    for (int c = lane; c < chunks; c += 64) { le += part[((long)c * B + b) * 2]; dt += part[((long)c * B + b) * 2 + 1]; }
+    le = wave_sum(le); dt = wave_sum(dt);
+    if (lane == 0) { rowstat[b * 4 + 2] = dt; rowstat[b * 4 + 3] = le; }
+  }
+}
+// rec = sum_b rowloss[b] / (B V); terms[7] = rec, terms[8] = terms[0] + rec
+__global__ __launch_bounds__(256) void decoder_total_kernel(const float* __restrict__ rowstat, int B, float inv_bv, float* __restrict__ terms) {
   __shared__ float red[16];
   float tot = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    if (pass == 1) {
-      float m = -INFINITY;
-      for (int c = 0; c < chunks; ++c) m = fmaxf(m, part[((long)c * B + b) * 2]);
-      float s = 0.f;
-      for (int c = 0; c < chunks; ++c) s += part[((long)c * B + b) * 2 + 1] * expf(part[((long)c * B + b) * 2] - m);
-      rowstat[b * 4] = m; rowstat[b * 4 + 1] = logf(s);
-    } else {
-      float le = 0.f, dt = 0.f;
-      for (int c = 0; c < chunks; ++c) { le += part[((long)c * B + b) * 2]; dt += part[((long)c * B + b) * 2 + 1]; }
-      rowstat[b * 4 + 2] = dt; rowstat[b * 4 + 3] = le;
-      tot += le;
-    }
-  }
-  if (pass == 2) {
-    tot = block_sum(tot, red);
-    if (threadIdx.x == 0) { terms[7] = tot * inv_bv; terms[8] = terms[0] + tot * inv_bv; }
-  }
+  for (int b = threadIdx.x; b < B; b += 256) tot += rowstat[b * 4 + 3];
+  tot = block_sum(tot, red);
+  if (threadIdx.x == 0) { terms[7] = tot * inv_bv; terms[8] = terms[0] + tot * inv_bv; }
 }
 
 // dlat = dlat_direct + [dz_e, dz_e*eps_e*exp(lv_e), dz_c, dz_c*eps_c*exp(lv_c)], dz = dz_core + sum_chunks dz_part
@@ -477,7 +497,7 @@ static size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct TailWork {     // carve-up of the caller's f32 workspace
   float* dz_core; float* dlat_direct; float* dlat; float* dpooled; float* dpre; float* part; float* rowstat; float* dz_part;
-  float* dcls; float* pair_dead;
+  float* dcls; float* dgpart; float* pair_dead;
   size_t total;
 };
 static TailWork carve(float* base, int B, int D, int V) {
@@ -487,6 +507,7 @@ static TailWork carve(float* base, int B, int D, int V) {
   w.dz_core = take((size_t)B * 2 * D); w.dlat_direct = take((size_t)B * 4 * D); w.dlat = take((size_t)B * 4 * D);
   w.dpooled = take((size_t)B * TH); w.dpre = take((size_t)B * TH); w.part = take((size_t)chunks * B * 2);
   w.rowstat = take((size_t)B * 4); w.dz_part = take((size_t)chunks * B * 2 * D); w.dcls = take((size_t)B * TH);
+  w.dgpart = take((size_t)((TH + DG_CHUNK - 1) / DG_CHUNK) * B * TH);
   w.pair_dead = take(16);
   w.total = o;
   return w;
@@ -596,9 +617,10 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
     else hipLaunchKernelGGL((decoder_kernel<PASS, 0>), dim3(chunks), dim3(DEC_J), LDS, stream, d);      \
   } while (0)
   DEC_LAUNCH(1, lds12);
-  hipLaunchKernelGGL(decoder_combine_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.part, chunks, B, 1, w.rowstat, (float*)a->terms, 0.f);
+  hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 1, w.rowstat);
   DEC_LAUNCH(2, lds12);
-  hipLaunchKernelGGL(decoder_combine_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.part, chunks, B, 2, w.rowstat, (float*)a->terms, d.gscale);
+  hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 2, w.rowstat);
+  hipLaunchKernelGGL(decoder_total_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.rowstat, B, d.gscale, (float*)a->terms);
   DEC_LAUNCH(3, lds3);
 #undef DEC_LAUNCH
   if ((rc = check_launch("decoder kernels"))) return rc;
@@ -640,16 +662,20 @@ extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_ou
   if (ho.w[0] && ho.w[1] && ho.w[2] && ho.w[3])
     hipLaunchKernelGGL(rowvec_wgrad_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)w.dlat, (long)N, (const float*)a->pooled,
                        (long)TH, B, N, D, ho);
-  hipLaunchKernelGGL(rowvec_dgrad_kernel<0>, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.dlat, (long)N, B, N, D, hp,
-                     (const float*)nullptr, (float*)nullptr, w.dpooled, (long)TH);
+  const int hc = (N + DG_CHUNK - 1) / DG_CHUNK, pc = (TH + DG_CHUNK - 1) / DG_CHUNK;
+  const long bt = (long)B * TH;
+  hipLaunchKernelGGL(rowvec_dgrad_kernel<0>, dim3((B + 3) / 4, hc), dim3(256), 0, stream, (const float*)w.dlat, (long)N, B, N, D, hp,
+                     (const float*)nullptr, (float*)nullptr, w.dgpart);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((bt / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)w.dgpart, w.dpooled, bt, hc);
   PtrSet4 pp; OutSet4 po;
   for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; po.w[i] = nullptr; po.b[i] = nullptr; }
   pp.w[0] = (const float*)a->pooler_w; po.w[0] = (float*)a->d_pooler_w; po.b[0] = (float*)a->d_pooler_b;
-  hipLaunchKernelGGL(rowvec_dgrad_kernel<1>, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.dpooled, (long)TH, B, TH, TH, pp,
-                     (const float*)a->pooled, w.dpre, w.dcls, (long)TH);
+  hipLaunchKernelGGL(rowvec_dgrad_kernel<1>, dim3((B + 3) / 4, pc), dim3(256), 0, stream, (const float*)w.dpooled, (long)TH, B, TH, TH, pp,
+                     (const float*)a->pooled, w.dpre, w.dgpart);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((bt / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)w.dgpart, w.dcls, bt, pc);
   hipLaunchKernelGGL(rowvec_wgrad_kernel, dim3(TH / 4), dim3(256), 0, stream, (const float*)w.dpre, (long)TH, (const float*)a->x_last_f32,
                      (long)a->seq_len * TH, B, TH, TH, po);
-  hipMemsetAsync(a->dx_last_f32, 0, (size_t)B * a->seq_len * TH * sizeof(float), stream);
+  (void)hipMemsetAsync(a->dx_last_f32, 0, (size_t)B * a->seq_len * TH * sizeof(float), stream);
   hipLaunchKernelGGL(scatter_cls_kernel, dim3(B), dim3(256), 0, stream, (const float*)w.dcls, B, a->seq_len, (float*)a->dx_last_f32);
   return check_launch("tail backward");
 }

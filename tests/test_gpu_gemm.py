@@ -102,3 +102,50 @@ def test_bad_shapes_are_refused():
     out = torch.empty((100, 128), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(L.CarelError):
         gemm(A, A, L.GEMM_NT, L.EPI_BIAS_BF16, 100, 128, 64, out_bf16=out)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("form", ["NT", "NN", "TN"])
+def test_both_tile_variants_agree(variant, form):
+    """The 128x128 and the 256x96 (3-stage pipelined) kernels on a shape both accept; many K steps so that every
+    LDS stage is recycled several times (race screen on exact small-integer data: any stale tile shows)."""
+    lib = L.load()
+    M, N, K = 512, 384, 1024
+    g = torch.Generator().manual_seed(5)
+    ints = lambda shape: torch.randint(-3, 4, shape, generator=g).float().cuda().bfloat16()
+    try:
+        L.check(lib.carel_gemm_set_variant(variant))
+        if form == "NT":
+            A, B = ints((M, K)), ints((N, K))
+            out = torch.empty((M, N), device="cuda")
+            gemm(A, B, L.GEMM_NT, L.EPI_ADD_F32, M, N, K, out_f32=out)
+            ref = A.double() @ B.double().t()
+        elif form == "NN":
+            A, B = ints((M, K)), ints((K, N))
+            out = torch.empty((M, N), device="cuda")
+            gemm(A, B, L.GEMM_NN, L.EPI_ADD_F32, M, N, K, out_f32=out)
+            ref = A.double() @ B.double()
+        else:
+            A, B = ints((K, M)), ints((K, N))
+            slabs = torch.empty((2, M, N), device="cuda")
+            gemm(A, B, L.GEMM_TN, L.EPI_SLAB_F32, M, N, K, splits=2, out_f32=slabs)
+            out = slabs.sum(0)
+            ref = A.double().t() @ B.double()
+        assert torch.equal(out.double(), ref), float((out.double() - ref).abs().max())
+    finally:
+        L.check(lib.carel_gemm_set_variant(0))
+
+
+def test_v2_repeated_launches_are_identical():
+    """Race screen for the counted-vmcnt pipeline: 20 launches of an encoder-sized GEMM must agree bit for bit."""
+    M, N, K = 2048, 768, 3072
+    A, W = _rand((M, K), 1, 21).bfloat16(), _rand((N, K), 0.05, 22).bfloat16()
+    ref = None
+    for _ in range(20):
+        out = torch.empty((M, N), device="cuda")
+        gemm(A, W, L.GEMM_NT, L.EPI_ADD_F32, M, N, K, out_f32=out)
+        if ref is None:
+            ref = out.clone()
+            assert rel_err(out, A.double() @ W.double().t()) < TOL
+        else:
+            assert torch.equal(out, ref)
