@@ -1,0 +1,228 @@
+"""Host data path of the hot path's callers: `read_ECPE_data`, `ECPEDataset`, bag-of-words vocabulary.
+
+Mirrors drl_classifier_ec_mmd_final_mul.py :86-146 (ECPEDataset), :631-731 (read_ECPE_data) and
+bow_util.py :20-81 of the reference -- same names, argument meaning, outputs and quirks -- but written for
+current pandas / scikit-learn (the reference relies on `DataFrame.append` and `get_feature_names`, both
+removed) and without the reference's module globals: `tokenizer`, `bow` and `opt` are explicit arguments.
+This stays on the host by design: it runs once per dataset, not per step.
+"""
+import ast
+import random
+import re
+
+import numpy as np
+import pandas as pd
+import torch
+
+_DOC_HEADER = re.compile(r"[0-9]{1,4}[\s][0-9]{1,2}")      # the reference's document-header test (:639)
+_NON_ZH = re.compile(u"[^一-龥]")                   # non-Chinese unicode range (:102, bow_util.py:14)
+
+
+# ----------------------------------------------------------------------------------------------
+# bag-of-words vocabulary (bow_util.py)
+# ----------------------------------------------------------------------------------------------
+def _default_segmenter():
+    try:
+        import jieba
+    except ImportError as e:      # jieba is what the reference uses (:105); it is not vendored here
+        raise ImportError("Chinese word segmentation needs `jieba` (as in the reference) or an explicit "
+                          "`segmenter=` callable returning a list of words") from e
+    return jieba.lcut
+
+
+def tokenize_zh(text, segmenter=None):
+    """bow_util.py:13-17: strip every non-CJK character, then segment."""
+    seg = segmenter or _default_segmenter()
+    return seg(_NON_ZH.sub(r"", text))
+
+
+def _corpus_sentences(file_path, keep_spaces=False):
+    """Clause texts of an ECPE-format file in order (bow_util.py:21-35 / :58-75)."""
+    out = []
+    with open(file_path, encoding="utf8") as f:
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            if _DOC_HEADER.search(line):
+                doc_len = int(line.strip().split(" ")[1])
+                f.readline()                                  # pair info
+                for _ in range(doc_len):
+                    txt = f.readline().strip().split(",")[3]
+                    out.append(txt if keep_spaces else txt.replace(" ", ""))
+    return out
+
+
+def _count_vocabulary(corpus, tokenizer=None):
+    """Sorted feature names of sklearn's CountVectorizer fitted on `corpus` (get_feature_names() in the
+    reference, bow_util.py:39 / :80; get_feature_names_out() in scikit-learn >= 1.0)."""
+    from sklearn.feature_extraction.text import CountVectorizer
+    vec = CountVectorizer(tokenizer=tokenizer, token_pattern=None) if tokenizer else CountVectorizer()
+    vec.fit(corpus)
+    return list(vec.get_feature_names_out())
+
+
+def get_bow_zh(file_path, segmenter=None):
+    """bow_util.py:20-40."""
+    return _count_vocabulary(_corpus_sentences(file_path), tokenizer=lambda t: tokenize_zh(t, segmenter))
+
+
+def bow_tokenize(sentence, tokenizer=None):
+    """bow_util.py:42-48."""
+    sentence = re.sub(r"[^\w\s]", "", sentence.lower())
+    return [x for x in [t.replace("Ġ", "") for t in sentence.split(" ")] if x != ""]
+
+
+def get_bow_en(file_path, bow_optimize=False, tokenizer=None):
+    """bow_util.py:50-81 (note: with bow_optimize=False the spaces are removed, so each clause is one token)."""
+    if not bow_optimize:
+        corpus = _corpus_sentences(file_path)
+    else:
+        corpus = {"sep"}
+        for line in _corpus_sentences(file_path, keep_spaces=True):
+            corpus.update(bow_tokenize(line, tokenizer))
+        corpus = sorted(corpus)
+    return _count_vocabulary(corpus)
+
+
+# ----------------------------------------------------------------------------------------------
+# read_ECPE_data (:631-731)
+# ----------------------------------------------------------------------------------------------
+def _parse_pairs(line, language):
+    if language == "zh":       # " (5,4), (6,5)"  -> eval of each ", "-separated chunk (:647-648)
+        return [tuple(ast.literal_eval(x)) for x in line.strip().split(", ")]
+    pairs = ast.literal_eval("[" + line.strip() + "]")          # en: " (2, 1)," (:650)
+    return [(e, c) for e, c in pairs]
+
+
+def read_ECPE_data(file_path, test=False, language="zh", rng=random):
+    """Returns (df[pair,label,emotion], docs_pair_size, num_unpred_emotions) exactly like the reference:
+    same row order, same use of `random.sample` for the training negatives (so `random.seed(42)`, :27,
+    reproduces the reference's rows), same treatment of predicted emotions in test files."""
+    rows, docs_pair_size, num_unpred = [], [], 0
+    with open(file_path, encoding="utf8") as f:
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            if not _DOC_HEADER.search(line):
+                continue
+            doc_len = int(line.strip().split(" ")[1])
+            pos_pairs = _parse_pairs(f.readline(), language)
+            sentence_list, pred_emotions, sen_emo = [], [], {}
+            for _ in range(doc_len):
+                sentence = f.readline()
+                sentence_list.append(sentence)
+                parts = sentence.strip().split(",")
+                sen_emotion, sen_id = int(parts[1]), int(parts[0])
+                if sen_emotion != 6:
+                    sen_emo[sen_id] = sen_emotion
+                    pred_emotions.append(sen_id)
+            if not test:
+                emotions = list(dict.fromkeys(e for e, _ in pos_pairs))
+            else:                                   # keep only pairs whose emotion clause was predicted (:669-682)
+                keep, pre_e = [], -1
+                for i, (e, _) in enumerate(pos_pairs):
+                    if e not in pred_emotions and e != pre_e:
+                        num_unpred += 1
+                    elif e == pre_e:
+                        keep.append(i)
+                    else:
+                        keep.append(i)
+                        pred_emotions.remove(e)
+                        pre_e = e
+                pos_pairs = [pos_pairs[i] for i in keep]
+                emotions = list(dict.fromkeys(e for e, _ in pos_pairs))
+            causes = [c for _, c in pos_pairs]
+            non_causes = [i + 1 for i in range(doc_len) if (i + 1) not in causes]
+            neg_pairs = [(e, nc) for e in emotions for nc in non_causes]
+            if not test:
+                k = min(len(pos_pairs), len(neg_pairs))
+                neg_pairs = rng.sample(neg_pairs, k)                     # (:699-701)
+            else:
+                for e in pred_emotions:                                  # (:704-708)
+                    for c in range(1, doc_len + 1):
+                        neg_pairs.append((e, c))
+
+            def text(i):
+                return sentence_list[i - 1].strip().split(",")[3].replace(" ", "")
+            for e, c in pos_pairs:
+                rows.append((text(e) + "[SEP]" + text(c), 1, sen_emo[e]))
+            for e, c in neg_pairs:
+                rows.append((text(e) + "[SEP]" + text(c), 0, sen_emo[e]))
+            docs_pair_size.append(len(pos_pairs) + len(neg_pairs))
+    df = pd.DataFrame(rows, columns=["pair", "label", "emotion"])
+    if len(df) == 0:
+        df = pd.DataFrame(columns=["pair", "label", "emotion"])
+    return df, docs_pair_size, num_unpred
+
+
+# ----------------------------------------------------------------------------------------------
+# ECPEDataset (:86-146)
+# ----------------------------------------------------------------------------------------------
+class ECPEDataset(torch.utils.data.Dataset):
+    """Same item contract as the reference (:136-144): dict with `input_ids`, `attention_masks`,
+    `token_type_ids` (int64 [max_len]), `labels` f32 [1], `emo_labels` i64 [1], `cau_labels` f32 [1],
+    `bow_reps` f32 [V].  Works with the stock DataLoader(batch_size, shuffle, num_workers=0).
+
+    tokenizer: any object with the HF `encode_plus` interface (the reference's BertTokenizer /
+    RobertaTokenizer).  bow: the vocabulary list from get_bow_zh / get_bow_en.
+    pretokenize=True (default) tokenises every row once at construction instead of on every access, and the
+    vocabulary lookup is a dict instead of the reference's O(V) list.index per word -- same outputs.
+    """
+
+    def __init__(self, df, tokenizer=None, bow=None, max_len=128, segmenter=None, pretokenize=True):
+        self.tokenizer = tokenizer
+        self.pairs = df["pair"].reset_index(drop=True)
+        self.labels = df["label"].values
+        self.emo_labels = df["emotion"].values
+        self.cau_labels = df["label"].values               # (:92) cause label == pair label
+        self.max_len = max_len
+        self.bow_features = list(bow) if bow is not None else []
+        self._bow_index = {}
+        for i, w in enumerate(self.bow_features):          # first occurrence wins, like list.index
+            self._bow_index.setdefault(w, i)
+        self._segmenter = segmenter
+        self.bow_representations = [self._get_bow_representations(p) for p in self.pairs]
+        self._cache = None
+        if pretokenize and tokenizer is not None and len(self.pairs):
+            enc = [self._encode(str(p)) for p in self.pairs]
+            self._cache = tuple(torch.stack([e[k] for e in enc]) for k in range(3))
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def _get_bow_representations(self, text_pair):
+        """(:100-119) non-CJK characters are stripped even for English input."""
+        rep = np.zeros(shape=len(self.bow_features), dtype=np.float32)
+        text = _NON_ZH.sub(r"", str(text_pair))
+        if text:
+            seg = self._segmenter or _default_segmenter()
+            for word in seg(text):
+                j = self._bow_index.get(word)
+                if j is not None:
+                    rep[j] += 1
+        rep /= np.max([np.sum(rep), 1])
+        return rep
+
+    def _encode(self, pair):
+        inputs = self.tokenizer.encode_plus(pair, None, add_special_tokens=True, max_length=self.max_len,
+                                            padding="max_length", return_token_type_ids=True, truncation=True,
+                                            return_attention_mask=True, return_tensors="pt")
+        return (inputs["input_ids"].flatten().to(torch.long), inputs["attention_mask"].flatten().to(torch.long),
+                inputs["token_type_ids"].flatten().to(torch.long))
+
+    def __getitem__(self, index):
+        if self._cache is not None:
+            ids, att, tt = (c[index] for c in self._cache)
+        else:
+            ids, att, tt = self._encode(str(self.pairs[index]))
+        return {
+            "input_ids": ids,
+            "attention_masks": att,
+            "token_type_ids": tt,
+            "labels": torch.FloatTensor([self.labels[index]]),
+            "emo_labels": torch.LongTensor([self.emo_labels[index]]),
+            "cau_labels": torch.FloatTensor([self.cau_labels[index]]),
+            "bow_reps": torch.from_numpy(self.bow_representations[index]).clone(),
+        }

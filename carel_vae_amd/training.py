@@ -1,0 +1,140 @@
+"""The reference's training driver around the hot path: `train`, `generate_self_train_data`, `save_ckp`,
+`load_ckp` (drl_classifier_ec_mmd_final_mul.py :603-628, :734-799, :802-922), same signatures and control
+flow; `opt` is an explicit keyword instead of a module global.  The step body (:823-845) is unchanged: the
+model/optimiser objects it calls are carel_vae_amd.DrlClassifier and FusedAdam (or any torch optimiser).
+"""
+import os
+from random import randint
+
+import pandas as pd
+import torch
+
+
+def _prf1(labels, preds):
+    """binary precision / recall / F1 with sklearn's zero-division convention (0.0), ref :868-870."""
+    y = [int(round(v[0] if isinstance(v, (list, tuple)) else v)) for v in labels]
+    p = [int(round(v[0] if isinstance(v, (list, tuple)) else v)) for v in preds]
+    tp = sum(1 for a, b in zip(y, p) if a == 1 and b == 1)
+    fp = sum(1 for a, b in zip(y, p) if a == 0 and b == 1)
+    fn = sum(1 for a, b in zip(y, p) if a == 1 and b == 0)
+    prec = tp / (tp + fp) if tp + fp else 0.0
+    rec = tp / (tp + fn) if tp + fn else 0.0
+    f1 = 2 * prec * rec / (prec + rec) if prec + rec else 0.0
+    return prec, rec, f1
+
+
+def load_ckp(checkpoint_path, model):
+    """ref :603-613.  Loads tensors only (no pickled code is executed)."""
+    checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    model.load_state_dict(checkpoint)
+    return model
+
+
+def save_ckp(state, ckpt_path, model_id="carel"):
+    """ref :616-628: <ckpt_path>/<model_id>.pt holding the state_dict (reference key names)."""
+    if not os.path.exists(ckpt_path):
+        os.makedirs(ckpt_path)
+    torch.save({k: v.detach().cpu().clone() for k, v in state.items()}, os.path.join(ckpt_path, model_id + ".pt"))
+
+
+def generate_self_train_data(test_docs_pair_size, test_df, test_loader, model, strategy, device="cuda"):
+    """ref :734-799: pseudo-label the test documents (top pair positive, random / extreme / thresholded negative)."""
+    predicted_df = test_df.copy()
+    model.eval()
+    with torch.no_grad():
+        for data in test_loader:
+            ids = data["input_ids"].to(device, dtype=torch.long)
+            att = data["attention_masks"].to(device, dtype=torch.long)
+            tt = data["token_type_ids"].to(device, dtype=torch.long)
+            outs = model.get_pair_preds(ids, att, tt)
+            predicted_df["label"] = [x[0] for x in outs]
+    rows, curr = [], 0
+    for doc_pair_size in test_docs_pair_size:
+        max_pos, max_neg = float("-inf"), float("-inf")
+        pos_pair = pos_emotion = neg_pair = neg_emotion = None
+        prob_dict = {}
+        for i in range(doc_pair_size):
+            index = i + curr
+            row = predicted_df.iloc[index]
+            prob = row["label"]
+            if strategy == "threshold":
+                if prob > 0.5 and prob > max_pos:
+                    pos_pair, max_pos = row["pair"], prob
+                elif 0.5 >= prob > max_neg:
+                    neg_pair, max_neg = row["pair"], prob
+            elif strategy in ("random", "extreme"):
+                prob_dict[index] = prob
+                srt = sorted(prob_dict.items(), key=lambda x: x[1], reverse=True)
+                top = predicted_df.iloc[srt[0][0]]
+                pos_pair, pos_emotion = top["pair"], top["emotion"]
+                if strategy == "random":
+                    if len(srt) == 1:
+                        continue
+                    other = predicted_df.iloc[srt[randint(1, len(srt) - 1)][0]]
+                    neg_pair, neg_emotion = other["pair"], other["emotion"]
+                else:
+                    neg_pair = predicted_df.iloc[srt[-1][0]]["pair"]
+        curr += doc_pair_size
+        if pos_pair is not None and neg_pair is not None:
+            rows.append((pos_pair, 1, pos_emotion))
+            rows.append((neg_pair, 0, neg_emotion))
+    return pd.DataFrame(rows, columns=["pair", "label", "emotion"])
+
+
+def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs, self_metrics=None, self_train=False,
+          opt=None, log=print):
+    """ref :802-922.  One epoch = every batch through forward / zero_grad / backward / step (:823-845), then one
+    evaluation pass with `get_pair_preds`, checkpointing the best F1."""
+    opt = opt if opt is not None else model.opt
+    vae_and_cls_opt = optimizers[0]
+    max_p = max_r = max_f1 = 0.0
+    self_p = self_r = self_f1 = 0.0
+    if self_train:
+        self_p, self_r, self_f1 = self_metrics
+        epochs = opt.self_epochs
+    else:
+        epochs = opt.epochs
+    for epoch in range(1, epochs + 1):
+        running_loss = 0
+        model.train()
+        log("\n############ Epoch {}: Training Start ############\n".format(epoch))
+        for iteration, batch in enumerate(train_loader):
+            ids = batch["input_ids"].to(device, dtype=torch.long)
+            att = batch["attention_masks"].to(device, dtype=torch.long)
+            tt = batch["token_type_ids"].to(device, dtype=torch.long)
+            labels = batch["labels"].to(device, dtype=torch.float)
+            emo = batch["emo_labels"].to(device, dtype=torch.long)
+            cau = batch["cau_labels"].to(device, dtype=torch.float)
+            bow = batch["bow_reps"].to(device, dtype=torch.float)
+            loss = model(ids, att, tt, emo, cau, labels, bow, iteration)
+            vae_and_cls_opt.zero_grad()
+            loss.backward()
+            vae_and_cls_opt.step()
+            running_loss += loss.item()
+            if iteration % 10 == 9:
+                log("[%d, %5d] training loss: %.4f" % (epoch, iteration + 1, running_loss / 10))
+                running_loss = 0.0
+        model.eval()
+        with torch.no_grad():
+            for batch in test_loader:
+                ids = batch["input_ids"].to(device, dtype=torch.long)
+                att = batch["attention_masks"].to(device, dtype=torch.long)
+                tt = batch["token_type_ids"].to(device, dtype=torch.long)
+                labels = batch["labels"].cpu().numpy().tolist()
+                preds = model.get_pair_preds(ids, att, tt)
+                labels += [[1]] * num_unpred_pairs            # unpredicted emotions count as misses (:864-865)
+                preds += [[0]] * num_unpred_pairs
+                p, r, f1 = _prf1(labels, preds)
+                log("current test pair precision: {:.4f}, recall: {:.4f}, f1 socre: {:.4f}\n".format(p, r, f1))
+                checkpoint = model.state_dict()
+                if f1 > max_f1 and not self_train:
+                    save_ckp(checkpoint, opt.best_model_path, opt.model_id)
+                    max_p, max_r, max_f1 = p, r, f1
+                elif f1 > self_f1 and self_train:
+                    save_ckp(checkpoint, opt.best_model_path, opt.model_id)
+                    self_p, self_r, self_f1 = p, r, f1
+    best = os.path.join(opt.best_model_path, opt.model_id + ".pt")
+    best_model = load_ckp(best, model) if os.path.exists(best) else model
+    if not self_train:
+        return best_model
+    return best_model, self_p, self_r, self_f1

@@ -1,0 +1,79 @@
+"""Data-parallel plumbing on CPU: two gloo ranks exercise the bucketed gradient reducer and the
+global-batch exchange (z all-gather, label sum, noise broadcast) used by carel_vae_amd.dp.DataParallel."""
+import os
+import socket
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from carel_vae_amd import _lib as L
+        from carel_vae_amd.dp import DataParallel, FlatGradReducer
+        # ---- reducer: three buckets of a flat gradient, reduced asynchronously, then averaged
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        red = FlatGradReducer(flat, {"tail": (900, 1000), "layer0": (100, 900), "embeddings": (0, 100)})
+        for name in ("tail", "layer0", "embeddings"):
+            red.reduce(name)
+        red.wait()
+        expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        ok_reduce = bool(torch.allclose(flat, expect))
+        # ---- DataParallel hooks on a stand-in model (flat buffers + offsets only)
+        n_layers = 2
+        offs = {"encoder.embeddings.word_embeddings.weight": 0}
+        o = 64
+        for l in range(n_layers):
+            offs[f"encoder.encoder.layer.{l}.attention.self.query.weight"] = o
+            o += 128
+        offs["encoder.pooler.dense.weight"] = o
+        total = o + 96
+        model = SimpleNamespace(_flat=torch.full((total,), float(rank + 1)), _flat_grad=torch.full((total,), float(rank + 1)),
+                                _offs=offs, cfg=SimpleNamespace(layers=n_layers), _dp=None, _shadow_versions=1)
+        dp = DataParallel(model)
+        ok_bcast = bool((model._flat == 1.0).all()) and model._shadow_versions is None     # replicas start identical
+        b = dp.reducer.buckets
+        ok_buckets = b["embeddings"] == (0, 64) and b["layer0"] == (64, 192) and b["layer1"] == (192, 320) and b["tail"] == (320, total)
+        e, c = dp.broadcast_noise(torch.full((24,), float(rank)), torch.full((24,), 10.0 + rank))
+        ok_noise = bool((e == 0).all() and (c == 10).all())
+        B = 4
+        call = SimpleNamespace(buf=SimpleNamespace(z=torch.full((B, 48), float(rank))), labels={"pair": torch.ones(B) * (rank == 0)})
+        ta = L.TailArgs()
+        dp.fill_global(ta, call)
+        z_all, ysum = call.dp_keep
+        ok_global = (ta.global_n == world * B and ta.global_row_offset == rank * B and ta.mmd_grad_scale == float(world)
+                     and float(ysum) == B and bool((z_all[:B] == 0).all()) and bool((z_all[B:] == 1).all())
+                     and ta.z_global == z_all.data_ptr())
+        dp.tail_done(); dp.layer_done(1); dp.layer_done(0); dp.backward_done()
+        ok_avg = bool(torch.allclose(model._flat_grad, torch.full((total,), (1.0 + 2.0) / 2)))
+        ok_rows = dp.row_offset(B) == rank * B
+        q.put((rank, ok_reduce, ok_bcast, ok_buckets, ok_noise, ok_global, ok_avg, ok_rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel_plumbing():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r

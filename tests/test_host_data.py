@@ -1,0 +1,106 @@
+"""Host data path (read_ECPE_data / ECPEDataset / BoW vocabulary) against golden vectors produced by the
+reference's own read_ECPE_data (tests/golden/gen_golden_data.py)."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from carel_vae_amd import data as D
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "ecpe_data.json"), encoding="utf8"))
+
+
+def digest(df):
+    h = hashlib.sha1()
+    for p, l, e in zip(df["pair"], df["label"], df["emotion"]):
+        h.update(("%s|%d|%d\n" % (p, int(l), int(e))).encode("utf8"))
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", list(GOLD["samples"]))
+def test_read_ecpe_samples_match_reference(name):
+    g = GOLD["samples"][name]
+    random.seed(42)
+    df, sizes, unpred = D.read_ECPE_data(os.path.join(HERE, "golden", "ecpe", name), test=g["test"], language=g["language"])
+    assert len(df) == g["rows"] and sizes == g["docs_pair_size"] and unpred == g["num_unpred"]
+    assert [[p, int(l), int(e)] for p, l, e in zip(df["pair"][:6], df["label"][:6], df["emotion"][:6])] == g["head"]
+    assert digest(df) == g["digest"]
+    assert list(df.columns) == ["pair", "label", "emotion"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("rel", list(GOLD["reference_files"]))
+def test_read_ecpe_reference_files(rel):
+    g = GOLD["reference_files"][rel]
+    random.seed(42)
+    df, sizes, unpred = D.read_ECPE_data(os.path.join("/root/reference", rel), test=g["test"], language=g["language"])
+    assert (len(df), len(sizes), unpred) == (g["rows"], g["docs"], g["num_unpred"])
+    assert digest(df) == g["digest"]
+
+
+class FakeTokenizer:
+    """HF `encode_plus` interface: [CLS]=101, one id per character (ord % 1000 + 200), [SEP]=102, pad 0."""
+
+    def encode_plus(self, text, text_pair=None, add_special_tokens=True, max_length=128, padding="max_length",
+                    return_token_type_ids=True, truncation=True, return_attention_mask=True, return_tensors="pt"):
+        ids = [101] + [ord(c) % 1000 + 200 for c in text][:max_length - 2] + [102]
+        att = [1] * len(ids) + [0] * (max_length - len(ids))
+        ids = ids + [0] * (max_length - len(ids))
+        t = lambda v: torch.tensor([v])
+        return {"input_ids": t(ids), "attention_mask": t(att), "token_type_ids": t([0] * max_length)}
+
+
+def char_segmenter(text):
+    return list(text)
+
+
+def test_dataset_item_contract_and_bow():
+    random.seed(42)
+    df, _, _ = D.read_ECPE_data(os.path.join(HERE, "golden", "ecpe", "sample_zh_train.txt"))
+    bow = sorted({c for p in df["pair"] for c in D._NON_ZH.sub("", p)})
+    for pre in (True, False):
+        ds = D.ECPEDataset(df, FakeTokenizer(), bow, max_len=128, segmenter=char_segmenter, pretokenize=pre)
+        assert len(ds) == len(df)
+        it = ds[3]
+        assert set(it) == {"input_ids", "attention_masks", "token_type_ids", "labels", "emo_labels", "cau_labels", "bow_reps"}
+        assert it["input_ids"].dtype == torch.int64 and it["input_ids"].shape == (128,)
+        assert it["attention_masks"].dtype == torch.int64 and it["token_type_ids"].shape == (128,)
+        assert it["labels"].dtype == torch.float32 and it["labels"].shape == (1,)
+        assert it["emo_labels"].dtype == torch.int64 and it["cau_labels"].dtype == torch.float32
+        assert torch.equal(it["labels"], it["cau_labels"])                     # ref :92
+        assert it["bow_reps"].dtype == torch.float32 and it["bow_reps"].shape == (len(bow),)
+        assert abs(float(it["bow_reps"].sum()) - 1.0) < 1e-6                   # count / max(sum, 1)   ref :116
+        # reference semantics of one representation, recomputed the slow way (list.index per character)
+        txt = D._NON_ZH.sub("", df["pair"][3])
+        ref = np.zeros(len(bow), dtype=np.float32)
+        for ch in txt:
+            if ch in bow:
+                ref[bow.index(ch)] += 1
+        ref /= max(ref.sum(), 1)
+        np.testing.assert_allclose(it["bow_reps"].numpy(), ref)
+    loader = torch.utils.data.DataLoader(ds, batch_size=5, shuffle=False, num_workers=0)
+    b = next(iter(loader))
+    assert b["input_ids"].shape == (5, 128) and b["bow_reps"].shape == (5, len(bow)) and b["labels"].shape == (5, 1)
+
+
+def test_english_bow_targets_are_all_zero():
+    """non-CJK characters are stripped before the BoW lookup, so English targets are zero."""
+    random.seed(42)
+    df, _, _ = D.read_ECPE_data(os.path.join(HERE, "golden", "ecpe", "sample_en_train.txt"), language="en")
+    ds = D.ECPEDataset(df, FakeTokenizer(), ["letter", "storm"], segmenter=char_segmenter)
+    assert float(ds[0]["bow_reps"].abs().sum()) == 0.0
+
+
+def test_bow_vocabularies():
+    p = os.path.join(HERE, "golden", "ecpe", "sample_zh_train.txt")
+    v = D.get_bow_zh(p, segmenter=char_segmenter)
+    assert v == sorted(set(v)) and "雨" in v and all(len(w) == 1 for w in v)
+    ven = D.get_bow_en(os.path.join(HERE, "golden", "ecpe", "sample_en_train.txt"))
+    assert len(ven) == 7            # spaces are removed first (bow_util.py:70): one "word" per clause
+    vopt = D.get_bow_en(os.path.join(HERE, "golden", "ecpe", "sample_en_train.txt"), bow_optimize=True)
+    assert "sep" in vopt and "storm" in vopt and "villagers" in vopt

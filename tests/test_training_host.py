@@ -1,0 +1,74 @@
+"""Control flow of the reference's training driver (train / generate_self_train_data / save_ckp / load_ckp)
+with a stand-in model on CPU (the numeric step itself is covered by the -m gpu tests)."""
+import os
+import random
+
+import pandas as pd
+import torch
+import torch.nn as nn
+
+from carel_vae_amd import training as T
+from carel_vae_amd.drl_classifier import make_opt
+
+
+class TinyModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.zeros(3))
+        self.calls = []
+
+    def forward(self, ids, att, tt, emo, cau, labels, bow, iteration):
+        self.calls.append(int(iteration))
+        return (self.w.sum() - 1.0) ** 2 + labels.mean() * 0
+
+    def get_pair_preds(self, ids, att, tt):
+        return [[float(i % 2)] for i in range(ids.shape[0])]
+
+
+def batches(n, bs):
+    for s in range(0, n, bs):
+        m = min(bs, n - s)
+        yield {"input_ids": torch.zeros((m, 8), dtype=torch.long), "attention_masks": torch.ones((m, 8), dtype=torch.long),
+               "token_type_ids": torch.zeros((m, 8), dtype=torch.long), "labels": torch.tensor([[float(i % 2)] for i in range(s, s + m)]),
+               "emo_labels": torch.zeros((m, 1), dtype=torch.long), "cau_labels": torch.zeros((m, 1)), "bow_reps": torch.zeros((m, 5))}
+
+
+def test_prf1_matches_definition():
+    p, r, f = T._prf1([[1], [0], [1], [1]], [[1.0], [1.0], [0.0], [1.0]])
+    assert (p, r) == (2 / 3, 2 / 3) and abs(f - 2 / 3) < 1e-12
+    assert T._prf1([[0]], [[0.0]]) == (0.0, 0.0, 0.0)
+
+
+def test_train_loop_checkpoint_and_iteration_counter(tmp_path):
+    opt = make_opt(epochs=2, self_epochs=1, best_model_path=str(tmp_path / "ckpt"), model_id="t1")
+    model = TinyModel()
+    optim = torch.optim.SGD(model.parameters(), lr=0.1)
+    logs = []
+    best = T.train(list(batches(10, 4)), list(batches(6, 6)), model, [optim], "cpu", num_unpred_pairs=2, opt=opt, log=logs.append)
+    assert model.calls == [0, 1, 2, 0, 1, 2]           # `iteration` restarts every epoch (ref :823, quirk Q4)
+    assert os.path.exists(tmp_path / "ckpt" / "t1.pt") and best is model
+    assert float(model.w.sum()) != 0.0
+    out = T.train(list(batches(4, 4)), list(batches(6, 6)), model, [optim], "cpu", 2, self_metrics=[0.0, 0.0, 0.0], self_train=True,
+                  opt=opt, log=logs.append)
+    assert len(out) == 4 and out[0] is model
+
+
+def test_save_load_roundtrip(tmp_path):
+    m = TinyModel()
+    with torch.no_grad():
+        m.w.copy_(torch.tensor([1.0, 2.0, 3.0]))
+    T.save_ckp(m.state_dict(), str(tmp_path), "abc")
+    m2 = TinyModel()
+    T.load_ckp(str(tmp_path / "abc.pt"), m2)
+    assert torch.equal(m2.w, m.w)
+
+
+def test_generate_self_train_data_random_strategy():
+    random.seed(0)
+    df = pd.DataFrame({"pair": ["p%d" % i for i in range(7)], "label": [0] * 7, "emotion": [i % 6 for i in range(7)]})
+    loader = [{"input_ids": torch.zeros((7, 8), dtype=torch.long), "attention_masks": torch.ones((7, 8), dtype=torch.long),
+               "token_type_ids": torch.zeros((7, 8), dtype=torch.long)}]
+    out = T.generate_self_train_data([3, 1, 3], df, loader, TinyModel(), "random", device="cpu")
+    assert list(out.columns) == ["pair", "label", "emotion"]
+    assert list(out["label"]) == [1, 0, 1, 0]          # the single-pair document yields nothing (ref :782)
+    assert out["pair"][0] == "p1" and out["pair"][2] == "p5"   # highest predicted score per document
