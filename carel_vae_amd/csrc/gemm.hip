@@ -90,7 +90,67 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
   }
 }
 
-template <bool AT, bool BT, int EPI>
+// ---------------------------------------------------------------------------------------------
+// Coalesced epilogue: 8 consecutive columns (col..col+7) of C row `row`; v = fp32 accumulators read back
+// from the LDS-staged tile.  8 threads cover 64 columns of one row -> full 128/256-byte lines.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4 a, float* u) {
+  u[0] = bf2f((bf16_t)(a.x & 0xffff)); u[1] = bf2f((bf16_t)(a.x >> 16)); u[2] = bf2f((bf16_t)(a.y & 0xffff)); u[3] = bf2f((bf16_t)(a.y >> 16));
+  u[4] = bf2f((bf16_t)(a.z & 0xffff)); u[5] = bf2f((bf16_t)(a.z >> 16)); u[6] = bf2f((bf16_t)(a.w & 0xffff)); u[7] = bf2f((bf16_t)(a.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  return uint4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
+  const long off = row * p.ldc + col;
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
+    if (p.bias) {
+      const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+  }
+  if (EPI == EPI_BIAS_BF16) {
+    *(uint4*)(p.out0 + off) = pack8(v);
+  } else if (EPI == EPI_BIAS_GELU) {
+    const uint4 o = pack8(v);
+    *(uint4*)(p.out0 + off) = o;
+    float u[8];
+    unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = gelu_erf(u[e]);
+    *(uint4*)(p.out1 + off) = pack8(u);
+  } else if (EPI == EPI_BIAS_DROP_RESID) {
+    const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
+    const uint32_t e = (uint32_t)off;
+    float4 o0, o1;
+    o0.x = v[0] * dropout_mult(p.drop, e + 0) + r0.x; o0.y = v[1] * dropout_mult(p.drop, e + 1) + r0.y;
+    o0.z = v[2] * dropout_mult(p.drop, e + 2) + r0.z; o0.w = v[3] * dropout_mult(p.drop, e + 3) + r0.w;
+    o1.x = v[4] * dropout_mult(p.drop, e + 4) + r1.x; o1.y = v[5] * dropout_mult(p.drop, e + 5) + r1.y;
+    o1.z = v[6] * dropout_mult(p.drop, e + 6) + r1.z; o1.w = v[7] * dropout_mult(p.drop, e + 7) + r1.w;
+    *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
+  } else if (EPI == EPI_DGELU_BF16) {
+    float u[8];
+    unpack8(*(const uint4*)(p.aux + off), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(u[e]);
+    *(uint4*)(p.out0 + off) = pack8(v);
+  } else if (EPI == EPI_ADD_F32) {
+    float4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+    if (p.resid) {
+      const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
+      o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w; o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+    }
+    *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
+  } else {  // EPI_SLAB_F32
+    float* o = p.outf + (long)blockIdx.z * p.M * p.ldc + off;
+    *(float4*)o = float4{v[0], v[1], v[2], v[3]}; *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
+  }
+}
+
+// DBG (timing ablations only, results are wrong): 1 = no epilogue stores, 2 = no global->LDS loads after the
+// first tile, 3 = no MFMA.  0 = the real kernel.
+template <bool AT, bool BT, int EPI, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[65536];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -124,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && DBG != 2) stage(kt + 1, (kt + 1) & 1);
     const char* ta = smem + (kt & 1) * 32768;
     const char* tb = ta + 16384;
 #pragma unroll
@@ -138,19 +198,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
+        for (int j = 0; j < 4; ++j) {
+          if (DBG == 3) { asm volatile("" :: "v"(fb[j]), "v"(fa[i])); }
+          else acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  if (DBG == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    return;
+  }
 
   // ------------------------------------------------------------------ epilogue
-  // lane: C row = m0 + wr*64 + i*16 + (lane&15); columns n0 + wc*64 + j*16 + (lane>>4)*4 + [0..3]
+  // The accumulators go through LDS (the staging buffers are free now) so that global memory sees whole
+  // 128/256-byte row segments: two halves of 64 columns; lane -> fragment rows on the way in,
+  // 8 threads -> one 64-column row segment on the way out.
+  float* ct = (float*)smem;                 // [128][CT_LD] fp32
+  constexpr int CT_LD = 68;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long row = m0 + wr * 64 + i * 16 + (lane & 15);
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    if (wc == h) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) epi_store<EPI>(p, acc[i][j], row, n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *(f32x4*)(ct + (wr * 64 + i * 16 + (lane & 15)) * CT_LD + j * 16 + (lane >> 4) * 4) = acc[i][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 32 + (threadIdx.x >> 3), c8 = (threadIdx.x & 7) * 8;
+      const float4 a = *(const float4*)(ct + r * CT_LD + c8), b = *(const float4*)(ct + r * CT_LD + c8 + 4);
+      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      epi_store8<EPI>(p, v, m0 + r, n0 + h * 64 + c8);
+    }
   }
 }
 
@@ -288,6 +375,12 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (v2_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && !v1_ok))) return launch_v2<AT, BT, EPI>(p, splits, s);
   if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 13) {   // timing ablations
+    if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 1>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 2>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 3>), grid, dim3(256), 0, s, p);
+    return check_launch("gemm_kernel<dbg>");
+  }
   hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI>), grid, dim3(256), 0, s, p);
   return check_launch("gemm_kernel");
 }
