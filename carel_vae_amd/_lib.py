@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("out_bf16", C.c_void_p), ("out2_bf16", C.c_void_p), ("out_f32", C.c_void_p),
                 ("bias", C.c_void_p), ("resid_f32", C.c_void_p), ("aux_bf16", C.c_void_p),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float)]
+                ("drop_p", C.c_float), ("colsum_part", C.c_void_p)]
 
 
 class MmdArgs(C.Structure):
@@ -108,6 +108,12 @@ class EncoderArgs(C.Structure):
                 ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p)]
 
 
+class HsicArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("ldx", C.c_int64), ("ldy", C.c_int64), ("m", C.c_int32), ("d", C.c_int32),
+                ("s_x", C.c_float), ("s_y", C.c_float), ("hsic_out", C.c_void_p), ("grad_hsic", C.c_void_p),
+                ("gx", C.c_void_p), ("gy", C.c_void_p)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
 
@@ -123,6 +129,8 @@ SIGNATURES = {
     "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
+    "carel_hsic_fwd": (C.c_int, [C.POINTER(HsicArgs), C.c_void_p]),
+    "carel_hsic_bwd": (C.c_int, [C.POINTER(HsicArgs), C.c_void_p]),
     "carel_selftest_layouts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "carel_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     "carel_embed_ln_bwd_blocks": (C.c_int, [C.c_int64]),
@@ -132,6 +140,7 @@ SIGNATURES = {
     "carel_layernorm_bwd_blocks": (C.c_int, [C.c_int64]),
     "carel_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_float] + [C.c_void_p] * 7),
+    "carel_partial_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_colsum_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p]),
     "carel_tail_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -79,11 +79,29 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // ---------------------------------------------------------------- math
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-level): one exp, one reciprocal, a
+// degree-5 Horner chain -- about a third of the instructions of the correctly-rounded erff, which matters in
+// the GEMM epilogues that evaluate it 25 M times per layer.  ez = exp(-z^2) is returned for re-use.
+__device__ __forceinline__ float erf_as(float z, float& ez) {
+  const float az = fabsf(z);
+  const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
+  ez = __expf(-az * az);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = 1.0f - poly * t * ez;
+  return copysignf(e, z);
+}
+// GELU(x) = x * Phi(x), exact-erf form (HF `gelu`), and its derivative Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf(float x) {
+  float ez;
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f, ez));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float ez;                                     // = exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f, ez));
+  return fmaf(x * 0.39894228040143268f, ez, cdf);
 }
 
 // =========================================================================================

@@ -59,11 +59,11 @@ struct Scratch { char* dy; char* dyb; char* du; char* dctx; char* dqkv; char* sl
 struct ScratchLayout { size_t o_dy, o_dyb, o_du, o_dctx, o_dqkv, o_slabs, o_part, total; };
 
 // split-K factor of the weight-gradient GEMMs (K = tokens).  Measured at T = 8192 (tools/bench_gemm.py):
-// 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 4 (8 is ~10 % faster in the GEMM but the
-// slab reduction reads twice the bytes).
+// 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 8 (with the 1x8 XCD patch order: 66 us vs
+// 82 us at 4, which pays for the 6 us longer slab reduction).
 int wgrad_splits(long T, int M, int N) {
   const int tiles = (M / 128) * (N / 128);
-  const int want = tiles < 64 ? 8 : 4;
+  const int want = (tiles < 64 || tiles >= 128) ? 8 : 4;
   int s = 1;
   while (s < want && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
   return s;
@@ -108,11 +108,11 @@ int enc_check(const carel_encoder_args* a, const char* who) {
 
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
-              uint32_t off, float p, void* stream) {
+              uint32_t off, float p, void* stream, void* colsum_part = nullptr) {
   carel_gemm_args g;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
-  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p;
+  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part;
   return carel_gemm_bf16(&g, stream);
 }
 
@@ -206,10 +206,11 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = carel_layernorm_bwd(a->dx, la.h2, la.st2, w.ln2_g, T, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, s.dy, s.dyb,
                                 g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
+  //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)T, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
-                      nullptr, la.u, 0, 0, 0, 0.f, stream))) return rc;
+                      nullptr, la.u, 0, 0, 0, 0.f, stream, s.part))) return rc;
+  if ((rc = carel_partial_reduce_f32(s.part, g.ffn1_b, EI, (int)(T / 128), 0, stream))) return rc;
   if ((rc = wgrad_call(s.dyb, la.g, T, EH, EI, s.slabs, g.ffn2_w, stream))) return rc;
-  if ((rc = carel_colsum_bf16(s.du, EI, T, EI, g.ffn1_b, 0, s.part, stream))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)T, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
                       nullptr, 0, 0, 0, 0.f, stream))) return rc;

@@ -37,6 +37,8 @@ struct GemmParams {
   const bf16_t* aux;        // [M,ldc] bf16 (pre-GELU) for EPI_DGELU
   Dropout drop;
   int tiles_m, tiles_n;
+  float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
+  int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -101,6 +103,7 @@ __device__ __forceinline__ void unpack8(const uint4 a, float* u) {
 __device__ __forceinline__ uint4 pack8(const float* v) {
   return uint4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
+// after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
 template <int EPI>
 __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
   const long off = row * p.ldc + col;
@@ -156,12 +159,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  // XCD-aware, bijective tile remap: blocks that share an XCD (bid % 8) get neighbouring tiles
-  const int nwg = p.tiles_m * p.tiles_n;
+  // XCD-aware tile map: blocks that share an XCD (bid % 8; round-robin dispatch) get a compact 2-D patch of tiles
+  // (tiles_m / xm) x (tiles_n / xn), walked N-fastest, so that the patch's B columns stay in that XCD's L2 and each
+  // A row panel is read once per patch.  Falls back to bijective row-major chunks when the counts do not divide.
   const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  int tm, tn;
+  {
+    const int xn = p.xcd_n, xm = 8 / xn;
+    if (xn > 1 && p.tiles_m % xm == 0 && p.tiles_n % xn == 0) {
+      const int xcd = bid & 7, local = bid >> 3;
+      const int pm = p.tiles_m / xm, pn = p.tiles_n / xn;
+      (void)pm;
+      tm = (xcd / xn) * pm + local / pn;
+      tn = (xcd % xn) * pn + local % pn;
+    } else {
+      const int nwg = p.tiles_m * p.tiles_n;
+      const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+      const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+      tm = tid / p.tiles_n; tn = tid - tm * p.tiles_n;
+    }
+  }
   const long m0 = (long)tm * 128, n0 = (long)tn * 128;
   const long kbase = (long)blockIdx.z * p.K;
 
@@ -231,12 +248,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           *(f32x4*)(ct + (wr * 64 + i * 16 + (lane & 15)) * CT_LD + j * 16 + (lane >> 4) * 4) = acc[i][j];
     }
     __syncthreads();
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = it * 32 + (threadIdx.x >> 3), c8 = (threadIdx.x & 7) * 8;
       const float4 a = *(const float4*)(ct + r * CT_LD + c8), b = *(const float4*)(ct + r * CT_LD + c8 + 4);
       float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       epi_store8<EPI>(p, v, m0 + r, n0 + h * 64 + c8);
+      if (EPI == EPI_DGELU_BF16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += v[e];
+      }
+    }
+    if (EPI == EPI_DGELU_BF16 && p.colsum_part) {       // block-uniform branch
+      __syncthreads();
+      float* sc = ct;                                     // [32][64] partial column sums
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc[(threadIdx.x >> 3) * 64 + (threadIdx.x & 7) * 8 + e] = cs[e];
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += sc[r * 64 + threadIdx.x];
+        p.colsum_part[(long)tm * p.N + n0 + h * 64 + threadIdx.x] = t;
+      }
     }
   }
 }
@@ -364,6 +399,7 @@ static int launch_v2(GemmParams p, int splits, hipStream_t s) {
 }
 
 static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x96 kernel
+static int g_xcd_n = 1;          // tuning hook: XCD patch layout (see gemm_kernel)
 
 template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
@@ -372,7 +408,10 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
   // measured on MI355X (tools/bench_gemm.py, T = 8192): the 128x128 tile at 2 workgroups/CU wins or ties on every
   // encoder shape (the second resident workgroup hides the other's prologue/epilogue; K is only 12-48 steps), so
   // the 256x96 three-stage kernel is used only when asked for or when the shape does not fit 128x128.
-  if (v2_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && !v1_ok))) return launch_v2<AT, BT, EPI>(p, splits, s);
+  if (v2_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && !v1_ok))) {
+    if (p.colsum_part) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: colsum_part needs the 128x128 tile (M, N multiples of 128)");
+    return launch_v2<AT, BT, EPI>(p, splits, s);
+  }
   if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
   if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 13) {   // timing ablations
@@ -467,7 +506,11 @@ static int gemm_shape_ok(int M, int N, int K, int splits) {
   return 1;
 }
 
-extern "C" int carel_gemm_set_variant(int32_t v) { g_gemm_variant = v; return CAREL_OK; }
+extern "C" int carel_gemm_set_variant(int32_t v) {
+  if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
+  g_gemm_variant = v;
+  return CAREL_OK;
+}
 
 extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -486,6 +529,8 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   p.bias = (const float*)a->bias; p.resid = (const float*)a->resid_f32; p.aux = (const bf16_t*)a->aux_bf16;
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
+  p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n == 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
+  p.colsum_part = (float*)a->colsum_part;
   const int form = a->form, epi = a->epilogue;
   if (splits != 1 && epi != EPI_SLAB_F32) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: split-K only with the slab epilogue");
 #define NEED(ptr, what) if (!(ptr)) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: epilogue needs " what)

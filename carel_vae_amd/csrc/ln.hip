@@ -450,3 +450,10 @@ extern "C" int carel_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_
                      chunks, accumulate);
   return check_launch("partial_reduce_kernel");
 }
+
+extern "C" int carel_partial_reduce_f32(const void* partials, void* out, int32_t n, int32_t nparts, int32_t accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!partials || !out || n <= 0 || nparts <= 0) return set_error(CAREL_ERR_ARG, "carel_partial_reduce_f32: bad arguments");
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, (const float*)partials, (float*)out, n, nparts, accumulate);
+  return check_launch("partial_reduce_kernel");
+}

@@ -181,6 +181,26 @@ class _MMDFn(torch.autograd.Function):
         return g1, g2, None, None
 
 
+class _HSICFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, s_x, s_y):
+        xc, yc = x.contiguous().float(), y.contiguous().float()
+        ctx.save_for_backward(xc, yc)
+        ctx.s = (s_x, s_y)
+        return ops.hsic(xc, yc, s_x, s_y).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gx, gy = ops.hsic_backward(x, y, g, *ctx.s)
+        return gx, gy, None, None
+
+
+def HSIC(x, y, s_x=1, s_y=1):
+    """Drop-in for `HSIC` of the ablation script drl_classifier_ec_hsic.py:540-547 (HIP kernel, differentiable)."""
+    return _HSICFn.apply(x, y, float(s_x), float(s_y))
+
+
 class MMDStatistic:
     """Drop-in for the reference's `MMDStatistic` (:537-577); `__call__` runs the HIP RBF-MMD kernel."""
 

@@ -19,7 +19,7 @@ def _chk_cuda(*ts):
 
 
 def gemm(A, B, form, epi, M, N, K, *, splits=1, out_bf16=None, out2_bf16=None, out_f32=None, bias=None,
-         resid=None, aux=None, drop=(0, 0, 0, 0.0), lda=None, ldb=None, ldc=None):
+         resid=None, aux=None, drop=(0, 0, 0, 0.0), lda=None, ldb=None, ldc=None, colsum_part=None):
     a = L.GemmArgs()
     a.A, a.B = A.data_ptr(), B.data_ptr()
     a.lda = lda if lda is not None else A.stride(0)
@@ -34,6 +34,7 @@ def gemm(A, B, form, epi, M, N, K, *, splits=1, out_bf16=None, out2_bf16=None, o
     a.resid_f32 = None if resid is None else resid.data_ptr()
     a.aux_bf16 = None if aux is None else aux.data_ptr()
     a.drop_seed, a.drop_site, a.drop_idx_offset, a.drop_p = drop
+    a.colsum_part = None if colsum_part is None else colsum_part.data_ptr()
     L.check(L.load().carel_gemm_bf16(C.byref(a), L.current_stream()), "carel_gemm_bf16")
 
 
@@ -163,3 +164,29 @@ def pair_probs(lat, eps_e, eps_c, pair_w, pair_b, D):
     L.check(L.load().carel_pair_probs(lat.data_ptr(), eps_e.data_ptr(), eps_c.data_ptr(), pair_w.data_ptr(),
                                       pair_b.data_ptr(), B, D, prob.data_ptr(), L.current_stream()), "carel_pair_probs")
     return prob
+
+
+def _hsic_args(x, y, s_x, s_y):
+    _chk_cuda(x, y)
+    if x.shape != y.shape or x.dtype != torch.float32 or y.dtype != torch.float32 or x.stride(1) != 1 or y.stride(1) != 1:
+        raise L.CarelError("hsic: two float32 [m, d] samples of equal shape, contiguous rows")
+    a = L.HsicArgs()
+    a.x, a.y, a.ldx, a.ldy, a.m, a.d, a.s_x, a.s_y = x.data_ptr(), y.data_ptr(), x.stride(0), y.stride(0), x.shape[0], x.shape[1], s_x, s_y
+    return a
+
+
+def hsic(x, y, s_x=1.0, s_y=1.0):
+    a = _hsic_args(x, y, s_x, s_y)
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    a.hsic_out = out.data_ptr()
+    L.check(L.load().carel_hsic_fwd(C.byref(a), L.current_stream()), "carel_hsic_fwd")
+    return out
+
+
+def hsic_backward(x, y, grad, s_x=1.0, s_y=1.0):
+    a = _hsic_args(x, y, s_x, s_y)
+    gx, gy = torch.empty(x.shape, device=x.device, dtype=torch.float32), torch.empty(y.shape, device=x.device, dtype=torch.float32)
+    grad = grad.reshape(1).to(torch.float32).contiguous()
+    a.grad_hsic, a.gx, a.gy = grad.data_ptr(), gx.data_ptr(), gy.data_ptr()
+    L.check(L.load().carel_hsic_bwd(C.byref(a), L.current_stream()), "carel_hsic_bwd")
+    return gx, gy

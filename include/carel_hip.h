@@ -77,6 +77,8 @@ typedef struct carel_gemm_args {
   const void* aux_bf16;
   uint32_t drop_seed, drop_site, drop_idx_offset;
   float drop_p;
+  void* colsum_part;    /* optional, CAREL_EPI_DGELU_BF16 only: f32 [M/128][N] per-row-tile column sums of the output
+                           (pre-rounding); summing them over M/128 gives the FFN1 bias gradient */
 } carel_gemm_args;
 
 int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
@@ -135,6 +137,8 @@ int carel_layernorm_bwd_blocks(int64_t rows);
 int carel_layernorm_bwd(const void* dy_f32, const void* h_f32, const void* stats, const void* gamma, int64_t rows,
                         int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p,
                         void* dh_f32, void* dy_bf16, void* dgamma, void* dbeta, void* dbias, void* partials, void* stream);
+/* out[c] (+)= sum_p partials[p][c]  (c < n, p < nparts), fixed summation order */
+int carel_partial_reduce_f32(const void* partials, void* out, int32_t n, int32_t nparts, int32_t accumulate, void* stream);
 /* out[n] (+)= column sums of a bf16 matrix [rows, n] (bias gradients); partials: ceil(rows/256)*n floats */
 int carel_colsum_bf16(const void* x_bf16, int64_t ld, int64_t rows, int32_t n, void* out_f32, int32_t accumulate,
                       void* partials, void* stream);
@@ -315,6 +319,23 @@ typedef struct carel_mmd_args {
 
 int carel_rbf_mmd_fwd(const carel_mmd_args* args, void* stream);
 int carel_rbf_mmd_bwd(const carel_mmd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HSIC statistic (ablation head).  Replaces HSIC / GaussianKernelMatrix / pairwise_distances of
+ * drl_classifier_ec_hsic.py:529-547 and their backward: tr(L H K H)/(m-1)^2, K = exp(-D(x)/s_x),
+ * L = exp(-D(y)/s_y), D = squared Euclidean distances, H = I - 11^T/m.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_hsic_args {
+  const void* x; const void* y;     /* f32 [m, d], row strides ldx / ldy */
+  int64_t ldx, ldy;
+  int32_t m, d;                     /* d <= 64 */
+  float s_x, s_y;                   /* 1 in the reference */
+  void* hsic_out;                   /* f32 [1] */
+  const void* grad_hsic;            /* bwd: f32 [1] upstream gradient (NULL = 1) */
+  void* gx; void* gy;               /* bwd: f32 [m, d] contiguous */
+} carel_hsic_args;
+int carel_hsic_fwd(const carel_hsic_args* args, void* stream);
+int carel_hsic_bwd(const carel_hsic_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Hardware-layout self test (MFMA fragment maps, transposed LDS reads, LDS-DMA staging) used by

@@ -81,6 +81,15 @@ def test_dgrad_nn_forms():
     uu = u.double()
     gp = 0.5 * (1 + torch.erf(uu / math.sqrt(2))) + uu * torch.exp(-0.5 * uu * uu) / math.sqrt(2 * math.pi)
     assert rel_err(du, (dy2.double() @ W2.double()) * gp) < TOL_BF16
+    # fused bias-gradient partials: column sums of the (pre-rounding) output per 128-row tile
+    part = torch.empty((M // 128, 3072), device="cuda")
+    gemm(dy2, W2, L.GEMM_NN, L.EPI_DGELU_BF16, M, 3072, 768, out_bf16=du, aux=u, colsum_part=part)
+    ref_cs = ((dy2.double() @ W2.double()) * gp).sum(0)
+    assert rel_err(part.sum(0), ref_cs) < 1e-4
+    lib = L.load()
+    out = torch.empty(3072, device="cuda")
+    L.check(lib.carel_partial_reduce_f32(part.data_ptr(), out.data_ptr(), 3072, M // 128, 0, L.current_stream()))
+    assert rel_err(out, ref_cs) < 1e-4
 
 
 @pytest.mark.parametrize("T,Nout,Nin,splits", [(1024, 768, 768, 8), (2048, 2304, 768, 4), (512, 128, 3072, 1)])

@@ -66,3 +66,22 @@ def test_mmd_properties_and_errors():
     assert m1 == m2
     with pytest.raises(L.CarelError):
         run_mmd(x[:1], x[:1], [0.1])      # n = 1 divides by zero in the reference
+
+
+def test_hsic_golden_and_gradients(golden_dir):
+    """HSIC ablation head (drl_classifier_ec_hsic.py:529-547) vs the reference's values and the oracle's autograd."""
+    from carel_vae_amd import HSIC
+    z = np.load(os.path.join(golden_dir, "statistics.npz"), allow_pickle=False)
+    for tag in "ab":
+        x, y = torch.from_numpy(z[f"h{tag}_x"]), torch.from_numpy(z[f"h{tag}_y"])
+        xg, yg = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+        h = HSIC(xg, yg)
+        np.testing.assert_allclose(h.item(), float(z[f"h{tag}_hsic"]), rtol=2e-4, atol=1e-7)
+        (3.0 * h).backward()
+        xo, yo = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        (3.0 * O.hsic_statistic(xo, yo)).backward()
+        sc = float(xo.grad.abs().max())
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=2e-3, atol=2e-4 * sc)
+        np.testing.assert_allclose(yg.grad.cpu().numpy(), yo.grad.numpy(), rtol=2e-3, atol=2e-4 * sc)
+    with pytest.raises(L.CarelError):
+        HSIC(torch.zeros(1, 24, device="cuda"), torch.zeros(1, 24, device="cuda"))
