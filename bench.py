@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clause pairs per GPU")
     ap.add_argument("--shape", default="A", choices=["A", "B"], help="A dense (roofline headline), B ECPE-shaped lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-varlen", action="store_true", help="run padded positions through the encoder like the reference does")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
     return ap.parse_args()
 
@@ -117,15 +118,17 @@ def main():
     optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr)
 
     ocfg = O.EncoderConfig()
-    batches = []
+    batches, lengths = [], []
     for i in range(4):
         b = O.synthetic_batch(a.batch, 128, ocfg, opt.pair_bow_dim, seed=1 + 10 * rank + i, shape=a.shape)
+        lengths.append(b["attention_masks"].sum(1).tolist())     # known on the host before the H2D copy (as in a DataLoader)
         batches.append({k: v.to(dev) for k, v in b.items()})
+    model.varlen = not a.no_varlen
 
     def step(i):
         b = batches[i % len(batches)]
         loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"],
-                     b["bow_reps"], i % 41)
+                     b["bow_reps"], i % 41, seq_lengths=lengths[i % len(batches)])
         optim.zero_grad()
         loss.backward()
         optim.step()
@@ -180,6 +183,8 @@ def main():
            "config": {"workload": "zh ECPE training step (fwd+bwd+Adam), BERT-base vocab 21128, S=128 shape-%s, B=%d/GPU, "
                                   "bow V=23771, dropout on, random-init weights" % (a.shape, a.batch),
                       "global_batch": world * a.batch, "seq_len": 128, "parallelism": "dp%d" % world,
+                      "attended_tokens_per_pair": sum(sum(l) for l in lengths) / (len(lengths) * a.batch),
+                      "padding_skipped": bool(model.varlen and a.shape == "B"),
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam"},
            "roofline": roof, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("out_bf16", C.c_void_p), ("out2_bf16", C.c_void_p), ("out_f32", C.c_void_p),
                 ("bias", C.c_void_p), ("resid_f32", C.c_void_p), ("aux_bf16", C.c_void_p),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float), ("colsum_part", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_row_map", C.c_void_p), ("colsum_part", C.c_void_p)]
 
 
 class MmdArgs(C.Structure):
@@ -42,7 +42,8 @@ class EmbedArgs(C.Structure):
                 ("vocab_size", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
                 ("roberta", C.c_int32), ("pad_id", C.c_int32),
                 ("drop_seed", C.c_uint32), ("drop_idx_offset", C.c_uint32), ("drop_p", C.c_float),
-                ("x_f32", C.c_void_p), ("x_bf16", C.c_void_p), ("stats", C.c_void_p)]
+                ("x_f32", C.c_void_p), ("x_bf16", C.c_void_p), ("stats", C.c_void_p),
+                ("tok_row", C.c_void_p), ("n_rows", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -50,7 +51,7 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("batch", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float)]
+                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p)]
 
 
 class TailArgs(C.Structure):
@@ -73,7 +74,8 @@ class TailArgs(C.Structure):
                 ("d_emo_w", C.c_void_p), ("d_emo_b", C.c_void_p), ("d_cau_w", C.c_void_p), ("d_cau_b", C.c_void_p),
                 ("d_pair_w", C.c_void_p), ("d_pair_b", C.c_void_p), ("d_dec_w", C.c_void_p), ("d_dec_b", C.c_void_p),
                 ("d_head_w", C.c_void_p * 4), ("d_head_b", C.c_void_p * 4),
-                ("d_pooler_w", C.c_void_p), ("d_pooler_b", C.c_void_p), ("dx_last_f32", C.c_void_p)]
+                ("d_pooler_w", C.c_void_p), ("d_pooler_b", C.c_void_p), ("dx_last_f32", C.c_void_p),
+                ("cls_rows", C.c_void_p), ("n_rows", C.c_int32)]
 
 
 class AdamArgs(C.Structure):
@@ -103,6 +105,7 @@ class EncoderArgs(C.Structure):
                 ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p),
                 ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p),
                 ("layers", C.POINTER(LayerParams)), ("act", C.c_void_p), ("scratch", C.c_void_p),
+                ("n_tokens", C.c_int32), ("tok_row", C.c_void_p), ("cu_seqlens", C.c_void_p),
                 ("layer_grads", C.POINTER(LayerGrads)),
                 ("d_word_emb", C.c_void_p), ("d_pos_emb", C.c_void_p), ("d_type_emb", C.c_void_p),
                 ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p)]
@@ -141,6 +144,8 @@ SIGNATURES = {
     "carel_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_float] + [C.c_void_p] * 7),
     "carel_partial_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "carel_layernorm_bwd_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_float] + [C.c_void_p] * 8),
     "carel_colsum_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p]),
     "carel_tail_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -74,6 +74,7 @@ struct AttnParams {
   bf16_t* dqkv;             // bwd out  [B*S, 2304]
   int B, S;
   Dropout drop;             // element index ((b*NH + h)*S + q)*S + k
+  const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
 };
 
 constexpr float MASK_NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, as HF adds it
@@ -87,13 +88,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   float* maskadd = (float*)(smem + 32768);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
-  const int S = p.S, nkt = S >> 5;
-  const long row0 = (long)b * S;
+  const int S = p.S;
+  // packed: this sample's `len` tokens start at row cu[b]; tiles may run past them into rows of the next sample
+  // (finite data, masked as keys, never stored as queries)
+  const long row0 = p.cu ? (long)p.cu[b] : (long)b * S;
+  const int len = p.cu ? (p.cu[b + 1] - p.cu[b]) : S;
+  const int nkt = (len + 31) >> 5, rows = nkt << 5;
   const bf16_t* qbase = p.qkv + row0 * QKV_LD + h * HD;
-  stage_att(qbase + HID, QKV_LD, S, kimg);
-  stage_att(qbase + 2 * HID, QKV_LD, S, vimg);
-  for (int k = threadIdx.x; k < S; k += 256)
-    maskadd[k] = (p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f;
+  stage_att(qbase + HID, QKV_LD, rows, kimg);
+  stage_att(qbase + 2 * HID, QKV_LD, rows, vimg);
+  for (int k = threadIdx.x; k < rows; k += 256)
+    maskadd[k] = p.cu ? (k < len ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave >= nkt) return;                       // no barrier below this point
@@ -142,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
   }
   lsum += __shfl_xor(lsum, 32, 64);
-  if (hh == 0) p.lse[((long)b * NH + h) * S + q0 + (lane & 31)] = m + __logf(lsum);
+  const bool qlive = q0 + (lane & 31) < len;
+  if (hh == 0 && qlive) p.lse[((long)b * NH + h) * S + q0 + (lane & 31)] = m + __logf(lsum);
   const float inv = 1.0f / lsum;
   // O^T[d][q] = sum_k V^T[d][k] P^T[k][q]
   f32x16 o[2];
@@ -162,14 +168,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
   }
   bf16_t* crow = p.ctx + (row0 + q0 + (lane & 31)) * HID + h * HD;
+  if (qlive) {
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = dt * 32 + 8 * i + 4 * hh;
-      uint2 v = {pack2bf(o[dt][4 * i] * inv, o[dt][4 * i + 1] * inv), pack2bf(o[dt][4 * i + 2] * inv, o[dt][4 * i + 3] * inv)};
-      *(uint2*)(crow + d) = v;
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int d = dt * 32 + 8 * i + 4 * hh;
+        uint2 v = {pack2bf(o[dt][4 * i] * inv, o[dt][4 * i + 1] * inv), pack2bf(o[dt][4 * i + 2] * inv, o[dt][4 * i + 3] * inv)};
+        *(uint2*)(crow + d) = v;
+      }
+  }
 }
 
 // =========================================================================================== backward
@@ -185,18 +193,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   float* delta = lse + 128;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
-  const int S = p.S, nt = S >> 5;
-  const long row0 = (long)b * S;
+  const int S = p.S;
+  const long row0 = p.cu ? (long)p.cu[b] : (long)b * S;
+  const int len = p.cu ? (p.cu[b + 1] - p.cu[b]) : S;
+  const int nt = (len + 31) >> 5, rows = nt << 5;
   const bf16_t* qbase = p.qkv + row0 * QKV_LD + h * HD;
   const bf16_t* dobase = p.dctx + row0 * HID + h * HD;
   const bf16_t* obase = p.ctx + row0 * HID + h * HD;
-  stage_att(qbase, QKV_LD, S, qimg);
-  stage_att(dobase, HID, S, doimg);
-  for (int k = threadIdx.x; k < S; k += 256) lse[k] = p.lse[((long)b * NH + h) * S + k];
+  stage_att(qbase, QKV_LD, rows, qimg);
+  stage_att(dobase, HID, rows, doimg);
+  for (int k = threadIdx.x; k < rows; k += 256) lse[k] = k < len ? p.lse[((long)b * NH + h) * S + k] : 0.f;
   {  // delta[q] = sum_d dO[q][d] * O[q][d]; 2 threads per query, 32 d each
     const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
     float s = 0.f;
-    if (q < S) {
+    if (q < len) {
       const uint4* a = (const uint4*)(dobase + (long)q * HID + half * 32);
       const uint4* c = (const uint4*)(obase + (long)q * HID + half * 32);
 #pragma unroll
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       }
     }
     s += __shfl_xor(s, 1, 64);
-    if (q < S && half == 0) delta[q] = s;
+    if (q < rows && half == 0) delta[q] = s;      // 0 for q >= len
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -231,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       vf[s] = load_frag_global(qbase + 2 * HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
     }
     const int key = kw + (lane & 31);
-    const float madd = (p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f;
+    const bool klive = key < len;
+    const float madd = p.cu ? (klive ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f);
     for (int qt = 0; qt < nt; ++qt) {
       f32x16 sa, dp;
 #pragma unroll
@@ -245,10 +256,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + acc32_row(r, lane);
-        const float pr = __expf(sa[r] * 0.125f + madd - lse[q]);
+        const bool live = klive && q < len;      // rows / keys past the sample belong to its neighbours: contribute exact zeros
+        const float pr = live ? __expf(sa[r] * 0.125f + madd - lse[q]) : 0.f;
         const float dm = dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
-        pd[r] = pr * dm;
-        dsv[r] = pr * (dp[r] * dm - delta[q]) * 0.125f;            // includes the 1/sqrt(d) of the scores
+        pd[r] = live ? pr * dm : 0.f;
+        dsv[r] = live ? pr * (dp[r] * dm - delta[q]) * 0.125f : 0.f;    // includes the 1/sqrt(d) of the scores
       }
       // dS^T[k][q] -> LDS (4 consecutive q per register group)
 #pragma unroll
@@ -268,19 +280,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       }
     }
     bf16_t* out = p.dqkv + (row0 + key) * QKV_LD + h * HD;
+    if (klive) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d = dt * 32 + 8 * i + 4 * hh;
-        uint2 a = {pack2bf(dk[dt][4 * i], dk[dt][4 * i + 1]), pack2bf(dk[dt][4 * i + 2], dk[dt][4 * i + 3])};
-        uint2 c = {pack2bf(dv[dt][4 * i], dv[dt][4 * i + 1]), pack2bf(dv[dt][4 * i + 2], dv[dt][4 * i + 3])};
-        *(uint2*)(out + HID + d) = a;
-        *(uint2*)(out + 2 * HID + d) = c;
-      }
+        for (int i = 0; i < 4; ++i) {
+          const int d = dt * 32 + 8 * i + 4 * hh;
+          uint2 a = {pack2bf(dk[dt][4 * i], dk[dt][4 * i + 1]), pack2bf(dk[dt][4 * i + 2], dk[dt][4 * i + 3])};
+          uint2 c = {pack2bf(dv[dt][4 * i], dv[dt][4 * i + 1]), pack2bf(dv[dt][4 * i + 2], dv[dt][4 * i + 3])};
+          *(uint2*)(out + HID + d) = a;
+          *(uint2*)(out + 2 * HID + d) = c;
+        }
+    }
   }
   __syncthreads();                           // every wave: dO image dead, dS^T complete
-  stage_att(qbase + HID, QKV_LD, S, doimg);  // K image for the dQ phase
+  stage_att(qbase + HID, QKV_LD, rows, doimg);  // K image for the dQ phase
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!active) return;
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
   {
     const int g = lane >> 4, g1 = g & 1, h2 = g >> 1, qq = (lane & 15) >> 2, pp = lane & 3;
-    for (int ks = 0; ks < (S >> 4); ++ks) {
+    for (int ks = 0; ks < (rows >> 4); ++ks) {
       // B operand: dS^T[k = 16ks + 8*h2 + j][q = kw + (l&31)] via transposed reads of the dS^T image
       const int kr0 = 16 * ks + 8 * h2 + qq, kr1 = kr0 + 4;
       const int qcol = kw + 16 * g1 + 4 * pp;
@@ -305,14 +319,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     }
   }
   bf16_t* out = p.dqkv + (row0 + kw + (lane & 31)) * QKV_LD + h * HD;
+  if (kw + (lane & 31) < len) {
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = dt * 32 + 8 * i + 4 * hh;
-      uint2 a = {pack2bf(dq[dt][4 * i], dq[dt][4 * i + 1]), pack2bf(dq[dt][4 * i + 2], dq[dt][4 * i + 3])};
-      *(uint2*)(out + d) = a;
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int d = dt * 32 + 8 * i + 4 * hh;
+        uint2 a = {pack2bf(dq[dt][4 * i], dq[dt][4 * i + 1]), pack2bf(dq[dt][4 * i + 2], dq[dt][4 * i + 3])};
+        *(uint2*)(out + d) = a;
+      }
+  }
 }
 
 }  // namespace carel
@@ -328,7 +344,7 @@ static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who
   if (bwd && (!a->dctx || !a->dqkv)) return set_error(CAREL_ERR_ARG, "%s: null gradient tensor", who);
   p->qkv = (const bf16_t*)a->qkv; p->att_mask = (const long*)a->attention_mask; p->ctx = (bf16_t*)a->ctx;
   p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
-  p->B = a->batch; p->S = a->seq_len;
+  p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens;
   p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   return CAREL_OK;
 }

@@ -95,6 +95,10 @@ Scratch scratch_of(const ScratchLayout& l, char* b) {
   return s;
 }
 
+long n_rows_of(const carel_encoder_args* a) {
+  return (a->tok_row && a->n_tokens > 0) ? (long)a->n_tokens : (long)a->batch * a->seq_len;
+}
+
 int enc_check(const carel_encoder_args* a, const char* who) {
   if (!a) return set_error(CAREL_ERR_ARG, "%s: null args", who);
   if (a->hidden != EH || a->heads != ENH || a->intermediate != EI)
@@ -103,16 +107,20 @@ int enc_check(const carel_encoder_args* a, const char* who) {
   if (a->seq_len < 32 || a->seq_len > 128 || (a->seq_len & 31)) return set_error(CAREL_ERR_SHAPE, "%s: seq_len must be 32/64/96/128", who);
   if (((long)a->batch * a->seq_len) % 128) return set_error(CAREL_ERR_SHAPE, "%s: batch*seq_len must be a multiple of 128 (pad the batch)", who);
   if (!a->input_ids || !a->layers || !a->act) return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  if (a->tok_row || a->cu_seqlens || a->n_tokens) {
+    if (!a->tok_row || !a->cu_seqlens || a->n_tokens <= 0 || a->n_tokens % 128 || a->n_tokens > a->batch * a->seq_len)
+      return set_error(CAREL_ERR_ARG, "%s: packing needs tok_row, cu_seqlens and n_tokens (multiple of 128, <= batch*seq_len)", who);
+  }
   return CAREL_OK;
 }
 
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
-              uint32_t off, float p, void* stream, void* colsum_part = nullptr) {
+              uint32_t off, float p, void* stream, void* colsum_part = nullptr, const void* row_map = nullptr) {
   carel_gemm_args g;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
-  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part;
+  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map;
   return carel_gemm_bf16(&g, stream);
 }
 
@@ -147,6 +155,7 @@ static carel_embed_args embed_args_of(const carel_encoder_args* a, const ActLayo
   e.type_vocab = a->type_vocab; e.roberta = a->roberta; e.pad_id = a->pad_id;
   e.drop_seed = a->drop_seed; e.drop_idx_offset = a->drop_row_offset * (uint32_t)(a->seq_len * EH); e.drop_p = a->hidden_dropout;
   e.x_f32 = (char*)a->act + l.o_xa; e.x_bf16 = first.xin_bf16; e.stats = (char*)a->act + l.o_embst;
+  e.tok_row = a->tok_row; e.n_rows = a->tok_row ? a->n_tokens : 0;
   return e;
 }
 
@@ -154,7 +163,7 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   int rc = enc_check(a, "carel_encoder_forward");
   if (rc) return rc;
   if (!a->word_emb || !a->pos_emb || !a->type_emb || !a->emb_ln_g || !a->emb_ln_b) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: null embedding tensor");
-  const long B = a->batch, S = a->seq_len, T = B * S;
+  const long B = a->batch, S = a->seq_len, T = n_rows_of(a);     // T = rows actually processed (packed or dense)
   const ActLayout l = act_layout(B, S, a->n_layers, a->inference);
   char* base = (char*)a->act;
   char* xa = base + l.o_xa;
@@ -172,14 +181,15 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
     at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
     at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
+    at.cu_seqlens = a->cu_seqlens;
     if ((rc = carel_attention_fwd(&at, stream))) return rc;
     if ((rc = gemm_call(la.ctx, w.out_w, EH, EH, (int)T, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
-                        w.out_b, xa, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream))) return rc;
+                        w.out_b, xa, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, a->tok_row))) return rc;
     if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, T, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)T, EI, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_GELU, 1, la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)T, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream))) return rc;
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, a->tok_row))) return rc;
     void* next_bf16 = nullptr;
     if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16;
     if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, T, EH, xa, next_bf16, la.st2, stream))) return rc;
@@ -195,7 +205,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if (a->inference) return set_error(CAREL_ERR_ARG, "carel_encoder_backward_layer: forward ran in inference mode (no saved activations)");
   if (layer < 0 || layer >= a->n_layers || !a->layer_grads || !a->scratch || !a->dx)
     return set_error(CAREL_ERR_ARG, "carel_encoder_backward_layer: bad layer index or null buffer");
-  const long B = a->batch, S = a->seq_len, T = B * S;
+  const long B = a->batch, S = a->seq_len, T = n_rows_of(a);
   const ActLayout l = act_layout(B, S, a->n_layers, 0);
   const LayerAct la = layer_act(l, (char*)a->act, layer, 0);
   const Scratch s = scratch_of(scratch_layout(B, S), (char*)a->scratch);
@@ -203,8 +213,8 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const carel_layer_grads& g = a->layer_grads[layer];
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
-  if ((rc = carel_layernorm_bwd(a->dx, la.h2, la.st2, w.ln2_g, T, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, s.dy, s.dyb,
-                                g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
+  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h2, la.st2, w.ln2_g, T, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout,
+                                       a->tok_row, s.dy, s.dyb, g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)T, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
@@ -216,8 +226,8 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
                       nullptr, 0, 0, 0, 0.f, stream))) return rc;
   if ((rc = wgrad_call(s.du, la.x1_bf16, T, EI, EH, s.slabs, g.ffn1_w, stream))) return rc;
   // LN1 backward
-  if ((rc = carel_layernorm_bwd(a->dx, la.h1, la.st1, w.ln1_g, T, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, s.dy, s.dyb,
-                                g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
+  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h1, la.st1, w.ln1_g, T, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout,
+                                       a->tok_row, s.dy, s.dyb, g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
   if ((rc = gemm_call(s.dyb, w.out_w, EH, EH, (int)T, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, s.dctx, nullptr, nullptr, nullptr,
                       nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
@@ -227,6 +237,13 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = s.dctx; at.dqkv = s.dqkv;
   at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
   at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * layer; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
+  at.cu_seqlens = a->cu_seqlens;
+  if (a->tok_row) {
+    // packed: the attention backward writes only rows that belong to a sample; the filler rows up to the next multiple
+    // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows
+    hipError_t he = hipMemsetAsync(s.dqkv + (size_t)(T - 128) * 3 * EH * 2, 0, (size_t)128 * 3 * EH * 2, (hipStream_t)stream);
+    if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
+  }
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
   if ((rc = carel_colsum_bf16(s.dqkv, 3 * EH, T, 3 * EH, g.qkv_b, 0, s.part, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in

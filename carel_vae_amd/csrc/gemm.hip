@@ -37,6 +37,7 @@ struct GemmParams {
   const bf16_t* aux;        // [M,ldc] bf16 (pre-GELU) for EPI_DGELU
   Dropout drop;
   int tiles_m, tiles_n;
+  const int* drop_row_map;  // optional [M]: original row of each packed row (dropout element index)
   float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
 };
@@ -65,7 +66,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     *(uint2*)(p.out1 + off) = g;
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r = *(const float4*)(p.resid + off);
-    const uint32_t e = (uint32_t)off;
+    const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o;
     o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
     o.y = v[1] * dropout_mult(p.drop, e + 1) + r.y;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     *(uint4*)(p.out1 + off) = pack8(u);
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
-    const uint32_t e = (uint32_t)off;
+    const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o0, o1;
     o0.x = v[0] * dropout_mult(p.drop, e + 0) + r0.x; o0.y = v[1] * dropout_mult(p.drop, e + 1) + r0.y;
     o0.z = v[2] * dropout_mult(p.drop, e + 2) + r0.z; o0.w = v[3] * dropout_mult(p.drop, e + 3) + r0.w;
@@ -530,7 +531,7 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
   p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n == 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
-  p.colsum_part = (float*)a->colsum_part;
+  p.colsum_part = (float*)a->colsum_part; p.drop_row_map = (const int*)a->drop_row_map;
   const int form = a->form, epi = a->epilogue;
   if (splits != 1 && epi != EPI_SLAB_F32) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: split-K only with the slab epilogue");
 #define NEED(ptr, what) if (!(ptr)) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: epilogue needs " what)

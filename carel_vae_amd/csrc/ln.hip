@@ -87,6 +87,7 @@ struct EmbedArgs {
   const float* gamma; const float* beta;
   float eps; int S; long rows; int roberta; int pad_id; int vocab, max_pos, type_vocab;
   Dropout drop;
+  const int* tok_row;     // packed: original row of output row t (-1 = filler); null = identity
 };
 
 __device__ __forceinline__ int position_id(const EmbedArgs& a, long row, int lane) {
@@ -119,8 +120,18 @@ __device__ __forceinline__ Row embed_gather(const EmbedArgs& a, long row, int la
 __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a, float* __restrict__ x_f32, bf16_t* __restrict__ x_bf16,
                                                         float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
+  const long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // output row
+  if (orow >= a.rows) return;
+  const long row = a.tok_row ? (long)a.tok_row[orow] : orow;        // original row b*S + s
+  if (row < 0) {                                                    // filler row of a packed batch
+    Row Z;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) Z.v[i] = float4{0.f, 0.f, 0.f, 0.f};
+    store_row(x_f32 + orow * H, lane, Z);
+    store_row_bf16(x_bf16 + orow * H, lane, Z);
+    if (lane == 0) { stats[orow * 2] = 0.f; stats[orow * 2 + 1] = 0.f; }
+    return;
+  }
   int pid, tid_;
   Row X = embed_gather(a, row, lane, pid, tid_);
   const Row G = load_row(a.gamma, lane), Bt = load_row(a.beta, lane);
@@ -134,9 +145,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a, float* __re
       X.v[i].z *= dropout_mult(a.drop, e0 + 2); X.v[i].w *= dropout_mult(a.drop, e0 + 3);
     }
   }
-  store_row(x_f32 + row * H, lane, X);
-  store_row_bf16(x_bf16 + row * H, lane, X);
-  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  store_row(x_f32 + orow * H, lane, X);
+  store_row_bf16(x_bf16 + orow * H, lane, X);
+  if (lane == 0) { stats[orow * 2] = mean; stats[orow * 2 + 1] = rstd; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -186,8 +197,9 @@ __device__ __forceinline__ void write_partials(float* lds /*[4][H]*/, const Row&
 // partials[blk][3][H] = {dgamma, dbeta, dbias}.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy_out, const float* __restrict__ h,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     long rows, Dropout drop, float* __restrict__ dh,
-                                                     bf16_t* __restrict__ dyb, float* __restrict__ partials) {
+                                                     long rows, Dropout drop, const int* __restrict__ row_map,
+                                                     float* __restrict__ dh, bf16_t* __restrict__ dyb,
+                                                     float* __restrict__ partials) {
   __shared__ float lds[4 * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const Row G = load_row(gamma, lane);
@@ -207,9 +219,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < NV; ++i) { accG.v[i].x += XH.v[i].x; accG.v[i].y += XH.v[i].y; accG.v[i].z += XH.v[i].z; accG.v[i].w += XH.v[i].w; }
     if (dh) store_row(dh + row * H, lane, DY);
     if (drop.thresh) {
+      const long drow = row_map ? (long)row_map[row] : row;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const uint32_t e0 = (uint32_t)(row * H + (i * 64 + lane) * 4);
+        const uint32_t e0 = (uint32_t)(drow * H + (i * 64 + lane) * 4);
         DY.v[i].x *= dropout_mult(drop, e0); DY.v[i].y *= dropout_mult(drop, e0 + 1);
         DY.v[i].z *= dropout_mult(drop, e0 + 2); DY.v[i].w *= dropout_mult(drop, e0 + 3);
       }
@@ -237,11 +250,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
 #pragma unroll
   for (int i = 0; i < NV; ++i) accG.v[i] = accB.v[i] = accT0.v[i] = accT1.v[i] = float4{0.f, 0.f, 0.f, 0.f};
   for (int r = wave; r < LNB_ROWS; r += 4) {
-    const long row = (long)blockIdx.x * LNB_ROWS + r;
-    if (row >= a.rows) break;
+    const long orow = (long)blockIdx.x * LNB_ROWS + r;
+    if (orow >= a.rows) break;
+    const long row = a.tok_row ? (long)a.tok_row[orow] : orow;
+    if (row < 0) continue;                                  // filler row: no gradient
     int pid, tid_;
     Row XH = embed_gather(a, row, lane, pid, tid_);
-    Row DY = load_row(dx0 + row * H, lane);
+    Row DY = load_row(dx0 + orow * H, lane);
     if (a.drop.thresh) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) { accB.v[i].x += DY.v[i].x; accB.v[i].y += DY.v[i].y; accB.v[i].z += DY.v[i].z; accB.v[i].w += DY.v[i].w; }
-    ln_bwd_row(DY, XH, G, stats[row * 2], stats[row * 2 + 1]);
+    ln_bwd_row(DY, XH, G, stats[orow * 2], stats[orow * 2 + 1]);
 #pragma unroll
     for (int i = 0; i < NV; ++i) { accG.v[i].x += XH.v[i].x; accG.v[i].y += XH.v[i].y; accG.v[i].z += XH.v[i].z; accG.v[i].w += XH.v[i].w; }
     long id = a.ids[row];
@@ -354,7 +369,9 @@ static EmbedArgs make_embed(const carel_embed_args* a) {
   e.ids = (const long*)a->input_ids; e.tt = (const long*)a->token_type_ids;
   e.word = (const float*)a->word_emb; e.pos = (const float*)a->pos_emb; e.type = (const float*)a->type_emb;
   e.gamma = (const float*)a->ln_gamma; e.beta = (const float*)a->ln_beta;
-  e.eps = a->ln_eps; e.S = a->seq_len; e.rows = (long)a->batch * a->seq_len; e.roberta = a->roberta; e.pad_id = a->pad_id;
+  e.eps = a->ln_eps; e.S = a->seq_len; e.roberta = a->roberta; e.pad_id = a->pad_id;
+  e.tok_row = (const int*)a->tok_row;
+  e.rows = (a->tok_row && a->n_rows > 0) ? (long)a->n_rows : (long)a->batch * a->seq_len;
   e.vocab = a->vocab_size; e.max_pos = a->max_pos; e.type_vocab = a->type_vocab;
   e.drop = make_dropout(a->drop_seed, 0u, a->drop_p, a->drop_idx_offset);
   return e;
@@ -421,13 +438,21 @@ extern "C" int carel_layernorm_bwd(const void* dy, const void* h, const void* st
                                    int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset,
                                    float drop_p, void* dh_f32, void* dy_bf16, void* dgamma, void* dbeta, void* dbias,
                                    void* partials, void* stream_) {
+  return carel_layernorm_bwd_packed(dy, h, stats, gamma, rows, hidden, drop_seed, drop_site, drop_idx_offset, drop_p, nullptr, dh_f32,
+                                    dy_bf16, dgamma, dbeta, dbias, partials, stream_);
+}
+
+extern "C" int carel_layernorm_bwd_packed(const void* dy, const void* h, const void* stats, const void* gamma, int64_t rows,
+                                          int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset,
+                                          float drop_p, const void* drop_row_map, void* dh_f32, void* dy_bf16, void* dgamma,
+                                          void* dbeta, void* dbias, void* partials, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (hidden != H) return set_error(CAREL_ERR_SHAPE, "carel_layernorm_bwd: hidden must be %d", H);
   if (!dy || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_bwd: bad arguments");
   const int nblk = carel_layernorm_bwd_blocks(rows);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
                      (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
-                     (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials);
+                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials);
   int rc = check_launch("ln_bwd_kernel");
   if (rc) return rc;
   SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dbias; so.p[3] = nullptr;

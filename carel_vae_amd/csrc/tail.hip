@@ -21,8 +21,8 @@ constexpr int TNV = TH / 256;
 struct PtrSet4 { const float* w[4]; const float* b[4]; };
 
 template <int ACT>   // 0 none, 1 tanh
-__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ in, long in_stride, int B, int N,
-                                                            int seg, PtrSet4 ps, float* __restrict__ out, long out_stride) {
+__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ in, long in_stride, const int* __restrict__ row_idx,
+                                                            int B, int N, int seg, PtrSet4 ps, float* __restrict__ out, long out_stride) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < TNV; ++i) wv[i] = *(const float4*)(w + (i * 64 + lane) * 4);
   for (int b = 0; b < B; ++b) {
-    const float* x = in + (long)b * in_stride;
+    const float* x = row_idx ? in + (long)row_idx[b] * TH : in + (long)b * in_stride;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < TNV; ++i) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
 // dW_n[k] = sum_b dY[b][n] * X[b*x_stride + k] ; db_n = sum_b dY[b][n]   (one wave per n)
 struct OutSet4 { float* w[4]; float* b[4]; };
 __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* __restrict__ dY, long dy_stride, const float* __restrict__ X,
-                                                           long x_stride, int B, int N, int seg, OutSet4 os) {
+                                                           long x_stride, const int* __restrict__ row_idx, int B, int N, int seg, OutSet4 os) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* __restri
   for (int b = 0; b < B; ++b) {
     const float g = dY[(long)b * dy_stride + n];
     sb += g;
-    const float* x = X + (long)b * x_stride;
+    const float* x = row_idx ? X + (long)row_idx[b] * TH : X + (long)b * x_stride;
 #pragma unroll
     for (int i = 0; i < TNV; ++i) {
       const float4 xv = *(const float4*)(x + (i * 64 + lane) * 4);
@@ -484,9 +484,11 @@ __global__ void scale_inplace_kernel(float* __restrict__ x, long n, const float*
   for (; i < n; i += stride) x[i] *= s;
 }
 // scatter the CLS-row gradients into the [T, 768] gradient of the last encoder output (zeroed first)
-__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ dcls, int B, int S, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restrict__ dcls, int B, int S, const int* __restrict__ row_idx,
+                                                          float* __restrict__ dx) {
   const int b = blockIdx.x;
-  for (int k = threadIdx.x; k < TH; k += 256) dx[(long)b * S * TH + k] = dcls[(long)b * TH + k];
+  const long row = row_idx ? (long)row_idx[b] : (long)b * S;
+  for (int k = threadIdx.x; k < TH; k += 256) dx[row * TH + k] = dcls[(long)b * TH + k];
 }
 
 }  // namespace carel
@@ -537,11 +539,11 @@ extern "C" int carel_tail_latents(const carel_tail_args* a, void* stream_) {
   PtrSet4 pp; for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; }
   pp.w[0] = (const float*)a->pooler_w; pp.b[0] = (const float*)a->pooler_b;
   hipLaunchKernelGGL(rowvec_linear_kernel<1>, dim3(TH / 4), dim3(256), 0, stream, (const float*)a->x_last_f32,
-                     (long)a->seq_len * TH, a->batch, TH, TH, pp, (float*)a->pooled, (long)TH);
+                     (long)a->seq_len * TH, (const int*)a->cls_rows, a->batch, TH, TH, pp, (float*)a->pooled, (long)TH);
   PtrSet4 hp; for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = (const float*)a->head_b[i]; }
   const int N = 4 * a->ec_dim;
   hipLaunchKernelGGL(rowvec_linear_kernel<0>, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)a->pooled, (long)TH,
-                     a->batch, N, a->ec_dim, hp, (float*)a->lat, (long)N);
+                     (const int*)nullptr, a->batch, N, a->ec_dim, hp, (float*)a->lat, (long)N);
   return check_launch("tail latents");
 }
 
@@ -661,7 +663,7 @@ extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_ou
   for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = nullptr; ho.w[i] = (float*)a->d_head_w[i]; ho.b[i] = (float*)a->d_head_b[i]; }
   if (ho.w[0] && ho.w[1] && ho.w[2] && ho.w[3])
     hipLaunchKernelGGL(rowvec_wgrad_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)w.dlat, (long)N, (const float*)a->pooled,
-                       (long)TH, B, N, D, ho);
+                       (long)TH, (const int*)nullptr, B, N, D, ho);
   const int hc = (N + DG_CHUNK - 1) / DG_CHUNK, pc = (TH + DG_CHUNK - 1) / DG_CHUNK;
   const long bt = (long)B * TH;
   hipLaunchKernelGGL(rowvec_dgrad_kernel<0>, dim3((B + 3) / 4, hc), dim3(256), 0, stream, (const float*)w.dlat, (long)N, B, N, D, hp,
@@ -674,8 +676,10 @@ extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_ou
                      (const float*)a->pooled, w.dpre, w.dgpart);
   hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((bt / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)w.dgpart, w.dcls, bt, pc);
   hipLaunchKernelGGL(rowvec_wgrad_kernel, dim3(TH / 4), dim3(256), 0, stream, (const float*)w.dpre, (long)TH, (const float*)a->x_last_f32,
-                     (long)a->seq_len * TH, B, TH, TH, po);
-  (void)hipMemsetAsync(a->dx_last_f32, 0, (size_t)B * a->seq_len * TH * sizeof(float), stream);
-  hipLaunchKernelGGL(scatter_cls_kernel, dim3(B), dim3(256), 0, stream, (const float*)w.dcls, B, a->seq_len, (float*)a->dx_last_f32);
+                     (long)a->seq_len * TH, (const int*)a->cls_rows, B, TH, TH, po);
+  const size_t dx_rows = a->n_rows > 0 ? (size_t)a->n_rows : (size_t)B * a->seq_len;
+  (void)hipMemsetAsync(a->dx_last_f32, 0, dx_rows * TH * sizeof(float), stream);
+  hipLaunchKernelGGL(scatter_cls_kernel, dim3(B), dim3(256), 0, stream, (const float*)w.dcls, B, a->seq_len, (const int*)a->cls_rows,
+                     (float*)a->dx_last_f32);
   return check_launch("tail backward");
 }

@@ -10,6 +10,7 @@ import ctypes as C
 import math
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -270,6 +271,7 @@ class DrlClassifier(nn.Module):
             gen = torch.Generator().manual_seed(seed)
         _init_like_reference(self, gen)
         self.dropout_base_seed = 0x5EED
+        self.varlen = True                   # skip padded positions (results identical; see _pack_info)
         self._fwd_count = 0
         self._noise = None
         self._ws = {}
@@ -405,13 +407,17 @@ class DrlClassifier(nn.Module):
             lib = L.load()
             dev = self._flat.device
             ws = SimpleNamespace()
-            ws.act = torch.empty(lib.carel_encoder_act_bytes(B, S, self.cfg.layers, int(inference)), device=dev, dtype=torch.uint8)
-            ws.scratch = None if inference else torch.empty(lib.carel_encoder_scratch_bytes(B, S), device=dev, dtype=torch.uint8)
+            # zero-filled once: with token packing, attention tiles read (masked) rows past a sample's last token, and
+            # 0 * NaN from never-written memory would poison the MFMA sums; everything written later is finite
+            ws.act = torch.zeros(lib.carel_encoder_act_bytes(B, S, self.cfg.layers, int(inference)), device=dev, dtype=torch.uint8)
+            ws.scratch = None if inference else torch.zeros(lib.carel_encoder_scratch_bytes(B, S), device=dev, dtype=torch.uint8)
             self._ws[key] = ws
         return ws
 
-    def _encoder_args(self, ids, att, tt, ws, B, S, inference, train, seed, row_offset):
+    def _encoder_args(self, ids, att, tt, ws, B, S, inference, train, seed, row_offset, pack=None):
         a = L.EncoderArgs()
+        if pack is not None:
+            a.n_tokens, a.tok_row, a.cu_seqlens = pack.n_tokens, pack.tok_row.data_ptr(), pack.cu.data_ptr()
         c = self.cfg
         a.batch, a.seq_len, a.n_layers, a.hidden, a.heads, a.intermediate = B, S, c.layers, H, NH, I_FF
         a.vocab_size, a.max_pos, a.type_vocab, a.roberta, a.pad_id, a.inference = (c.vocab_size, c.max_pos, c.type_vocab,
@@ -451,6 +457,39 @@ class DrlClassifier(nn.Module):
             Bp += 1
         return Bp
 
+    def _pack_info(self, att, B, Bp, S, seq_lengths=None):
+        """Token packing for padded batches: only attended positions go through the encoder (the reference pads every
+        pair to max_len and ~77 % of ECPE tokens are padding).  Exact for prefix-form masks (HF right padding): padded
+        positions are never attended to and nothing but [CLS] is read from the last layer, so every output and
+        gradient is unchanged; dropout masks and position ids keep using the ORIGINAL (sample, position) index.
+        Returns None to run dense (no padding in the batch, non-prefix mask, or varlen disabled)."""
+        if not self.varlen or att is None:
+            return None
+        if seq_lengths is None:
+            m = att[:B].to(torch.int32)
+            lens = m.sum(1)
+            prefix = ((torch.arange(S, device=m.device)[None, :] < lens[:, None]).to(torch.int32) == m).all()
+            info = torch.cat((lens, prefix.to(torch.int32).reshape(1))).cpu()        # the one host sync of the packed path
+            lens_l, ok = info[:-1].tolist(), bool(info[-1])
+        else:
+            lens_l, ok = [int(v) for v in seq_lengths], True
+        if not ok or min(lens_l) < 1:
+            return None
+        t_eff = sum(lens_l)
+        if t_eff == B * S:
+            return None
+        t_pad = (t_eff + 127) // 128 * 128
+        lens_a = np.asarray(lens_l, dtype=np.int64)
+        cu = np.zeros(Bp + 1, dtype=np.int32)
+        cu[1:B + 1] = np.cumsum(lens_a)
+        cu[B + 1:] = t_eff
+        tok = np.full(t_pad, -1, dtype=np.int32)
+        starts = np.repeat(np.arange(B, dtype=np.int64) * S - cu[:B], lens_a)
+        tok[:t_eff] = (np.arange(t_eff, dtype=np.int64) + starts).astype(np.int32)
+        dev = att.device
+        return SimpleNamespace(n_tokens=t_pad, t_eff=t_eff, cu=torch.from_numpy(cu).to(dev, non_blocking=True),
+                               tok_row=torch.from_numpy(tok).to(dev, non_blocking=True))
+
     def set_noise(self, eps_e, eps_c):
         """Test hook: use these two [ec_dim] vectors as the next call's reparameterisation noise (ref :350)."""
         self._noise = None if eps_e is None else (eps_e, eps_c)
@@ -468,7 +507,8 @@ class DrlClassifier(nn.Module):
         return eps_e, eps_c
 
     # ------------------------------------------------------------------ forward / backward bodies
-    def _make_call(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration, training):
+    def _make_call(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration, training,
+                   seq_lengths=None):
         self._require_cuda()
         ops._chk_cuda(input_ids, att_masks, token_type_ids, content_bow)
         B, S = input_ids.shape
@@ -489,10 +529,11 @@ class DrlClassifier(nn.Module):
         self._fwd_count += 1
         c.seed = (self.dropout_base_seed * 1000003 + self._fwd_count) & 0xFFFFFFFF
         c.row_offset = 0 if self._dp is None else self._dp.row_offset(B)
+        c.pack = self._pack_info(c.att, B, Bp, S, seq_lengths)
         key = ("tail", B, S)
         buf = self._ws.get(key)
         if buf is None:
-            buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev)
+            buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev, rows=Bp * S)
             self._ws[key] = buf
         c.buf = buf
         return c
@@ -512,7 +553,7 @@ class DrlClassifier(nn.Module):
         self._refresh_shadow()
         train_drop = self.training          # dropout follows module mode (model.train() / .eval()), like nn.Dropout
         ws = self._workspace(c.Bp, c.S, inference=not training)
-        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset)
+        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset, c.pack)
         lib = L.load()
         st = L.current_stream()
         L.check(lib.carel_encoder_forward(C.byref(ea), st), "carel_encoder_forward")
@@ -521,7 +562,9 @@ class DrlClassifier(nn.Module):
         xl = SimpleNamespace(data_ptr=lambda: x_last_ptr)
         klw = ops.kl_anneal_weight(c.iteration, self.opt)
         drop = (self.opt.dropout if train_drop else 0.0, c.seed, c.row_offset)
-        ta = ops.tail_args(c.buf, xl, W, c.labels, c.eps_e, c.eps_c, self.opt, klw, grads=G, drop=drop)
+        ta = ops.tail_args(c.buf, xl, W, c.labels, c.eps_e, c.eps_c, self.opt, klw, grads=G, drop=drop,
+                           cls_rows=None if c.pack is None else c.pack.cu,
+                           n_rows=c.Bp * c.S if c.pack is None else c.pack.n_tokens)
         ops.tail_latents(ta)
         if self._dp is not None:
             self._dp.fill_global(ta, c)                  # all-gather z, all-reduce label sum
@@ -537,17 +580,9 @@ class DrlClassifier(nn.Module):
         accumulate = first.grad is not None
         prev = self._flat_grad.clone() if accumulate else None
         go = grad_out.to(torch.float32).reshape(1).contiguous()      # device scalar, never read on the host
-        c.ta.dx_last_f32 = c.buf.dx_last.data_ptr()
         ea = c.ea
-        if c.Bp == c.B:
-            ea.dx = c.buf.dx_last.data_ptr()
-            dxbuf = None
-        else:
-            dxbuf = torch.zeros((c.Bp * c.S, H), device=self._flat.device, dtype=torch.float32)
-            ea.dx = dxbuf.data_ptr()
+        ea.dx = c.buf.dx_last.data_ptr()          # [Bp*S (or packed n_tokens), 768]; cleared + CLS rows written by the tail backward
         ops.tail_backward(c.ta, go)
-        if dxbuf is not None:
-            dxbuf[:c.B * c.S].copy_(c.buf.dx_last)
         # classifier / decoder gradients were produced for grad_output = 1: one contiguous range of the flat buffer
         lo = self._offs["decoder.weight"]
         ops.scale_(self._flat_grad[lo:self._pair_hi], go)
@@ -571,10 +606,13 @@ class DrlClassifier(nn.Module):
             p.grad = self._grad_views[k]
 
     # ------------------------------------------------------------------ public API (reference surface)
-    def forward(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration):
-        """Reference `forward` (:184-263): returns the scalar `vae_and_classifier_loss`."""
+    def forward(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration,
+                seq_lengths=None):
+        """Reference `forward` (:184-263): returns the scalar `vae_and_classifier_loss`.
+        seq_lengths (optional extension): host list of attended lengths per pair; saves the device->host read that the
+        padding-skipping path otherwise needs to learn them from `att_masks`."""
         c = self._make_call(input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration,
-                            training=torch.is_grad_enabled())
+                            training=torch.is_grad_enabled(), seq_lengths=seq_lengths)
         self._last_call = c
         if torch.is_grad_enabled():
             anchor = self._flat.new_zeros((), requires_grad=True)
@@ -617,16 +655,19 @@ class DrlClassifier(nn.Module):
             att = self._prep_ids(att_masks[s:s + chunk], Bp)
             tt = None if token_type_ids is None else self._prep_ids(token_type_ids[s:s + chunk], Bp)
             ws = self._workspace(Bp, S, inference=True)
-            ea = self._encoder_args(ids, att, tt, ws, Bp, S, True, False, 0, 0)
+            pack = self._pack_info(att, B, Bp, S)
+            ea = self._encoder_args(ids, att, tt, ws, Bp, S, True, False, 0, 0, pack)
             L.check(lib.carel_encoder_forward(C.byref(ea), L.current_stream()), "carel_encoder_forward")
             x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
             key = ("tail", B, S)
             buf = self._ws.get(key)
             if buf is None:
-                buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev)
+                buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev, rows=Bp * S)
                 self._ws[key] = buf
             W, _ = self._tail_weights()
-            ta = ops.tail_args(buf, SimpleNamespace(data_ptr=lambda: x_last_ptr), W, None, None, None, self.opt, 1.0)
+            ta = ops.tail_args(buf, SimpleNamespace(data_ptr=lambda: x_last_ptr), W, None, None, None, self.opt, 1.0,
+                               cls_rows=None if pack is None else pack.cu)
+            ta._keep = pack
             ops.tail_latents(ta)
             out[s:s + B] = ops.pair_probs(buf.lat, eps_e, eps_c, W["pair_classifier.weight"], W["pair_classifier.bias"], self.opt.ec_dim)
         return out

@@ -84,19 +84,21 @@ def kl_anneal_weight(iteration, opt):
 class TailBuffers:
     """Outputs + workspace of the tail calls for one (batch, ec_dim, bow_dim) shape."""
 
-    def __init__(self, B, S, D, EC, V, device):
+    def __init__(self, B, S, D, EC, V, device, rows=None):
         f = dict(device=device, dtype=torch.float32)
         self.B, self.S, self.D, self.EC, self.V = B, S, D, EC, V
+        self.rows = rows if rows is not None else B * S        # rows of the encoder's last hidden state / its gradient
         self.pooled = torch.empty((B, H), **f)
         self.lat = torch.empty((B, 4 * D), **f)
         self.z = torch.empty((B, 2 * D), **f)
         self.terms = torch.zeros(16, **f)
         self.work = torch.empty(L.load().carel_tail_workspace_floats(B, D, V), **f)
-        self.dx_last = torch.empty((B * S, H), **f)
+        self.dx_last = torch.empty((self.rows, H), **f)
 
 
 def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight, *, grads=None, drop=(0.0, 0, 0),
-              global_label_sum=None, global_n=0, global_row_offset=0, z_global=None, mmd_grad_scale=1.0):
+              global_label_sum=None, global_n=0, global_row_offset=0, z_global=None, mmd_grad_scale=1.0, cls_rows=None,
+              n_rows=0):
     """W / grads: dicts keyed by the reference's state_dict names (tail part)."""
     a = L.TailArgs()
     a.batch, a.seq_len, a.hidden, a.ec_dim, a.e_classes, a.bow_dim = buf.B, buf.S, H, buf.D, buf.EC, buf.V
@@ -127,6 +129,8 @@ def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight,
     a.pooled, a.lat, a.z, a.terms, a.work = (buf.pooled.data_ptr(), buf.lat.data_ptr(), buf.z.data_ptr(),
                                              buf.terms.data_ptr(), buf.work.data_ptr())
     a.dx_last_f32 = buf.dx_last.data_ptr()
+    a.cls_rows = None if cls_rows is None else cls_rows.data_ptr()
+    a.n_rows = n_rows if n_rows else buf.rows
     if grads is not None:
         a.d_emo_w, a.d_emo_b = grads["emotion_classifier.weight"].data_ptr(), grads["emotion_classifier.bias"].data_ptr()
         a.d_cau_w, a.d_cau_b = grads["cause_classifier.weight"].data_ptr(), grads["cause_classifier.bias"].data_ptr()

@@ -77,6 +77,8 @@ typedef struct carel_gemm_args {
   const void* aux_bf16;
   uint32_t drop_seed, drop_site, drop_idx_offset;
   float drop_p;
+  const void* drop_row_map; /* optional int32 [M]: original row of each (packed) row for the dropout element index
+                               (= row_map[row] * ldc + col); NULL = identity */
   void* colsum_part;    /* optional, CAREL_EPI_DGELU_BF16 only: f32 [M/128][N] per-row-tile column sums of the output
                            (pre-rounding); summing them over M/128 gives the FFN1 bias gradient */
 } carel_gemm_args;
@@ -114,6 +116,10 @@ typedef struct carel_embed_args {
   void* x_f32;                 /* out f32  [B*S, 768] */
   void* x_bf16;                /* out bf16 [B*S, 768] */
   void* stats;                 /* out f32  [B*S, 2] (mean, rstd); input of the backward */
+  /* token packing (padding skipped): row t of the outputs is original row tok_row[t] (= b*S + s), -1 = filler
+   * row (written as zeros); n_rows rows are produced.  NULL / 0 = dense (row t = original row t, B*S rows). */
+  const void* tok_row;         /* int32 [n_rows] or NULL */
+  int32_t n_rows;
 } carel_embed_args;
 
 int carel_embed_ln_fwd(const carel_embed_args* args, void* stream);
@@ -137,6 +143,11 @@ int carel_layernorm_bwd_blocks(int64_t rows);
 int carel_layernorm_bwd(const void* dy_f32, const void* h_f32, const void* stats, const void* gamma, int64_t rows,
                         int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p,
                         void* dh_f32, void* dy_bf16, void* dgamma, void* dbeta, void* dbias, void* partials, void* stream);
+/* same with packed rows: drop_row_map int32 [rows] gives each row's original row for the dropout index */
+int carel_layernorm_bwd_packed(const void* dy_f32, const void* h_f32, const void* stats, const void* gamma, int64_t rows,
+                               int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p,
+                               const void* drop_row_map, void* dh_f32, void* dy_bf16, void* dgamma, void* dbeta, void* dbias,
+                               void* partials, void* stream);
 /* out[c] (+)= sum_p partials[p][c]  (c < n, p < nparts), fixed summation order */
 int carel_partial_reduce_f32(const void* partials, void* out, int32_t n, int32_t nparts, int32_t accumulate, void* stream);
 /* out[n] (+)= column sums of a bf16 matrix [rows, n] (bias gradients); partials: ceil(rows/256)*n floats */
@@ -160,6 +171,9 @@ typedef struct carel_attn_args {
   int32_t batch, seq_len, heads, head_dim;
   uint32_t drop_seed, drop_site, drop_idx_offset;
   float drop_p;
+  /* token packing: sample b owns rows [cu_seqlens[b], cu_seqlens[b+1]) of qkv/ctx/dctx/dqkv and attends to exactly
+   * those (attention_mask is ignored); seq_len stays the ORIGINAL padded length (dropout index, lse stride). */
+  const void* cu_seqlens;      /* int32 [B+1] or NULL */
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);
@@ -200,6 +214,10 @@ typedef struct carel_encoder_args {
   const void* word_emb; const void* pos_emb; const void* type_emb; const void* emb_ln_g; const void* emb_ln_b; /* f32 */
   const carel_layer_params* layers;         /* HOST array [n_layers] of device pointers */
   void* act; void* scratch;
+  /* token packing (skip padded positions; results identical for prefix-form attention masks):
+   * n_tokens = packed row count rounded up to 128, tok_row int32 [n_tokens] (original row or -1),
+   * cu_seqlens int32 [B+1].  n_tokens = 0 / NULL pointers = dense. */
+  int32_t n_tokens; const void* tok_row; const void* cu_seqlens;
   const carel_layer_grads* layer_grads;     /* HOST array [n_layers] */
   void* d_word_emb; void* d_pos_emb; void* d_type_emb; void* d_emb_ln_g; void* d_emb_ln_b;
   void* dx;
@@ -263,7 +281,9 @@ typedef struct carel_tail_args {
   void* d_dec_w; void* d_dec_b;
   void* d_head_w[4]; void* d_head_b[4];   /* may be NULL (heads are not optimised, ref :292-295) */
   void* d_pooler_w; void* d_pooler_b;
-  void* dx_last_f32;                 /* f32 [B*S, 768] */
+  void* dx_last_f32;                 /* f32 [B*S, 768] (packed: [n_rows, 768]) */
+  const void* cls_rows;              /* int32 [B]: row of each sample's [CLS] token in x_last / dx_last; NULL = b*seq_len */
+  int32_t n_rows;                    /* rows of dx_last to clear (0 = B*seq_len) */
 } carel_tail_args;
 
 int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim);

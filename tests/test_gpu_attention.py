@@ -87,3 +87,47 @@ def test_attention_rejects_bad_shapes():
     qkv = torch.zeros((100, 3 * H), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(L.CarelError):
         run_attn(qkv, None, 1, 100)
+
+
+def test_packed_attention_matches_per_sample_reference():
+    """cu_seqlens mode: samples of different lengths stored back to back; tiles that run past a sample must not leak."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    S = 128
+    lens = [37, 128, 5, 64, 33, 1, 96]
+    B = len(lens)
+    T = sum(lens)
+    Tp = (T + 127) // 128 * 128
+    qkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device="cuda")          # buffer is B*S rows like the encoder's
+    qkv[:Tp] = (torch.randn((Tp, 3 * H), generator=g) * 1.5).cuda().bfloat16()
+    dctx = torch.zeros((B * S, H), dtype=torch.bfloat16, device="cuda")
+    dctx[:Tp] = torch.randn((Tp, H), generator=g).cuda().bfloat16()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    a = L.AttnArgs()
+    ctx = torch.full((B * S, H), 7.0, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros((B, NH, S), device="cuda")
+    dqkv = torch.full((B * S, 3 * H), 7.0, device="cuda", dtype=torch.bfloat16)
+    a.qkv, a.attention_mask, a.ctx, a.lse, a.dctx, a.dqkv = qkv.data_ptr(), None, ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dqkv.data_ptr()
+    a.batch, a.seq_len, a.heads, a.head_dim = B, S, NH, HD
+    p, seed, site, off = 0.1, 5, O.site_attn_probs(2), 0
+    a.drop_seed, a.drop_site, a.drop_idx_offset, a.drop_p = seed, site, off, p
+    a.cu_seqlens = cu.data_ptr()
+    L.check(lib.carel_attention_fwd(C.byref(a), L.current_stream()), "attn fwd packed")
+    L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd packed")
+    torch.cuda.synchronize()
+    idx_all = np.arange(B * NH * S * S, dtype=np.uint64).astype(np.uint32)
+    keep_all = torch.from_numpy(O.dropout_keep(seed, site, idx_all, p).astype(np.float64) / (1 - p)).view(B, NH, S, S).cuda()
+    start = 0
+    for b, n in enumerate(lens):
+        x = qkv[start:start + n].double().view(n, 3, NH, HD).requires_grad_(True)
+        q, k, v = (x[:, i].transpose(0, 1) for i in range(3))            # [NH, n, HD]
+        s = q @ k.transpose(-1, -2) / math.sqrt(HD)
+        pr = torch.softmax(s, dim=-1) * keep_all[b, :, :n, :n]
+        out = (pr @ v).transpose(0, 1).reshape(n, H)
+        assert rel_err(ctx[start:start + n], out.detach()) < 8e-3, b
+        out.backward(dctx[start:start + n].double())
+        e = rel_err(dqkv[start:start + n], x.grad.reshape(n, 3 * H))
+        assert e < 2e-2, (b, n, e)
+        start += n
+    # rows that belong to no sample were not touched
+    assert float((ctx[T:] - 7.0).abs().max()) == 0.0 and float((dqkv[T:] - 7.0).abs().max()) == 0.0

@@ -215,3 +215,56 @@ def test_get_pair_preds_and_cpu_refusal(golden_dir):
     assert torch.equal(torch.tensor(preds).squeeze(1)[far], prob.round()[far])
     with pytest.raises(M.L.CarelError):
         model.get_pair_preds(batch["input_ids"], batch["attention_masks"], batch["token_type_ids"])   # CPU tensors
+
+
+@pytest.mark.parametrize("name,dropout", [("zh_ragged", False), ("zh_ragged", True), ("en_small", True)])
+def test_token_packing_equals_padded_computation(golden_dir, name, dropout):
+    """Skipping the padded positions (varlen packing) must not change anything: same loss terms, latents and
+    gradients as the padded computation, with dropout masks ON (they hash the original (sample, position) index)."""
+    cfg, opt = CASES[name]
+    if dropout:
+        opt = O.Opt(**{**vars(opt), "dropout": 0.5})
+    z, batch = load(golden_dir, name)
+    B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
+    eps_e, eps_c = torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"])
+    res = {}
+    for varlen in (False, True):
+        model, P = build(cfg, opt, wseed, train_dropout=dropout)
+        model.train()
+        model.varlen = varlen
+        model.set_noise(eps_e, eps_c)
+        loss = model(*call(model, batch, it0))
+        packed = model._last_call.pack is not None
+        assert packed == varlen
+        loss.backward()
+        torch.cuda.synchronize()
+        res[varlen] = (float(loss), {k: float(v) for k, v in model.last_terms().items()}, model._last_call.buf.lat.clone(),
+                       {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    (l0, t0, lat0, g0), (l1, t1, lat1, g1) = res[False], res[True]
+    for k in t0:
+        assert abs(t0[k] - t1[k]) <= 2e-5 * max(abs(t0[k]), 1e-3), (k, t0[k], t1[k])
+    assert relnorm(lat1, lat0) < 1e-5
+    worst = max(relnorm(g1[k], g0[k]) for k in g0 if float(g0[k].norm()) > 1e-6)
+    assert worst < 2e-3, worst          # only the summation order over tokens differs (split-K / atomics)
+    # a host-provided length list gives the same packing without the device->host read
+    lens = batch["attention_masks"].sum(1).tolist()
+    model.set_noise(eps_e, eps_c)
+    model._fwd_count -= 1               # same dropout seed as the previous call
+    args = call(model, batch, it0)
+    with torch.no_grad():
+        l2 = model(*args, seq_lengths=lens)
+    assert abs(float(l2) - l1) <= 2e-5 * max(abs(l1), 1e-3)
+
+
+def test_packing_falls_back_to_dense_for_non_prefix_masks(golden_dir):
+    cfg, opt = CASES["zh_small"]
+    z, batch = load(golden_dir, "zh_small")
+    model, P = build(cfg, opt, int(z["meta"][5]))
+    model.eval()
+    b = {k: v.clone() for k, v in batch.items()}
+    b["attention_masks"][:, 5] = 0           # a hole in the middle: not right-padding
+    model.set_noise(torch.zeros(24), torch.zeros(24))
+    out = model.forward_terms(*call(model, b, 0))
+    assert model._last_call.pack is None
+    ref = O.forward_terms(P, b, 0, cfg, opt, torch.zeros(24), torch.zeros(24), quant=O.bf16_round)
+    assert abs(float(out["emo"]) - float(ref["emo"])) < 5e-3 * abs(float(ref["emo"]))
