@@ -158,6 +158,35 @@ def main():
     log("timed region done: %.3f ms/step; roofline leg" % (1e3 * dt / a.steps))
     pairs_per_s = world * a.batch * a.steps / dt
 
+    # ---- secondary line: the same step on ECPE-shaped batches (SURVEY 8(d) shape-B: ~77 % padding), padding skipped ----
+    ecpe = None
+    if a.shape == "A" and not a.no_varlen:
+        bb, ll = [], []
+        for i in range(4):
+            b = O.synthetic_batch(a.batch, 128, ocfg, opt.pair_bow_dim, seed=101 + 10 * rank + i, shape="B")
+            ll.append(b["attention_masks"].sum(1).tolist())
+            bb.append({k: v.to(dev) for k, v in b.items()})
+        keep = (batches, lengths)
+        batches, lengths = bb, ll
+        for i in range(3):
+            step(i)
+        sync()
+        t1 = time.perf_counter()
+        nb = max(5, a.steps // 2)
+        for i in range(nb):
+            step(i)
+        sync()
+        dtb = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtb], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtb = float(t.item())
+        ecpe = {"value": world * a.batch * nb / dtb, "unit": "clause-pairs/s", "ms_per_step": 1e3 * dtb / nb, "steps": nb,
+                "attended_tokens_per_pair": sum(sum(l) for l in ll) / (len(ll) * a.batch),
+                "note": "same step, ECPE-shaped lengths; padded positions are not run through the encoder (results identical)"}
+        batches, lengths = keep
+        log("ECPE-shaped leg: %.3f ms/step" % (1e3 * dtb / nb))
+
     # ---- roofline leg: HIP events around every GEMM launch of a few more steps (same stream) ----
     roof = None
     L.check(lib.carel_profile_gemm(1, 4096))
@@ -186,7 +215,7 @@ def main():
                       "attended_tokens_per_pair": sum(sum(l) for l in lengths) / (len(lengths) * a.batch),
                       "padding_skipped": bool(model.varlen and a.shape == "B"),
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam"},
-           "roofline": roof, "final_loss": final_loss}
+           "roofline": roof, "ecpe_shaped": ecpe, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):
             m2 = M.DrlClassifier(M.make_opt(**vars(oopt)), M.encoder_config("zh", hidden_dropout=0.0, attn_dropout=0.0), seed=0)

@@ -179,6 +179,7 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
                         w.qkv_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     carel_attn_args at;
     at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
+    at.dqkv_colsum_part = nullptr;
     at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
     at.cu_seqlens = a->cu_seqlens;
@@ -244,8 +245,9 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
     hipError_t he = hipMemsetAsync(s.dqkv + (size_t)(T - 128) * 3 * EH * 2, 0, (size_t)128 * 3 * EH * 2, (hipStream_t)stream);
     if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
   }
+  at.dqkv_colsum_part = s.part;                    // [B][2304] per-sample column sums -> QKV bias gradient
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
-  if ((rc = carel_colsum_bf16(s.dqkv, 3 * EH, T, 3 * EH, g.qkv_b, 0, s.part, stream))) return rc;
+  if ((rc = carel_partial_reduce_f32(s.part, g.qkv_b, 3 * EH, (int)B, 0, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
                       s.dy, nullptr, 0, 0, 0, 0.f, stream))) return rc;

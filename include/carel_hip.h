@@ -174,6 +174,8 @@ typedef struct carel_attn_args {
   /* token packing: sample b owns rows [cu_seqlens[b], cu_seqlens[b+1]) of qkv/ctx/dctx/dqkv and attends to exactly
    * those (attention_mask is ignored); seq_len stays the ORIGINAL padded length (dropout index, lse stride). */
   const void* cu_seqlens;      /* int32 [B+1] or NULL */
+  void* dqkv_colsum_part;      /* bwd, optional: f32 [B, 2304] per-sample column sums of dqkv; summing over B gives the
+                                  q/k/v bias gradient */
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);
