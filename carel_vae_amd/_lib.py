@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("out_bf16", C.c_void_p), ("out2_bf16", C.c_void_p), ("out_f32", C.c_void_p),
                 ("bias", C.c_void_p), ("resid_f32", C.c_void_p), ("aux_bf16", C.c_void_p),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float), ("drop_row_map", C.c_void_p), ("colsum_part", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_row_map", C.c_void_p), ("colsum_a", C.c_void_p), ("colsum_part", C.c_void_p)]
 
 
 class MmdArgs(C.Structure):
@@ -51,7 +51,7 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("batch", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p), ("dqkv_colsum_part", C.c_void_p)]
+                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p)]
 
 
 class TailArgs(C.Structure):

@@ -75,11 +75,10 @@ struct AttnParams {
   int B, S;
   Dropout drop;             // element index ((b*NH + h)*S + q)*S + k
   const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
-  float* colsum_part;       // bwd, optional: [B][2304] per-sample column sums of dqkv (QKV bias gradient partials)
 };
 
 constexpr float MASK_NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, as HF adds it
-constexpr int ATTN_BWD_LDS = 16384 + 16384 + 32768 + 1024 + 3072;   // images + lse/delta + per-wave column sums
+constexpr int ATTN_BWD_LDS = 16384 + 16384 + 32768 + 1024;
 
 // =========================================================================================== forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
@@ -192,8 +191,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   char* dsimg = smem + 32768;        // dS^T [k][q] bf16, 256-B rows
   float* lse = (float*)(smem + 65536);
   float* delta = lse + 128;
-  float* csum = delta + 128;         // [4 waves][3 (q,k,v)][64 d] column sums of this block's dqkv rows
-  for (int i = threadIdx.x; i < 768; i += 256) csum[i] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
   const int S = p.S;
@@ -282,21 +279,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         }
       }
     }
-    if (p.colsum_part) {            // block-uniform: bias-gradient partials, summed over this wave's 32 keys
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float a = dk[dt][r], c = dv[dt][r];     // exact zeros for keys past the sample
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
-          if ((lane & 31) == 0) {
-            const int d = dt * 32 + acc32_row(r, lane);
-            csum[(wave * 3 + 1) * 64 + d] = a;
-            csum[(wave * 3 + 2) * 64 + d] = c;
-          }
-        }
-    }
     bf16_t* out = p.dqkv + (row0 + key) * QKV_LD + h * HD;
     if (klive) {
 #pragma unroll
@@ -315,58 +297,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   stage_att(qbase + HID, QKV_LD, rows, doimg);  // K image for the dQ phase
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (active) {
-    // dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]   for this wave's 32 queries q = kw + ..
-    f32x16 dq[2];
+  if (!active) return;
+  // dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]   for this wave's 32 queries q = kw + ..
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  {
+    const int g = lane >> 4, g1 = g & 1, h2 = g >> 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    for (int ks = 0; ks < (rows >> 4); ++ks) {
+      // B operand: dS^T[k = 16ks + 8*h2 + j][q = kw + (l&31)] via transposed reads of the dS^T image
+      const int kr0 = 16 * ks + 8 * h2 + qq, kr1 = kr0 + 4;
+      const int qcol = kw + 16 * g1 + 4 * pp;
+      s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(dsimg + ds_off(kr0, qcol)));
+      s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(dsimg + ds_off(kr1, qcol)));
+      s16x8 bb = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, bb);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(frag32_tr<false>(doimg, dt * 32, 16 * ks), bf, dq[dt]);
+    }
+  }
+  bf16_t* out = p.dqkv + (row0 + kw + (lane & 31)) * QKV_LD + h * HD;
+  if (kw + (lane & 31) < len) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    {
-      const int g = lane >> 4, g1 = g & 1, h2 = g >> 1, qq = (lane & 15) >> 2, pp = lane & 3;
-      for (int ks = 0; ks < (rows >> 4); ++ks) {
-        // B operand: dS^T[k = 16ks + 8*h2 + j][q = kw + (l&31)] via transposed reads of the dS^T image
-        const int kr0 = 16 * ks + 8 * h2 + qq, kr1 = kr0 + 4;
-        const int qcol = kw + 16 * g1 + 4 * pp;
-        s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(dsimg + ds_off(kr0, qcol)));
-        s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CAREL_LDS s16x4*)(dsimg + ds_off(kr1, qcol)));
-        s16x8 bb = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-        const bf16x8 bf = __builtin_bit_cast(bf16x8, bb);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(frag32_tr<false>(doimg, dt * 32, 16 * ks), bf, dq[dt]);
+      for (int i = 0; i < 4; ++i) {
+        const int d = dt * 32 + 8 * i + 4 * hh;
+        uint2 a = {pack2bf(dq[dt][4 * i], dq[dt][4 * i + 1]), pack2bf(dq[dt][4 * i + 2], dq[dt][4 * i + 3])};
+        *(uint2*)(out + d) = a;
       }
-    }
-    if (p.colsum_part) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float a = dq[dt][r];                    // exact zeros for queries past the sample
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o, 64);
-          if ((lane & 31) == 0) csum[(wave * 3 + 0) * 64 + dt * 32 + acc32_row(r, lane)] = a;
-        }
-    }
-    bf16_t* out = p.dqkv + (row0 + kw + (lane & 31)) * QKV_LD + h * HD;
-    if (kw + (lane & 31) < len) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int d = dt * 32 + 8 * i + 4 * hh;
-          uint2 a = {pack2bf(dq[dt][4 * i], dq[dt][4 * i + 1]), pack2bf(dq[dt][4 * i + 2], dq[dt][4 * i + 3])};
-          *(uint2*)(out + d) = a;
-        }
-    }
-  }
-  if (p.colsum_part) {                            // block-uniform
-    __syncthreads();
-    if (threadIdx.x < 192) {
-      const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
-      const float t = (csum[(0 * 3 + which) * 64 + d] + csum[(1 * 3 + which) * 64 + d]) +
-                      (csum[(2 * 3 + which) * 64 + d] + csum[(3 * 3 + which) * 64 + d]);
-      p.colsum_part[(long)b * QKV_LD + which * HID + h * HD + d] = t;
-    }
   }
 }
 
@@ -383,7 +344,7 @@ static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who
   if (bwd && (!a->dctx || !a->dqkv)) return set_error(CAREL_ERR_ARG, "%s: null gradient tensor", who);
   p->qkv = (const bf16_t*)a->qkv; p->att_mask = (const long*)a->attention_mask; p->ctx = (bf16_t*)a->ctx;
   p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
-  p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens; p->colsum_part = (float*)a->dqkv_colsum_part;
+  p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens;
   p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   return CAREL_OK;
 }

@@ -79,7 +79,7 @@ ScratchLayout scratch_layout(long B, long S) {
   s.o_dqkv = o; o += al(T * 3 * EH * 2);
   size_t slab = 0;
   const int shapes[4][2] = {{EH, EI}, {EI, EH}, {EH, EH}, {3 * EH, EH}};
-  for (auto& sh : shapes) { size_t n = (size_t)wgrad_splits((long)T, sh[0], sh[1]) * sh[0] * sh[1] * 4; slab = n > slab ? n : slab; }
+  for (auto& sh : shapes) { size_t n = (size_t)wgrad_splits((long)T, sh[0], sh[1]) * ((size_t)sh[0] * sh[1] + sh[0]) * 4; slab = n > slab ? n : slab; }
   s.o_slabs = o; o += al(slab);
   size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;
   const size_t cs = ((T + 255) / 256) * EI * 4;
@@ -120,17 +120,25 @@ int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, in
   carel_gemm_args g;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
-  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map;
+  g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map; g.colsum_a = nullptr;
   return carel_gemm_bf16(&g, stream);
 }
 
-// dW[M,N] = A^T[M x T] * B[T x N]  (A = dY [T,M], B = X [T,N])  via split-K slabs
-int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs, void* dW, void* stream) {
+// dW[M,N] = A^T[M x T] * B[T x N]  (A = dY [T,M], B = X [T,N])  via split-K slabs.  With db != null the bias gradient
+// db[M] = column sums of dY comes out of the same GEMM (ones-vector MFMA) as [splits][M] partials behind the slabs.
+int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs, void* dW, void* stream, void* db = nullptr) {
   const int splits = wgrad_splits(T, M, N);
-  int rc = gemm_call(dY, X, M, N, M, N, (int)T, CAREL_GEMM_TN, CAREL_EPI_SLAB_F32, splits, nullptr, nullptr, slabs, nullptr, nullptr,
-                     nullptr, 0, 0, 0, 0.f, stream);
+  carel_gemm_args g;
+  g.A = dY; g.B = X; g.lda = M; g.ldb = N; g.ldc = N; g.M = M; g.N = N; g.K = (int)T; g.form = CAREL_GEMM_TN; g.epilogue = CAREL_EPI_SLAB_F32;
+  g.splits = splits; g.out_bf16 = nullptr; g.out2_bf16 = nullptr; g.out_f32 = slabs; g.bias = nullptr; g.resid_f32 = nullptr; g.aux_bf16 = nullptr;
+  g.drop_seed = 0; g.drop_site = 0; g.drop_idx_offset = 0; g.drop_p = 0.f; g.drop_row_map = nullptr; g.colsum_part = nullptr;
+  float* cs = db ? (float*)slabs + (size_t)splits * M * N : nullptr;
+  g.colsum_a = cs;
+  int rc = carel_gemm_bf16(&g, stream);
   if (rc) return rc;
-  return carel_slab_reduce_f32(slabs, dW, (int64_t)M * N, splits, 0, stream);
+  if ((rc = carel_slab_reduce_f32(slabs, dW, (int64_t)M * N, splits, 0, stream))) return rc;
+  if (db) rc = carel_slab_reduce_f32(cs, db, M, splits, 0, stream);
+  return rc;
 }
 
 }  // namespace
@@ -179,7 +187,6 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
                         w.qkv_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     carel_attn_args at;
     at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
-    at.dqkv_colsum_part = nullptr;
     at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
     at.cu_seqlens = a->cu_seqlens;
@@ -245,13 +252,11 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
     hipError_t he = hipMemsetAsync(s.dqkv + (size_t)(T - 128) * 3 * EH * 2, 0, (size_t)128 * 3 * EH * 2, (hipStream_t)stream);
     if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
   }
-  at.dqkv_colsum_part = s.part;                    // [B][2304] per-sample column sums -> QKV bias gradient
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
-  if ((rc = carel_partial_reduce_f32(s.part, g.qkv_b, 3 * EH, (int)B, 0, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
                       s.dy, nullptr, 0, 0, 0, 0.f, stream))) return rc;
-  return wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, stream);
+  return wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, stream, g.qkv_b);
 }
 
 // Backward of the embedding block: a->dx = d(loss)/d(embedding output).  d_word_emb / d_pos_emb are

@@ -38,6 +38,7 @@ struct GemmParams {
   Dropout drop;
   int tiles_m, tiles_n;
   const int* drop_row_map;  // optional [M]: original row of each packed row (dropout element index)
+  float* colsum_a;          // optional, TN form: [splits][M] sums of A over this K-slice (bias gradient)
   float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
 };
@@ -189,6 +190,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // TN form, first tile column only: also accumulate sum_k A[k][m] (ones-vector B operand) -> bias gradient
+  const bool do_cs = AT && p.colsum_a != nullptr && tn == 0;
+  f32x4 acc1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
+
   auto stage = [&](int kt, int buf) {
     char* ta = smem + buf * 32768;
     char* tb = ta + 16384;
@@ -220,6 +229,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           if (DBG == 3) { asm volatile("" :: "v"(fb[j]), "v"(fa[i])); }
           else acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
         }
+      if (AT && do_cs && wc == 0) {                           // block-uniform x wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc1[i] = mfma16(ones, fa[i], acc1[i]);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -232,6 +245,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     return;
   }
 
+  if (AT && do_cs && wc == 0 && lane < 16) {                 // D[n][m]: every row n holds the same sum; lane = m
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p.colsum_a[(long)blockIdx.z * p.M + m0 + wr * 64 + i * 16 + lane] = acc1[i][0];
+  }
   // ------------------------------------------------------------------ epilogue
   // The accumulators go through LDS (the staging buffers are free now) so that global memory sees whole
   // 128/256-byte row segments: two halves of 64 columns; lane -> fragment rows on the way in,
@@ -410,7 +427,7 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
   // encoder shape (the second resident workgroup hides the other's prologue/epilogue; K is only 12-48 steps), so
   // the 256x96 three-stage kernel is used only when asked for or when the shape does not fit 128x128.
   if (v2_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && !v1_ok))) {
-    if (p.colsum_part) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: colsum_part needs the 128x128 tile (M, N multiples of 128)");
+    if (p.colsum_part || p.colsum_a) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: colsum outputs need the 128x128 tile (M, N multiples of 128)");
     return launch_v2<AT, BT, EPI>(p, splits, s);
   }
   if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
@@ -531,7 +548,8 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
   p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n == 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
-  p.colsum_part = (float*)a->colsum_part; p.drop_row_map = (const int*)a->drop_row_map;
+  p.colsum_part = (float*)a->colsum_part; p.drop_row_map = (const int*)a->drop_row_map; p.colsum_a = (float*)a->colsum_a;
+  if (p.colsum_a && a->form != CAREL_GEMM_TN) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: colsum_a is a TN-form (wgrad) option");
   const int form = a->form, epi = a->epilogue;
   if (splits != 1 && epi != EPI_SLAB_F32) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: split-K only with the slab epilogue");
 #define NEED(ptr, what) if (!(ptr)) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: epilogue needs " what)

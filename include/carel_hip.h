@@ -79,6 +79,9 @@ typedef struct carel_gemm_args {
   float drop_p;
   const void* drop_row_map; /* optional int32 [M]: original row of each (packed) row for the dropout element index
                                (= row_map[row] * ldc + col); NULL = identity */
+  void* colsum_a;       /* optional, CAREL_GEMM_TN only: f32 [splits][M] = sum over the K (token) dimension of A[k][m] per
+                           K-slice, i.e. the bias gradient that goes with the weight gradient; computed with one extra
+                           ones-vector MFMA per step in the first tile column */
   void* colsum_part;    /* optional, CAREL_EPI_DGELU_BF16 only: f32 [M/128][N] per-row-tile column sums of the output
                            (pre-rounding); summing them over M/128 gives the FFN1 bias gradient */
 } carel_gemm_args;
@@ -174,8 +177,6 @@ typedef struct carel_attn_args {
   /* token packing: sample b owns rows [cu_seqlens[b], cu_seqlens[b+1]) of qkv/ctx/dctx/dqkv and attends to exactly
    * those (attention_mask is ignored); seq_len stays the ORIGINAL padded length (dropout index, lse stride). */
   const void* cu_seqlens;      /* int32 [B+1] or NULL */
-  void* dqkv_colsum_part;      /* bwd, optional: f32 [B, 2304] per-sample column sums of dqkv; summing over B gives the
-                                  q/k/v bias gradient */
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);

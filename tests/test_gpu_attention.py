@@ -27,13 +27,8 @@ def run_attn(qkv, mask, B, S, drop=(0, 0, 0, 0.0), dctx=None):
     dqkv = None
     if dctx is not None:
         dqkv = torch.empty((B * S, 3 * H), device="cuda", dtype=torch.bfloat16)
-        part = torch.full((B, 3 * H), float("nan"), device="cuda")
-        a.dctx, a.dqkv, a.dqkv_colsum_part = dctx.data_ptr(), dqkv.data_ptr(), part.data_ptr()
+        a.dctx, a.dqkv = dctx.data_ptr(), dqkv.data_ptr()
         L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd")
-        torch.cuda.synchronize()
-        # fused bias-gradient partials == column sums of each sample's dqkv rows (before bf16 rounding)
-        ref = dqkv.double().view(B, S, 3 * H).sum(1)
-        assert rel_err(part, ref) < 5e-3
     torch.cuda.synchronize()
     return ctx, lse, dqkv
 

@@ -104,6 +104,11 @@ def test_wgrad_tn_split_k(T, Nout, Nin, splits):
     assert rel_err(dW, ref) < TOL
     L.check(lib.carel_slab_reduce_f32(slabs.data_ptr(), dW.data_ptr(), Nout * Nin, splits, 1, L.current_stream()))
     assert rel_err(dW, 2 * ref) < TOL
+    # bias gradient from the same GEMM: column sums of dY per K-slice (ones-vector MFMA in the first tile column)
+    cs = torch.full((splits, Nout), float("nan"), device="cuda")
+    gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, Nout, Nin, T, splits=splits, out_f32=slabs, colsum_a=cs)
+    assert rel_err(cs.sum(0), dY.double().sum(0)) < TOL
+    assert rel_err(slabs.sum(0), ref) < TOL
 
 
 def test_bad_shapes_are_refused():
