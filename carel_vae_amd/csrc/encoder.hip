@@ -116,11 +116,13 @@ int enc_check(const carel_encoder_args* a, const char* who) {
 
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
-              uint32_t off, float p, void* stream, void* colsum_part = nullptr, const void* row_map = nullptr) {
+              uint32_t off, float p, void* stream, void* colsum_part = nullptr, const void* row_map = nullptr, void* ws = nullptr,
+              size_t ws_bytes = 0) {
   carel_gemm_args g;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
   g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map; g.colsum_a = nullptr;
+  g.splitk_ws = ws; g.splitk_ws_bytes = (int64_t)ws_bytes;
   return carel_gemm_bf16(&g, stream);
 }
 
@@ -132,6 +134,7 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
   g.A = dY; g.B = X; g.lda = M; g.ldb = N; g.ldc = N; g.M = M; g.N = N; g.K = (int)T; g.form = CAREL_GEMM_TN; g.epilogue = CAREL_EPI_SLAB_F32;
   g.splits = splits; g.out_bf16 = nullptr; g.out2_bf16 = nullptr; g.out_f32 = slabs; g.bias = nullptr; g.resid_f32 = nullptr; g.aux_bf16 = nullptr;
   g.drop_seed = 0; g.drop_site = 0; g.drop_idx_offset = 0; g.drop_p = 0.f; g.drop_row_map = nullptr; g.colsum_part = nullptr;
+  g.splitk_ws = nullptr; g.splitk_ws_bytes = 0;
   float* cs = db ? (float*)slabs + (size_t)splits * M * N : nullptr;
   g.colsum_a = cs;
   int rc = carel_gemm_bf16(&g, stream);
@@ -177,6 +180,9 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   char* xa = base + l.o_xa;
   char* xb = base + l.o_xb;
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
+  const ScratchLayout sl = scratch_layout(B, S);
+  char* ws = a->scratch ? (char*)a->scratch + sl.o_slabs : nullptr;       // split-K workspace for small (packed) batches
+  const size_t ws_bytes = a->scratch ? sl.o_part - sl.o_slabs : 0;
   LayerAct la = layer_act(l, base, 0, a->inference);
   carel_embed_args e = embed_args_of(a, l, la);
   if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
@@ -197,7 +203,7 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)T, EI, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_GELU, 1, la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)T, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, a->tok_row))) return rc;
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, a->tok_row, ws, ws_bytes))) return rc;
     void* next_bf16 = nullptr;
     if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16;
     if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, T, EH, xa, next_bf16, la.st2, stream))) return rc;
@@ -220,6 +226,8 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const carel_layer_params& w = a->layers[layer];
   const carel_layer_grads& g = a->layer_grads[layer];
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
+  const ScratchLayout sl = scratch_layout(B, S);
+  const size_t ws_bytes = sl.o_part - sl.o_slabs;
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
   if ((rc = carel_layernorm_bwd_packed(a->dx, la.h2, la.st2, w.ln2_g, T, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout,
                                        a->tok_row, s.dy, s.dyb, g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
@@ -231,7 +239,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = wgrad_call(s.dyb, la.g, T, EH, EI, s.slabs, g.ffn2_w, stream))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)T, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
-                      nullptr, 0, 0, 0, 0.f, stream))) return rc;
+                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
   if ((rc = wgrad_call(s.du, la.x1_bf16, T, EI, EH, s.slabs, g.ffn1_w, stream))) return rc;
   // LN1 backward
   if ((rc = carel_layernorm_bwd_packed(a->dx, la.h1, la.st1, w.ln1_g, T, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout,
@@ -255,7 +263,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
-                      s.dy, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+                      s.dy, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
   return wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, stream, g.qkv_b);
 }
 

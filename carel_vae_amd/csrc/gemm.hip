@@ -38,6 +38,7 @@ struct GemmParams {
   Dropout drop;
   int tiles_m, tiles_n;
   const int* drop_row_map;  // optional [M]: original row of each packed row (dropout element index)
+  float* splitk_ws; size_t splitk_ws_bytes;   // optional workspace enabling the internal split-K path
   float* colsum_a;          // optional, TN form: [splits][M] sums of A over this K-slice (bias gradient)
   float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
@@ -151,6 +152,26 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     float* o = p.outf + (long)blockIdx.z * p.M * p.ldc + off;
     *(float4*)o = float4{v[0], v[1], v[2], v[3]}; *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
   }
+}
+
+// Epilogue of an internally split-K GEMM: v = sum_z slabs[z][row][col..col+7], then the normal fused epilogue.
+template <int EPI>
+__global__ __launch_bounds__(256) void slab_epilogue_kernel(GemmParams p, const float* __restrict__ slabs, int splits) {
+  const long chunk = (long)blockIdx.x * 256 + threadIdx.x;           // one thread per 8 consecutive columns
+  const int cpr = p.N >> 3;
+  if (chunk >= (long)p.M * cpr) return;
+  const long row = chunk / cpr, col = (chunk - row * cpr) * 8;
+  const long off = row * p.N + col, plane = (long)p.M * p.N;
+  float v[8];
+  {
+    const float4 a = *(const float4*)(slabs + off), b = *(const float4*)(slabs + off + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  for (int z = 1; z < splits; ++z) {
+    const float4 a = *(const float4*)(slabs + z * plane + off), b = *(const float4*)(slabs + z * plane + off + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  epi_store8<EPI>(p, v, row, col);
 }
 
 // DBG (timing ablations only, results are wrong): 1 = no epilogue stores, 2 = no global->LDS loads after the
@@ -419,6 +440,17 @@ static int launch_v2(GemmParams p, int splits, hipStream_t s) {
 static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x96 kernel
 static int g_xcd_n = 1;          // tuning hook: XCD patch layout (see gemm_kernel)
 
+// Small-M GEMMs (packed ECPE batches: ~1.8 k tokens) launch only 84-170 workgroups of 12-48 K steps each on 256 CUs.
+// With a workspace they are run split-K into fp32 slabs + one fused-epilogue pass instead.
+static int auto_splits(const GemmParams& p, size_t ws_bytes) {
+  if (g_gemm_variant != 0) return 1;
+  const int tiles = p.tiles_m * p.tiles_n;
+  int s = 1;
+  while (tiles * s < 256 && p.K >= 1536 && (p.K / (s * 2)) >= 384 && p.K % (128 * s) == 0 &&
+         (size_t)(s * 2) * p.M * p.N * 4 <= ws_bytes) s *= 2;
+  return s;
+}
+
 template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   const bool v2_ok = (p.M % 256 == 0) && (p.N % 96 == 0);
@@ -437,6 +469,17 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 2>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 3>), grid, dim3(256), 0, s, p);
     return check_launch("gemm_kernel<dbg>");
+  }
+  if (EPI != EPI_SLAB_F32 && p.splitk_ws) {
+    const int sp = auto_splits(p, p.splitk_ws_bytes);
+    if (sp > 1) {
+      GemmParams q = p;
+      q.K = p.K / sp; q.outf = p.splitk_ws; q.ldc = p.N; q.colsum_part = nullptr;
+      hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI_SLAB_F32>), dim3(p.tiles_m * p.tiles_n, 1, sp), dim3(256), 0, s, q);
+      const long chunks = (long)p.M * (p.N >> 3);
+      hipLaunchKernelGGL((slab_epilogue_kernel<EPI>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, p, (const float*)p.splitk_ws, sp);
+      return check_launch("gemm_kernel split-K + slab_epilogue_kernel");
+    }
   }
   hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI>), grid, dim3(256), 0, s, p);
   return check_launch("gemm_kernel");
@@ -548,6 +591,9 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
   p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n == 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
+  p.splitk_ws = (float*)a->splitk_ws; p.splitk_ws_bytes = a->splitk_ws ? (size_t)a->splitk_ws_bytes : 0;
+  if (a->ldc != a->N) p.splitk_ws = nullptr;                    // the slab epilogue assumes a dense C
+  if (a->colsum_part) p.splitk_ws = nullptr;                    // fused column sums live in the single-pass epilogue
   p.colsum_part = (float*)a->colsum_part; p.drop_row_map = (const int*)a->drop_row_map; p.colsum_a = (float*)a->colsum_a;
   if (p.colsum_a && a->form != CAREL_GEMM_TN) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: colsum_a is a TN-form (wgrad) option");
   const int form = a->form, epi = a->epilogue;

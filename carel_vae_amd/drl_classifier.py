@@ -410,7 +410,7 @@ class DrlClassifier(nn.Module):
             # zero-filled once: with token packing, attention tiles read (masked) rows past a sample's last token, and
             # 0 * NaN from never-written memory would poison the MFMA sums; everything written later is finite
             ws.act = torch.zeros(lib.carel_encoder_act_bytes(B, S, self.cfg.layers, int(inference)), device=dev, dtype=torch.uint8)
-            ws.scratch = None if inference else torch.zeros(lib.carel_encoder_scratch_bytes(B, S), device=dev, dtype=torch.uint8)
+            ws.scratch = torch.zeros(lib.carel_encoder_scratch_bytes(B, S), device=dev, dtype=torch.uint8)
             self._ws[key] = ws
         return ws
 

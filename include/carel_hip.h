@@ -79,6 +79,9 @@ typedef struct carel_gemm_args {
   float drop_p;
   const void* drop_row_map; /* optional int32 [M]: original row of each (packed) row for the dropout element index
                                (= row_map[row] * ldc + col); NULL = identity */
+  void* splitk_ws;      /* optional f32 workspace: lets small grids (< 256 tiles, K >= 1536) run split-K into slabs
+                           followed by one fused-epilogue pass; results equal up to fp32 summation order */
+  int64_t splitk_ws_bytes;
   void* colsum_a;       /* optional, CAREL_GEMM_TN only: f32 [splits][M] = sum over the K (token) dimension of A[k][m] per
                            K-slice, i.e. the bias gradient that goes with the weight gradient; computed with one extra
                            ones-vector MFMA per step in the first tile column */

@@ -241,11 +241,14 @@ def test_token_packing_equals_padded_computation(golden_dir, name, dropout):
         res[varlen] = (float(loss), {k: float(v) for k, v in model.last_terms().items()}, model._last_call.buf.lat.clone(),
                        {k: p.grad.detach().clone() for k, p in model.named_parameters()})
     (l0, t0, lat0, g0), (l1, t1, lat1, g1) = res[False], res[True]
+    # not bitwise: the packed batch is small enough for the split-K GEMM path, whose fp32 summation order differs, and a
+    # different last bit before a bf16 store is a 2^-8 relative change of that element
     for k in t0:
-        assert abs(t0[k] - t1[k]) <= 2e-5 * max(abs(t0[k]), 1e-3), (k, t0[k], t1[k])
-    assert relnorm(lat1, lat0) < 1e-5
-    worst = max(relnorm(g1[k], g0[k]) for k in g0 if float(g0[k].norm()) > 1e-6)
-    assert worst < 2e-3, worst          # only the summation order over tokens differs (split-K / atomics)
+        assert abs(t0[k] - t1[k]) <= 1e-3 * max(abs(t0[k]), 1e-3), (k, t0[k], t1[k])
+    assert relnorm(lat1, lat0) < 2e-3
+    # (key biases excluded: their gradient is analytically zero, what is stored is rounding noise)
+    worst = max(relnorm(g1[k], g0[k]) for k in g0 if float(g0[k].norm()) > 1e-6 and not k.endswith("key.bias"))
+    assert worst < 2e-2, worst
     # a host-provided length list gives the same packing without the device->host read
     lens = batch["attention_masks"].sum(1).tolist()
     model.set_noise(eps_e, eps_c)
@@ -253,7 +256,7 @@ def test_token_packing_equals_padded_computation(golden_dir, name, dropout):
     args = call(model, batch, it0)
     with torch.no_grad():
         l2 = model(*args, seq_lengths=lens)
-    assert abs(float(l2) - l1) <= 2e-5 * max(abs(l1), 1e-3)
+    assert abs(float(l2) - l1) <= 1e-5 * max(abs(l1), 1e-3)          # same path twice: identical
 
 
 def test_packing_falls_back_to_dense_for_non_prefix_masks(golden_dir):
