@@ -348,8 +348,8 @@ __global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* zl = (float*)smem_raw;                       // [B][D2]
   float* red = zl + a.B * D2;                       // 16
-  float* dl = red + 16;                               // PASS 3: [B][DEC_J] dlogits
-  float* wl = dl + (PASS == 3 ? a.B * DEC_J : 0);     // PASS 3: [DEC_J][D2+1]
+  float* dl = red + 16;                               // [B][DEC_J] staging tile (pass 3: dlogits)
+  float* wl = dl + a.B * DEC_J;                       // PASS 3: [DEC_J][D2+1]  (pass 2: second tile)
   const int t = threadIdx.x, j = blockIdx.x * DEC_J + t;
   const bool live = j < a.V;
   for (int e = t; e < a.B * D2; e += DEC_J) zl[e] = a.z[e];
@@ -357,14 +357,21 @@ __global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
   _Pragma("unroll") for (int k = 0; k < D2; ++k) wr[k] = live ? a.w[(long)j * D2 + k] : 0.f;
   const float bias = live ? a.b[j] : 0.f;
   __syncthreads();
+  // Passes 1 and 2 stage the per-(sample, entry) values of the chunk in an LDS tile [B][DEC_J] and reduce every
+  // sample's row with wave shuffles (each of the 2 waves takes every other sample) -- no per-sample block barriers.
+  float* tile = dl;                                     // [B][DEC_J]
+  const int lane = t & 63, wv = t >> 6;
   if (PASS == 1) {
-    for (int b = 0; b < a.B; ++b) {
-      const float lg = live ? dec_logit<CD2>(wr, zl + b * D2, D2, bias) : -INFINITY;
-      const float m = block_max(lg, red);
-      const float s = block_sum(live ? expf(lg - m) : 0.f, red);
-      if (t == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = m; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = s; }
+    for (int b = 0; b < a.B; ++b) tile[b * DEC_J + t] = live ? dec_logit<CD2>(wr, zl + b * D2, D2, bias) : -INFINITY;
+    __syncthreads();
+    for (int b = wv; b < a.B; b += DEC_J / 64) {
+      const float x0 = tile[b * DEC_J + lane], x1 = tile[b * DEC_J + 64 + lane];
+      const float m = wave_max(fmaxf(x0, x1));
+      const float s2 = wave_sum(expf(x0 - m) + expf(x1 - m));            // exp(-inf - m) = 0 for dead entries
+      if (lane == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = m; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = s2; }
     }
   } else if (PASS == 2) {
+    float* tile2 = tile + a.B * DEC_J;
     for (int b = 0; b < a.B; ++b) {
       float le = 0.f, dt = 0.f;
       if (live) {
@@ -374,9 +381,13 @@ __global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
         le = -(tg * fmaxf(lp, -100.f) + (1.f - tg) * fmaxf(log1pf(-p), -100.f));
         dt = p * ((p - tg) / fmaxf((1.f - p) * p, 1e-12f));
       }
-      le = block_sum(le, red);
-      dt = block_sum(dt, red);
-      if (t == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = le; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = dt; }
+      tile[b * DEC_J + t] = le; tile2[b * DEC_J + t] = dt;
+    }
+    __syncthreads();
+    for (int b = wv; b < a.B; b += DEC_J / 64) {
+      const float le = wave_sum(tile[b * DEC_J + lane] + tile[b * DEC_J + 64 + lane]);
+      const float dt = wave_sum(tile2[b * DEC_J + lane] + tile2[b * DEC_J + 64 + lane]);
+      if (lane == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = le; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = dt; }
     }
   } else {
     float dwr[CD2 ? CD2 : DEC_MAXD2];
@@ -441,6 +452,23 @@ __global__ __launch_bounds__(256) void decoder_total_kernel(const float* __restr
   for (int b = threadIdx.x; b < B; b += 256) tot += rowstat[b * 4 + 3];
   tot = block_sum(tot, red);
   if (threadIdx.x == 0) { terms[7] = tot * inv_bv; terms[8] = terms[0] + tot * inv_bv; }
+}
+
+// out[c] = sum_p parts[p][c]: 16 columns x 16 part-lanes per block, fixed order
+__global__ __launch_bounds__(256) void reduce_parts16_kernel(const float* __restrict__ parts, float* __restrict__ out, int n, int nparts) {
+  __shared__ float lds[256];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < n) for (int p = rl; p < nparts; p += 16) s += parts[(long)p * n + c];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += lds[r * 16 + cl];
+    out[c] = t;
+  }
 }
 
 // dlat = dlat_direct + [dz_e, dz_e*eps_e*exp(lv_e), dz_c, dz_c*eps_c*exp(lv_c)], dz = dz_core + sum_chunks dz_part
@@ -605,12 +633,17 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   d.bow = (const float*)a->bow; d.ls = a->label_smoothing; d.part = w.part; d.rowstat = w.rowstat; d.dz_part = w.dz_part;
   d.dw = (float*)a->d_dec_w; d.db = (float*)a->d_dec_b; d.gscale = 1.0f / ((float)B * (float)V);
   const int chunks = (V + DEC_J - 1) / DEC_J;
-  const size_t lds12 = sizeof(float) * ((size_t)B * 2 * D + 16);
-  const size_t lds3 = lds12 + sizeof(float) * ((size_t)B * DEC_J + (size_t)DEC_J * (2 * D + 1));
-  if (lds3 > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the decoder kernel");
-  if (lds3 > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)decoder_kernel<3, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decoder_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+  const size_t lds0 = sizeof(float) * ((size_t)B * 2 * D + 16);
+  const size_t lds1 = lds0 + sizeof(float) * (size_t)B * DEC_J;
+  const size_t lds2 = lds0 + sizeof(float) * 2 * (size_t)B * DEC_J;
+  const size_t lds3 = lds0 + sizeof(float) * ((size_t)B * DEC_J + (size_t)DEC_J * (2 * D + 1));
+  const size_t ldsmax = lds2 > lds3 ? lds2 : lds3;
+  if (ldsmax > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the decoder kernel");
+  if (ldsmax > 64 * 1024) {
+    hipError_t e = hipSuccess;
+    const void* fns[6] = {(const void*)decoder_kernel<1, 48>, (const void*)decoder_kernel<2, 48>, (const void*)decoder_kernel<3, 48>,
+                          (const void*)decoder_kernel<1, 0>, (const void*)decoder_kernel<2, 0>, (const void*)decoder_kernel<3, 0>};
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
 #define DEC_LAUNCH(PASS, LDS)                                                                              \
@@ -618,17 +651,19 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
     if (2 * D == 48) hipLaunchKernelGGL((decoder_kernel<PASS, 48>), dim3(chunks), dim3(DEC_J), LDS, stream, d); \
     else hipLaunchKernelGGL((decoder_kernel<PASS, 0>), dim3(chunks), dim3(DEC_J), LDS, stream, d);      \
   } while (0)
-  DEC_LAUNCH(1, lds12);
+  DEC_LAUNCH(1, lds1);
   hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 1, w.rowstat);
-  DEC_LAUNCH(2, lds12);
+  DEC_LAUNCH(2, lds2);
   hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 2, w.rowstat);
   hipLaunchKernelGGL(decoder_total_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.rowstat, B, d.gscale, (float*)a->terms);
   DEC_LAUNCH(3, lds3);
 #undef DEC_LAUNCH
   if ((rc = check_launch("decoder kernels"))) return rc;
   // d(loss)/d lat, unscaled (grad_output is applied in carel_tail_backward)
+  // sum the decoder's per-chunk dz partials into slot 0 (in place is safe: block c only reads column c of every part)
+  hipLaunchKernelGGL(reduce_parts16_kernel, dim3((B * 2 * D + 15) / 16), dim3(256), 0, stream, (const float*)w.dz_part, w.dz_part, B * 2 * D, chunks);
   hipLaunchKernelGGL(tail_dlat_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, stream, (const float*)w.dz_core, (const float*)w.dz_part,
-                     chunks, (const float*)w.dlat_direct, (const float*)a->lat, (const float*)a->eps_e, (const float*)a->eps_c, B, D, 1.0f, w.dlat);
+                     1, (const float*)w.dlat_direct, (const float*)a->lat, (const float*)a->eps_e, (const float*)a->eps_c, B, D, 1.0f, w.dlat);
   return check_launch("tail_dlat_kernel");
 }
 
