@@ -20,7 +20,7 @@ struct LayerAct {
 struct ActLayout {
   size_t per_layer, total;
   size_t o_xin, o_qkv, o_lse, o_ctx, o_h1, o_st1, o_x1, o_u, o_g, o_h2, o_st2;
-  size_t o_embst, o_xa, o_xb, o_layers;
+  size_t o_embst, o_xa, o_xb, o_cctx, o_cxres, o_layers;
 };
 
 ActLayout act_layout(long B, long S, int L, int inference) {
@@ -42,6 +42,9 @@ ActLayout act_layout(long B, long S, int L, int inference) {
   a.o_embst = g; g += al(T * 2 * 4);
   a.o_xa = g; g += al(T * EH * 4);
   a.o_xb = g; g += al(T * EH * 4);
+  const size_t Bc = ((size_t)B + 127) / 128 * 128;          // compact [CLS] rows of the last layer
+  a.o_cctx = g; g += al(Bc * EH * 2);
+  a.o_cxres = g; g += al(Bc * EH * 4);
   a.o_layers = g;
   a.total = g + a.per_layer * (inference ? 1 : (size_t)L);
   return a;
@@ -107,6 +110,10 @@ int enc_check(const carel_encoder_args* a, const char* who) {
   if (a->seq_len < 32 || a->seq_len > 128 || (a->seq_len & 31)) return set_error(CAREL_ERR_SHAPE, "%s: seq_len must be 32/64/96/128", who);
   if (((long)a->batch * a->seq_len) % 128) return set_error(CAREL_ERR_SHAPE, "%s: batch*seq_len must be a multiple of 128 (pad the batch)", who);
   if (!a->input_ids || !a->layers || !a->act) return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  if (a->n_cls) {
+    if (!a->cls_rows || !a->cls_orig_rows || a->n_cls % 128 || a->n_cls < a->batch || a->n_cls > ((a->batch + 127) / 128) * 128)
+      return set_error(CAREL_ERR_ARG, "%s: n_cls must be batch rounded up to 128, with cls_rows and cls_orig_rows", who);
+  }
   if (a->tok_row || a->cu_seqlens || a->n_tokens) {
     if (!a->tok_row || !a->cu_seqlens || a->n_tokens <= 0 || a->n_tokens % 128 || a->n_tokens > a->batch * a->seq_len)
       return set_error(CAREL_ERR_ARG, "%s: packing needs tok_row, cu_seqlens and n_tokens (multiple of 128, <= batch*seq_len)", who);
@@ -197,16 +204,25 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
     at.cu_seqlens = a->cu_seqlens;
     if ((rc = carel_attention_fwd(&at, stream))) return rc;
-    if ((rc = gemm_call(la.ctx, w.out_w, EH, EH, (int)T, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
-                        w.out_b, xa, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, a->tok_row))) return rc;
-    if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, T, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
-    if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)T, EI, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_GELU, 1, la.u, la.g, nullptr,
+    const bool cls_only = a->n_cls > 0 && i + 1 == a->n_layers;
+    long R = T;                                  // rows of the row-wise half of this layer
+    const void* Actx = la.ctx; const void* res1 = xa; const void* rmap = a->tok_row;
+    if (cls_only) {                              // only the [CLS] rows of the last layer are ever read
+      R = a->n_cls;
+      char* cctx = base + l.o_cctx; char* cxres = base + l.o_cxres;
+      if ((rc = gather_rows(xa, la.ctx, a->cls_rows, (int)R, cxres, cctx, (hipStream_t)stream))) return rc;
+      Actx = cctx; res1 = cxres; rmap = a->cls_orig_rows;
+    }
+    if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
+                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap))) return rc;
+    if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
+    if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_GELU, 1, la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
-    if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)T, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, a->tok_row, ws, ws_bytes))) return rc;
+    if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes))) return rc;
     void* next_bf16 = nullptr;
     if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16;
-    if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, T, EH, xa, next_bf16, la.st2, stream))) return rc;
+    if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, xa, next_bf16, la.st2, stream))) return rc;
   }
   return CAREL_OK;
 }
@@ -228,26 +244,42 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
   const ScratchLayout sl = scratch_layout(B, S);
   const size_t ws_bytes = sl.o_part - sl.o_slabs;
+  // Row-wise half of the layer.  Last layer with dead-row elimination: only the n_cls [CLS] rows exist (compact).
+  const bool cls_only = a->n_cls > 0 && layer + 1 == a->n_layers;
+  const long R = cls_only ? (long)a->n_cls : T;
+  const void* rmap = cls_only ? a->cls_orig_rows : a->tok_row;
+  const void* ctx_rows = cls_only ? (const void*)((char*)a->act + l.o_cctx) : (const void*)la.ctx;
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
-  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h2, la.st2, w.ln2_g, T, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout,
-                                       a->tok_row, s.dy, s.dyb, g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
+  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h2, la.st2, w.ln2_g, R, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout,
+                                       rmap, s.dy, s.dyb, g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
-  if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)T, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
+  if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
                       nullptr, la.u, 0, 0, 0, 0.f, stream, s.part))) return rc;
-  if ((rc = carel_partial_reduce_f32(s.part, g.ffn1_b, EI, (int)(T / 128), 0, stream))) return rc;
-  if ((rc = wgrad_call(s.dyb, la.g, T, EH, EI, s.slabs, g.ffn2_w, stream))) return rc;
+  if ((rc = carel_partial_reduce_f32(s.part, g.ffn1_b, EI, (int)(R / 128), 0, stream))) return rc;
+  if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, stream))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
-  if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)T, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
+  if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
                       nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
-  if ((rc = wgrad_call(s.du, la.x1_bf16, T, EI, EH, s.slabs, g.ffn1_w, stream))) return rc;
+  if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, stream))) return rc;
   // LN1 backward
-  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h1, la.st1, w.ln1_g, T, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout,
-                                       a->tok_row, s.dy, s.dyb, g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
+  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h1, la.st1, w.ln1_g, R, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout,
+                                       rmap, s.dy, s.dyb, g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
-  if ((rc = gemm_call(s.dyb, w.out_w, EH, EH, (int)T, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, s.dctx, nullptr, nullptr, nullptr,
+  void* dctx_rows = cls_only ? (void*)s.du : (void*)s.dctx;       // compact result parks in the (free) du buffer
+  if ((rc = gemm_call(s.dyb, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
                       nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
-  if ((rc = wgrad_call(s.dyb, la.ctx, T, EH, EH, s.slabs, g.out_w, stream))) return rc;
+  if ((rc = wgrad_call(s.dyb, ctx_rows, R, EH, EH, s.slabs, g.out_w, stream))) return rc;
+  if (cls_only) {
+    // expand the compact [CLS] gradients to token rows: dctx (attention backward input) and the residual-path
+    // gradient dh1 (added by the QKV dgrad epilogue) are zero everywhere else
+    hipError_t he = hipMemsetAsync(s.dctx, 0, (size_t)T * EH * 2, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a->dx, 0, (size_t)T * EH * 4, (hipStream_t)stream);
+    if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
+    if ((rc = scatter_rows(nullptr, s.du, a->cls_rows, (int)R, nullptr, s.dctx, (hipStream_t)stream))) return rc;
+    if ((rc = scatter_rows(s.dy, nullptr, a->cls_rows, (int)R, a->dx, nullptr, (hipStream_t)stream))) return rc;
+  }
+  const void* dh1_full = cls_only ? (const void*)a->dx : (const void*)s.dy;      // in-place residual add is safe (same thread)
   // attention backward
   carel_attn_args at;
   at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = s.dctx; at.dqkv = s.dqkv;
@@ -263,7 +295,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
-                      s.dy, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
+                      dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
   return wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, stream, g.qkv_b);
 }
 

@@ -360,6 +360,60 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   }
 }
 
+// out[i] = in[idx[i]] (768-wide rows; idx < 0 -> zeros); one wave per row.  f32 and bf16 variants.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in_f, const bf16_t* __restrict__ in_b,
+                                                          const int* __restrict__ idx, int n, float* __restrict__ out_f,
+                                                          bf16_t* __restrict__ out_b) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const long r = idx[i];
+  if (in_f) {
+    Row X;
+    if (r >= 0) X = load_row(in_f + r * H, lane);
+    else for (int v = 0; v < NV; ++v) X.v[v] = float4{0.f, 0.f, 0.f, 0.f};
+    store_row(out_f + (long)i * H, lane, X);
+  }
+  if (in_b) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      uint2 x = {0u, 0u};
+      if (r >= 0) x = *(const uint2*)(in_b + r * H + c);
+      *(uint2*)(out_b + (long)i * H + c) = x;
+    }
+  }
+}
+// out[idx[i]] = in[i] for idx[i] >= 0 (destination pre-zeroed by the caller)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ in_f, const bf16_t* __restrict__ in_b,
+                                                           const int* __restrict__ idx, int n, float* __restrict__ out_f,
+                                                           bf16_t* __restrict__ out_b) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const long r = idx[i];
+  if (r < 0) return;
+  if (in_f) store_row(out_f + r * H, lane, load_row(in_f + (long)i * H, lane));
+  if (in_b) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      *(uint2*)(out_b + r * H + c) = *(const uint2*)(in_b + (long)i * H + c);
+    }
+  }
+}
+
+int gather_rows(const void* in_f32, const void* in_bf16, const void* idx, int n, void* out_f32, void* out_bf16, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const float*)in_f32, (const bf16_t*)in_bf16,
+                     (const int*)idx, n, (float*)out_f32, (bf16_t*)out_bf16);
+  return check_launch("gather_rows_kernel");
+}
+int scatter_rows(const void* in_f32, const void* in_bf16, const void* idx, int n, void* out_f32, void* out_bf16, hipStream_t stream) {
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const float*)in_f32, (const bf16_t*)in_bf16,
+                     (const int*)idx, n, (float*)out_f32, (bf16_t*)out_bf16);
+  return check_launch("scatter_rows_kernel");
+}
+
 }  // namespace carel
 
 using namespace carel;

@@ -272,6 +272,7 @@ class DrlClassifier(nn.Module):
         _init_like_reference(self, gen)
         self.dropout_base_seed = 0x5EED
         self.varlen = True                   # skip padded positions (results identical; see _pack_info)
+        self.cls_only_last = True            # last layer's row-wise half on the [CLS] rows only (results identical)
         self._fwd_count = 0
         self._noise = None
         self._ws = {}
@@ -414,10 +415,32 @@ class DrlClassifier(nn.Module):
             self._ws[key] = ws
         return ws
 
-    def _encoder_args(self, ids, att, tt, ws, B, S, inference, train, seed, row_offset, pack=None):
+    def _cls_info(self, B, Bp, S, pack, dev):
+        """Index arrays of the dead-row elimination (include/carel_hip.h, carel_encoder_args.n_cls); B real samples,
+        Bp = batch the encoder runs (padded so that Bp*S is a multiple of 128)."""
+        if not self.cls_only_last:
+            return None
+        n_cls = (Bp + 127) // 128 * 128
+        key = ("cls", B, Bp, S)
+        base = self._ws.get(key)
+        if base is None:
+            orig = np.full(n_cls, -1, dtype=np.int32)
+            orig[:B] = np.arange(B, dtype=np.int32) * S
+            base = SimpleNamespace(orig=torch.from_numpy(orig).to(dev), compact=torch.arange(B, dtype=torch.int32, device=dev))
+            self._ws[key] = base
+        if pack is None:
+            rows = base.orig                      # dense: the [CLS] token of sample i sits at row i*S
+        else:
+            rows = torch.full((n_cls,), -1, dtype=torch.int32, device=dev)
+            rows[:B] = pack.cu[:B]
+        return SimpleNamespace(n_cls=n_cls, rows=rows, orig=base.orig, compact=base.compact)
+
+    def _encoder_args(self, ids, att, tt, ws, B, S, inference, train, seed, row_offset, pack=None, cls=None):
         a = L.EncoderArgs()
         if pack is not None:
             a.n_tokens, a.tok_row, a.cu_seqlens = pack.n_tokens, pack.tok_row.data_ptr(), pack.cu.data_ptr()
+        if cls is not None:
+            a.n_cls, a.cls_rows, a.cls_orig_rows = cls.n_cls, cls.rows.data_ptr(), cls.orig.data_ptr()
         c = self.cfg
         a.batch, a.seq_len, a.n_layers, a.hidden, a.heads, a.intermediate = B, S, c.layers, H, NH, I_FF
         a.vocab_size, a.max_pos, a.type_vocab, a.roberta, a.pad_id, a.inference = (c.vocab_size, c.max_pos, c.type_vocab,
@@ -553,7 +576,8 @@ class DrlClassifier(nn.Module):
         self._refresh_shadow()
         train_drop = self.training          # dropout follows module mode (model.train() / .eval()), like nn.Dropout
         ws = self._workspace(c.Bp, c.S, inference=not training)
-        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset, c.pack)
+        c.cls = self._cls_info(c.B, c.Bp, c.S, c.pack, self._flat.device)
+        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset, c.pack, c.cls)
         lib = L.load()
         st = L.current_stream()
         L.check(lib.carel_encoder_forward(C.byref(ea), st), "carel_encoder_forward")
@@ -562,9 +586,11 @@ class DrlClassifier(nn.Module):
         xl = SimpleNamespace(data_ptr=lambda: x_last_ptr)
         klw = ops.kl_anneal_weight(c.iteration, self.opt)
         drop = (self.opt.dropout if train_drop else 0.0, c.seed, c.row_offset)
-        ta = ops.tail_args(c.buf, xl, W, c.labels, c.eps_e, c.eps_c, self.opt, klw, grads=G, drop=drop,
-                           cls_rows=None if c.pack is None else c.pack.cu,
-                           n_rows=c.Bp * c.S if c.pack is None else c.pack.n_tokens)
+        if c.cls is not None:           # compact final hidden states: sample i's [CLS] is row i
+            cls_rows, n_rows = c.cls.compact, c.cls.n_cls
+        else:
+            cls_rows, n_rows = (None, c.Bp * c.S) if c.pack is None else (c.pack.cu, c.pack.n_tokens)
+        ta = ops.tail_args(c.buf, xl, W, c.labels, c.eps_e, c.eps_c, self.opt, klw, grads=G, drop=drop, cls_rows=cls_rows, n_rows=n_rows)
         ops.tail_latents(ta)
         if self._dp is not None:
             self._dp.fill_global(ta, c)                  # all-gather z, all-reduce label sum
@@ -656,7 +682,8 @@ class DrlClassifier(nn.Module):
             tt = None if token_type_ids is None else self._prep_ids(token_type_ids[s:s + chunk], Bp)
             ws = self._workspace(Bp, S, inference=True)
             pack = self._pack_info(att, B, Bp, S)
-            ea = self._encoder_args(ids, att, tt, ws, Bp, S, True, False, 0, 0, pack)
+            cls = self._cls_info(B, Bp, S, pack, dev)
+            ea = self._encoder_args(ids, att, tt, ws, Bp, S, True, False, 0, 0, pack, cls)
             L.check(lib.carel_encoder_forward(C.byref(ea), L.current_stream()), "carel_encoder_forward")
             x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
             key = ("tail", B, S)
@@ -666,8 +693,8 @@ class DrlClassifier(nn.Module):
                 self._ws[key] = buf
             W, _ = self._tail_weights()
             ta = ops.tail_args(buf, SimpleNamespace(data_ptr=lambda: x_last_ptr), W, None, None, None, self.opt, 1.0,
-                               cls_rows=None if pack is None else pack.cu)
-            ta._keep = pack
+                               cls_rows=cls.compact if cls is not None else (None if pack is None else pack.cu))
+            ta._keep = (pack, cls)
             ops.tail_latents(ta)
             out[s:s + B] = ops.pair_probs(buf.lat, eps_e, eps_c, W["pair_classifier.weight"], W["pair_classifier.bias"], self.opt.ec_dim)
         return out

@@ -224,6 +224,13 @@ typedef struct carel_encoder_args {
    * n_tokens = packed row count rounded up to 128, tok_row int32 [n_tokens] (original row or -1),
    * cu_seqlens int32 [B+1].  n_tokens = 0 / NULL pointers = dense. */
   int32_t n_tokens; const void* tok_row; const void* cu_seqlens;
+  /* dead-row elimination: nothing but the [CLS] row of the last layer's output is ever read (HF BertPooler), so the last
+   * layer runs its row-wise part (out-proj, LayerNorm, FFN, LayerNorm) and their backward on the n_cls (= batch rounded
+   * up to 128) [CLS] rows only; results are unchanged.  cls_rows int32 [n_cls]: row of sample i's [CLS] token in the
+   * current (dense or packed) row space, -1 for filler; cls_orig_rows int32 [n_cls]: its original row i*S (dropout
+   * index), -1 for filler.  The final hidden states (carel_encoder_x_last) are then the n_cls compact rows, and dx is
+   * read as n_cls compact rows by the backward of the last layer.  n_cls = 0 disables. */
+  int32_t n_cls; const void* cls_rows; const void* cls_orig_rows;
   const carel_layer_grads* layer_grads;     /* HOST array [n_layers] */
   void* d_word_emb; void* d_pos_emb; void* d_type_emb; void* d_emb_ln_g; void* d_emb_ln_b;
   void* dx;

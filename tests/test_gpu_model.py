@@ -271,3 +271,31 @@ def test_packing_falls_back_to_dense_for_non_prefix_masks(golden_dir):
     assert model._last_call.pack is None
     ref = O.forward_terms(P, b, 0, cfg, opt, torch.zeros(24), torch.zeros(24), quant=O.bf16_round)
     assert abs(float(out["emo"]) - float(ref["emo"])) < 5e-3 * abs(float(ref["emo"]))
+
+
+@pytest.mark.parametrize("name", ["zh_small", "zh_ragged", "zh_allneg"])
+def test_cls_only_last_layer_equals_full_computation(golden_dir, name):
+    """Dead-row elimination: running the last layer's row-wise half on the [CLS] rows only changes nothing."""
+    cfg, opt = CASES[name]
+    opt = O.Opt(**{**vars(opt), "dropout": 0.5})
+    z, batch = load(golden_dir, name)
+    B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
+    eps_e, eps_c = torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"])
+    res = {}
+    for flag in (False, True):
+        model, P = build(cfg, opt, wseed, train_dropout=True)
+        model.train()
+        model.cls_only_last = flag
+        model.set_noise(eps_e, eps_c)
+        loss = model(*call(model, batch, it0))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[flag] = ({k: float(v) for k, v in model.last_terms().items()}, model._last_call.buf.lat.clone(),
+                     {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    (t0, lat0, g0), (t1, lat1, g1) = res[False], res[True]
+    for k in t0:
+        assert abs(t0[k] - t1[k]) <= 1e-3 * max(abs(t0[k]), 1e-3), (k, t0[k], t1[k])
+    assert relnorm(lat1, lat0) < 2e-3
+    worst = {k: relnorm(g1[k], g0[k]) for k in g0 if float(g0[k].norm()) > 1e-6 and not k.endswith("key.bias")}
+    bad = {k: v for k, v in worst.items() if v > 2e-2}
+    assert not bad, bad
