@@ -100,9 +100,11 @@ def main():
     from carel_vae_amd import drl_classifier as M
     lib = L.load()
     L.check(lib.carel_init(local_rank), "carel_init")
-    if world > 1:
+    force_dp = os.environ.get("CAREL_FORCE_DP") == "1"      # exercise the RCCL path with a single rank (self-test)
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from oracle import carel_oracle as O          # synthetic batch generator only (test infrastructure helper)
@@ -112,7 +114,7 @@ def main():
     model = M.DrlClassifier(opt, cfg, seed=0).to(dev)
     model.train()
     dp = None
-    if world > 1:
+    if world > 1 or force_dp:
         from carel_vae_amd.dp import DataParallel
         dp = DataParallel(model)
     optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr)
@@ -233,7 +235,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = pairs_per_s / base["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

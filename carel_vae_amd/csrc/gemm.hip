@@ -235,6 +235,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     if (kt + 1 < nk && DBG != 2) stage(kt + 1, (kt + 1) & 1);
     const char* ta = smem + (kt & 1) * 32768;
     const char* tb = ta + 16384;
+    if (DBG >= 5) {
+      // variant under test: issue the fragment reads of BOTH k sub-steps before the first MFMA
+      bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[k2][i] = AT ? frag16_col(ta, wr * 64 + i * 16, k2 * 32) : frag16_row(ta, wr * 64 + i * 16, k2 * 32);
+          fb[k2][i] = BT ? frag16_col(tb, wc * 64 + i * 16, k2 * 32) : frag16_row(tb, wc * 64 + i * 16, k2 * 32);
+        }
+      if (DBG == 6) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[k2][j], fa[k2][i], acc[i][j]);
+      if (DBG == 6) __builtin_amdgcn_s_setprio(0);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 64; ks += 32) {
       bf16x8 fa[4], fb[4];
@@ -243,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         fa[i] = AT ? frag16_col(ta, wr * 64 + i * 16, ks) : frag16_row(ta, wr * 64 + i * 16, ks);
         fb[i] = BT ? frag16_col(tb, wc * 64 + i * 16, ks) : frag16_row(tb, wc * 64 + i * 16, ks);
       }
+      if (DBG == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -250,10 +270,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           if (DBG == 3) { asm volatile("" :: "v"(fb[j]), "v"(fa[i])); }
           else acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
         }
+      if (DBG == 4) __builtin_amdgcn_s_setprio(0);
       if (AT && do_cs && wc == 0) {                           // block-uniform x wave-uniform
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc1[i] = mfma16(ones, fa[i], acc1[i]);
       }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -464,10 +486,13 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
   }
   if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 13) {   // timing ablations
+  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 16) {   // timing ablations / variants
     if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 1>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 2>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 3>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 4>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 15) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 5>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 16) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 6>), grid, dim3(256), 0, s, p);
     return check_launch("gemm_kernel<dbg>");
   }
   if (EPI != EPI_SLAB_F32 && p.splitk_ws) {

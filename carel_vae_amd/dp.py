@@ -31,7 +31,7 @@ class FlatGradReducer:
 
     def reduce(self, name):
         lo, hi = self.buckets[name]
-        if hi <= lo or self.world == 1:
+        if hi <= lo:
             return
         view = self.flat[lo:hi]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
@@ -83,7 +83,7 @@ class DataParallel:
 
     def fill_global(self, ta, call):
         """All-gather the sampled latents and all-reduce the label sum; point the tail at them."""
-        if not self.global_batch_terms or self.world == 1:
+        if not self.global_batch_terms:
             return
         z = call.buf.z
         z_all = torch.empty((self.world * z.shape[0], z.shape[1]), device=z.device, dtype=z.dtype)
