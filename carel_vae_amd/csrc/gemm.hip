@@ -222,9 +222,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   auto stage = [&](int kt, int buf) {
     char* ta = smem + buf * 32768;
     char* tb = ta + 16384;
-    const long k0 = kbase + (long)kt * 64;
-    if (AT) stage_col_image(p.A, p.lda, k0, m0, ta); else stage_row_image<128>(p.A, p.lda, m0, k0, ta);
-    if (BT) stage_col_image(p.B, p.ldb, k0, n0, tb); else stage_row_image<128>(p.B, p.ldb, n0, k0, tb);
+    const long k0 = (DBG == 9) ? 0 : kbase + (long)kt * 64;             // DBG 9: every block re-reads one L2-hot tile
+    const long ms = (DBG == 9) ? 0 : m0, ns = (DBG == 9) ? 0 : n0;
+    if (AT) stage_col_image(p.A, p.lda, k0, ms, ta); else stage_row_image<128>(p.A, p.lda, ms, k0, ta);
+    if (BT) stage_col_image(p.B, p.ldb, k0, ns, tb); else stage_row_image<128>(p.B, p.ldb, ns, k0, tb);
   };
 
   const int nk = p.K >> 6;
@@ -235,7 +236,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     if (kt + 1 < nk && DBG != 2) stage(kt + 1, (kt + 1) & 1);
     const char* ta = smem + (kt & 1) * 32768;
     const char* tb = ta + 16384;
-    if (DBG >= 5) {
+    if (DBG == 7 || DBG == 8) {
+      // ablation: LDS fragment reads removed (7: all, 8: the B operand's) after the first K step
+      static_assert(true, "");
+      bf16x8 fa[4], fb[4];
+      if (kt == 0 || DBG == 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = frag16_row(ta, wr * 64 + i * 16, 0);
+      }
+      if (kt == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[i] = frag16_row(tb, wc * 64 + i * 16, 0);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        if (DBG == 8 && k2 == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[i] = frag16_row(ta, wr * 64 + i * 16, 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+      }
+    } else if (DBG >= 5) {
       // variant under test: issue the fragment reads of BOTH k sub-steps before the first MFMA
       bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
@@ -338,125 +362,178 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 }
 
 // =============================================================================================
-// v2: 256 x 96 x 64 block tile, 512 threads = 8 waves (4 x 2), each wave 64 x 48 = 4 x 3 MFMA tiles.
-// Three LDS stages (3 x 48 KiB, one workgroup per CU); the LDS-DMA loads of tile t+2 are issued right
-// after the single per-K-step barrier and stay in flight across the next barrier: the wait that retires
-// tile t is a COUNTED s_waitcnt vmcnt(G) (G = this wave's LDS-DMA instructions per tile), never 0 inside
-// the loop, and the barrier is a raw s_barrier (a __syncthreads() would drain vmcnt).
-// 96-wide N tiles make every encoder GEMM at M = 8192 an exact multiple of 256 workgroups
-// (N = 768 -> 256, 2304 -> 768, 3072 -> 1024).
+// "big" tile: 256 x 192 x 64, 512 threads = 8 waves (2 x 4), each wave 128 x 48 = 8 x 3 MFMA tiles.
+// The 128x128 kernel's main loop runs at the L2->LDS (LDS-DMA) bandwidth of its tile (64 FLOP per staged byte:
+// tools/ablate_gemm.py); this tile stages (256+192) x 64 x 2 B per 2*256*192*64 FLOP = 110 FLOP/B.  One workgroup per
+// CU (2 x 56..64 KiB LDS), two waves per SIMD.  Used for the N = 2304 / 3072 GEMMs and the weight gradients.
 // =============================================================================================
-constexpr int V2_STAGE = 49152;            // A 32 KiB + B 16 KiB
-constexpr int V2_LDS = 3 * V2_STAGE;
-
-template <int ROWS>
-__device__ __forceinline__ void stage_row_image8(const bf16_t* __restrict__ g, long ld, long row0, long k0, char* lds_tile) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int q = wave; q < ROWS / 8; q += 8) {
-    const int r = q * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
-    __builtin_amdgcn_global_load_lds(g + (row0 + r) * ld + k0 + c * 8, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
-  }
-}
-// one [64 k][128 x] COL image of which the first NCH 16-byte chunks per row are used
-template <int NCH>
-__device__ __forceinline__ void stage_col_image8(const bf16_t* __restrict__ g, long ld, long krow0, long x0, char* lds_tile) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int q = wave; q < 16; q += 8) {
-    const int r = q * 4 + (lane >> 4);
-    const int c = (lane & 15) ^ swz_col(r);
-    if (NCH == 16 || c < NCH)
-      __builtin_amdgcn_global_load_lds(g + (krow0 + r) * ld + x0 + c * 8, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
-  }
-}
+constexpr int BIG_STAGE = 65536;           // A 32 KiB + B up to 32 KiB (two COL images)
+constexpr int BIG_LDS = 2 * BIG_STAGE;
 
 template <bool AT, bool BT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_kernel_v2(GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm_kernel_big(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave >> 2, wc = wave & 3;
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
-  const long m0 = (long)tm * 256, n0 = (long)tn * 96;
+  const long m0 = (long)tm * 256, n0 = (long)tn * 192;
   const long kbase = (long)blockIdx.z * p.K;
 
-  f32x4 acc[4][3];
+  f32x4 acc[8][3];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = AT && p.colsum_a != nullptr && tn == 0;
+  f32x4 acc1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
   auto stage = [&](int kt, int buf) {
-    char* ta = smem + buf * V2_STAGE;
+    char* ta = smem + buf * BIG_STAGE;
     char* tb = ta + 32768;
     const long k0 = kbase + (long)kt * 64;
-    if (AT) {
-      for (int q = wave; q < 32; q += 8) {           // two [64][128] COL images side by side
-        const int img = q >> 4, qi = q & 15;
+    if (AT) {                                          // [64 k][256 m] = two COL images
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i, img = q >> 4, qi = q & 15;
         const int r = qi * 4 + (lane >> 4);
         const int c = (lane & 15) ^ swz_col(r);
-        __builtin_amdgcn_global_load_lds(p.A + (k0 + r) * p.lda + m0 + img * 128 + c * 8,
-                                         (CAREL_LDS void*)(ta + img * 16384 + qi * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(p.A + (k0 + r) * p.lda + m0 + img * 128 + c * 8, (CAREL_LDS void*)(ta + img * 16384 + qi * 1024), 16, 0, 0);
       }
-    } else {
-      stage_row_image8<256>(p.A, p.lda, m0, k0, ta);
+    } else {                                           // ROW image of 256 rows
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;
+        const int r = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        __builtin_amdgcn_global_load_lds(p.A + (m0 + r) * p.lda + k0 + c * 8, (CAREL_LDS void*)(ta + q * 1024), 16, 0, 0);
+      }
     }
-    if (BT) stage_col_image8<12>(p.B, p.ldb, k0, n0, tb); else stage_row_image8<96>(p.B, p.ldb, n0, k0, tb);
+    if (BT) {                                          // [64 k][192 n]: COL image 0 full, image 1 first 64 columns
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i, img = q >> 4, qi = q & 15;
+        const int r = qi * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ swz_col(r);
+        if (img == 0 || c < 8)
+          __builtin_amdgcn_global_load_lds(p.B + (k0 + r) * p.ldb + n0 + img * 128 + c * 8, (CAREL_LDS void*)(tb + img * 16384 + qi * 1024), 16, 0, 0);
+      }
+    } else {                                           // ROW image of 192 rows
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int q = wave * 3 + i;
+        const int r = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        __builtin_amdgcn_global_load_lds(p.B + (n0 + r) * p.ldb + k0 + c * 8, (CAREL_LDS void*)(tb + q * 1024), 16, 0, 0);
+      }
+    }
   };
-  // LDS-DMA instructions per tile issued by THIS wave: A 4; B 2 (COL image) or 2/1 (96-row ROW image: 12 pieces)
-  const bool six = BT || wave < 4;
 
   const int nk = p.K >> 6;
   stage(0, 0);
-  if (nk > 1) stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      if (six) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
-    const char* ta = smem + (kt % 3) * V2_STAGE;
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* ta = smem + (kt & 1) * BIG_STAGE;
     const char* tb = ta + 32768;
 #pragma unroll
     for (int ks = 0; ks < 64; ks += 32) {
-      bf16x8 fa[4], fb[3];
+      bf16x8 fa[8], fb[3];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[i] = AT ? frag16_col(ta + (wr >> 1) * 16384, (wr & 1) * 64 + i * 16, ks) : frag16_row(ta, wr * 64 + i * 16, ks);
+      for (int i = 0; i < 8; ++i) fa[i] = AT ? frag16_col(ta + wr * 16384, i * 16, ks) : frag16_row(ta, wr * 128 + i * 16, ks);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) fb[j] = BT ? frag16_col(tb, wc * 48 + j * 16, ks) : frag16_row(tb, wc * 48 + j * 16, ks);
+      for (int j = 0; j < 3; ++j) {
+        const int n = wc * 48 + j * 16;
+        fb[j] = BT ? frag16_col(tb + (n >> 7) * 16384, n & 127, ks) : frag16_row(tb, n, ks);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+      if (AT && do_cs && wc == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc1[i] = mfma16(ones, fa[i], acc1[i]);
+      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
+  if (AT && do_cs && wc == 0 && lane < 16) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long row = m0 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < 8; ++i) p.colsum_a[(long)blockIdx.z * p.M + m0 + wr * 128 + i * 16 + lane] = acc1[i][0];
+  }
+  // epilogue through LDS in four 48-column slabs: thread -> (column chunk c = t % 6 fixed, rows t/6 + 85*it)
+  float* ct = (float*)smem;
+  constexpr int CT_LD = 52;
+  const int t = threadIdx.x, cchunk = t % 6, rbase = t / 6;
+#pragma unroll 1
+  for (int h = 0; h < 4; ++h) {
+    __syncthreads();
+    if (wc == h) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) epi_store<EPI>(p, acc[i][j], row, n0 + wc * 48 + j * 16 + (lane >> 4) * 4);
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          *(f32x4*)(ct + (wr * 128 + i * 16 + (lane & 15)) * CT_LD + j * 16 + (lane >> 4) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    float cs[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs[0][e] = 0.f; cs[1][e] = 0.f; }
+    if (rbase < 85) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = rbase + 85 * it;
+        if (r < 256) {
+          const float4 a = *(const float4*)(ct + r * CT_LD + cchunk * 8), b = *(const float4*)(ct + r * CT_LD + cchunk * 8 + 4);
+          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          epi_store8<EPI>(p, v, m0 + r, n0 + h * 48 + cchunk * 8);
+          if (EPI == EPI_DGELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[r >> 7][e] += v[e];
+          }
+        }
+      }
+    }
+    if (EPI == EPI_DGELU_BF16 && p.colsum_part) {       // per-128-row partial column sums (bias gradient), block-uniform
+      __syncthreads();
+      float* sc = ct;                                     // [2][85][48]
+      if (rbase < 85) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[(0 * 85 + rbase) * 48 + cchunk * 8 + e] = cs[0][e]; sc[(1 * 85 + rbase) * 48 + cchunk * 8 + e] = cs[1][e]; }
+      }
+      __syncthreads();
+      if (t < 96) {
+        const int half = t / 48, c = t % 48;
+        float tot = 0.f;
+        for (int r = 0; r < 85; ++r) tot += sc[(half * 85 + r) * 48 + c];
+        p.colsum_part[((long)tm * 2 + half) * p.N + n0 + h * 48 + c] = tot;
+      }
+    }
   }
 }
 
 template <bool AT, bool BT, int EPI>
-static int launch_v2(GemmParams p, int splits, hipStream_t s) {
+static int launch_big(GemmParams p, int splits, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_v2<AT, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_kernel_v2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel_big<AT, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_kernel_big: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
-  p.tiles_m = p.M / 256; p.tiles_n = p.N / 96;
+  p.tiles_m = p.M / 256; p.tiles_n = p.N / 192;
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel_v2<AT, BT, EPI>), grid, dim3(512), V2_LDS, s, p);
-  return check_launch("gemm_kernel_v2");
+  hipLaunchKernelGGL((gemm_kernel_big<AT, BT, EPI>), grid, dim3(512), BIG_LDS, s, p);
+  return check_launch("gemm_kernel_big");
 }
 
 static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x96 kernel
@@ -473,26 +550,33 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   return s;
 }
 
+static int g_big_auto = 0;       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
+static bool big_auto(const GemmParams& p, int splits) {
+  if (!g_big_auto) return false;
+  const long tiles = (long)(p.M / 256) * (p.N / 192) * splits;
+  return tiles >= 192 && (p.N >= 2304 || splits > 1);
+}
+
 template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
-  const bool v2_ok = (p.M % 256 == 0) && (p.N % 96 == 0);
+  const bool big_ok = (p.M % 256 == 0) && (p.N % 192 == 0);
   const bool v1_ok = (p.M % 128 == 0) && (p.N % 128 == 0);
-  // measured on MI355X (tools/bench_gemm.py, T = 8192): the 128x128 tile at 2 workgroups/CU wins or ties on every
-  // encoder shape (the second resident workgroup hides the other's prologue/epilogue; K is only 12-48 steps), so
-  // the 256x96 three-stage kernel is used only when asked for or when the shape does not fit 128x128.
-  if (v2_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && !v1_ok))) {
-    if (p.colsum_part || p.colsum_a) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: colsum outputs need the 128x128 tile (M, N multiples of 128)");
-    return launch_v2<AT, BT, EPI>(p, splits, s);
-  }
+  // big tile when asked for (variant 2) or, automatically, where it wins: wide outputs / weight gradients with enough
+  // tiles to fill the chip (heuristic from tools/bench_gemm.py)
+  bool use_big = big_ok && (g_gemm_variant == 2 || (g_gemm_variant == 0 && (!v1_ok || big_auto(p, splits))));
+  if (use_big) return launch_big<AT, BT, EPI>(p, splits, s);
   if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 16) {   // timing ablations / variants
+  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 19) {   // timing ablations / variants
     if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 1>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 2>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 3>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 14) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 4>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 15) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 5>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 16) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 6>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 17) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 7>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 18) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 8>), grid, dim3(256), 0, s, p);
+    if (g_gemm_variant == 19) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 9>), grid, dim3(256), 0, s, p);
     return check_launch("gemm_kernel<dbg>");
   }
   if (EPI != EPI_SLAB_F32 && p.splitk_ws) {
@@ -587,13 +671,14 @@ extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, in
 
 static int gemm_shape_ok(int M, int N, int K, int splits) {
   if (M <= 0 || N <= 0 || K <= 0 || splits <= 0) return 0;
-  if (!((M % 128 == 0 && N % 128 == 0) || (M % 256 == 0 && N % 96 == 0))) return 0;
+  if (!((M % 128 == 0 && N % 128 == 0) || (M % 256 == 0 && N % 192 == 0))) return 0;
   if (K % (64 * splits)) return 0;
   return 1;
 }
 
 extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
+  if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }         // automatic use of the 256x192 tile off / on
   g_gemm_variant = v;
   return CAREL_OK;
 }
@@ -603,7 +688,7 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   if (!a) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null args");
   const int splits = a->splits > 0 ? a->splits : 1;
   if (!gemm_shape_ok(a->M, a->N, a->K, splits))
-    return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: (M,N) must be multiples of (128,128) or (256,96) and K of 64*splits (M=%d N=%d K=%d splits=%d)",
+    return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: (M,N) must be multiples of (128,128) or (256,192) and K of 64*splits (M=%d N=%d K=%d splits=%d)",
                      a->M, a->N, a->K, splits);
   if (!a->A || !a->B) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null operand");
   if (((uintptr_t)a->A | (uintptr_t)a->B) & 15 || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3))

@@ -65,7 +65,7 @@ typedef struct carel_gemm_args {
   const void* A;        /* bf16 */
   const void* B;        /* bf16 */
   int64_t lda, ldb, ldc; /* leading dimensions in elements */
-  int32_t M, N, K;      /* (M,N) multiples of (128,128) or of (256,96); K multiple of 64*splits */
+  int32_t M, N, K;      /* (M,N) multiples of (128,128) or of (256,192); K multiple of 64*splits */
   int32_t form;         /* CAREL_GEMM_* */
   int32_t epilogue;     /* CAREL_EPI_*  */
   int32_t splits;       /* split-K factor (slab epilogue only), else 1 */
@@ -90,7 +90,8 @@ typedef struct carel_gemm_args {
 } carel_gemm_args;
 
 int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
-/* test / tuning hook: 0 = choose the tile automatically, 1 = force 128x128, 2 = force 256x96 */
+/* test / tuning hook: 0 = choose the tile automatically, 1 = force 128x128, 2 = force 256x192; 30/31 = automatic use of
+ * the 256x192 tile off/on; 20..23 XCD patch layouts; 11..18 timing ablations (wrong results) */
 int carel_gemm_set_variant(int32_t variant);
 /* Measurement aid (bench.py roofline leg): while enabled, every carel_gemm_bf16 launch is bracketed by
  * HIP events on its stream.  carel_profile_gemm_read() synchronises and returns the summed kernel time

@@ -14,7 +14,7 @@ for (M, N, K) in [(8192, 2304, 768), (8192, 768, 3072), (8192, 3072, 768), (8192
     bias = torch.zeros(N, device="cuda")
     res = {}
     for rnd_i in range(3):
-        for v, name in ((1, "full"), (14, "setprio"), (15, "prefetch-frags"), (16, "prefetch+setprio"), (11, "no-epilogue")):
+        for v, name in ((1, "full"), (19, "L2-hot-loads"), (12, "no-global-loads"), (13, "no-mfma"), (11, "no-epilogue")):
             L.check(lib.carel_gemm_set_variant(v))
             for _ in range(2): gemm(A, B, L.GEMM_NT, L.EPI_BIAS_BF16, M, N, K, out_bf16=out, bias=bias)
             torch.cuda.synchronize()
