@@ -618,6 +618,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 using namespace carel;
 
 // ---- optional per-launch HIP-event timing of the GEMM kernel (bench.py's roofline leg) -------------
+#include <algorithm>
 #include <vector>
 namespace {
 struct GemmProf {
@@ -625,11 +626,22 @@ struct GemmProf {
   std::vector<hipEvent_t> ev;      // start/stop pairs
   std::vector<double> flops;
   size_t used = 0;
+  std::vector<hipEvent_t> cal;     // 16 start/stop pairs around an empty kernel: the bracket's own cost
+  bool calibrated = false;
 } g_prof;
+__global__ void prof_empty_kernel() {}
 struct ProfScope {
   hipStream_t s; bool active;
   ProfScope(hipStream_t st, double fl) : s(st), active(false) {
     if (!g_prof.on || g_prof.used + 2 > g_prof.ev.size()) return;
+    if (!g_prof.calibrated) {        // once, on the stream being profiled: what an event pair around a kernel costs by itself
+      g_prof.calibrated = true;
+      for (size_t i = 0; i + 1 < g_prof.cal.size(); i += 2) {
+        (void)hipEventRecord(g_prof.cal[i], s);
+        hipLaunchKernelGGL(prof_empty_kernel, dim3(1), dim3(64), 0, s);
+        (void)hipEventRecord(g_prof.cal[i + 1], s);
+      }
+    }
     active = true;
     g_prof.flops.push_back(fl);
     (void)hipEventRecord(g_prof.ev[g_prof.used], s);
@@ -644,25 +656,40 @@ struct ProfScope {
 
 extern "C" int carel_profile_gemm(int enable, int max_launches) {
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-  g_prof.ev.clear(); g_prof.flops.clear(); g_prof.used = 0; g_prof.on = false;
+  for (hipEvent_t e : g_prof.cal) (void)hipEventDestroy(e);
+  g_prof.ev.clear(); g_prof.cal.clear(); g_prof.flops.clear(); g_prof.used = 0; g_prof.on = false; g_prof.calibrated = false;
   if (!enable) return CAREL_OK;
   if (max_launches < 1) return set_error(CAREL_ERR_ARG, "carel_profile_gemm: max_launches must be positive");
   g_prof.ev.resize((size_t)max_launches * 2);
+  g_prof.cal.resize(32);
   for (auto& e : g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm: hipEventCreate failed");
+  for (auto& e : g_prof.cal)
     if (hipEventCreate(&e) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm: hipEventCreate failed");
   g_prof.on = true;
   return CAREL_OK;
 }
 
-// Host-synchronising read-out: sums the recorded launches (ms, algorithmic flops 2*M*N*K, count).
+// Host-synchronising read-out: sums the recorded launches (ms, algorithmic flops 2*M*N*K, count).  The time an event
+// pair around an EMPTY kernel takes on the same stream (median of 16, measured at the first profiled launch) is
+// subtracted from every bracket, so the sum is kernel time as `rocprofv3 --kernel-trace` reports it.
 extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches) {
   if (!total_ms || !total_flops || !launches) return set_error(CAREL_ERR_ARG, "carel_profile_gemm_read: null output");
   double ms = 0.0, fl = 0.0;
+  double overhead = 0.0;
+  if (g_prof.calibrated) {
+    std::vector<float> c;
+    for (size_t i = 0; i + 1 < g_prof.cal.size(); i += 2) {
+      float t = 0.f;
+      if (hipEventSynchronize(g_prof.cal[i + 1]) == hipSuccess && hipEventElapsedTime(&t, g_prof.cal[i], g_prof.cal[i + 1]) == hipSuccess) c.push_back(t);
+    }
+    if (!c.empty()) { std::sort(c.begin(), c.end()); overhead = c[c.size() / 2]; }
+  }
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
     if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm_read: event sync failed");
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm_read: elapsed failed");
-    ms += t; fl += g_prof.flops[i / 2];
+    ms += (t > overhead ? t - overhead : 0.0); fl += g_prof.flops[i / 2];
   }
   *total_ms = ms; *total_flops = fl; *launches = (int64_t)(g_prof.used / 2);
   g_prof.used = 0; g_prof.flops.clear();
