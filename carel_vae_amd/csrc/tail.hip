@@ -8,6 +8,7 @@
 // (the loss is the root of the graph, so backward only rescales them by grad_output).
 #include "carel_hip_internal.h"
 #include "mmd_device.h"
+#include "hsic_device.h"
 
 namespace carel {
 
@@ -131,6 +132,8 @@ struct TailCore {
   const float* pair_w; const float* pair_b;    // [1, 2D], [1]
   const long* emo_labels; const float* cau_labels; const float* pair_labels;
   float w_mmd, w_emo, w_cau, w_pair, kl_w, ls;
+  int dis_mode;                 // 0: -w_mmd * RBF-MMD (ref :231-233); 1: +w_mmd * HSIC (drl_classifier_ec_hsic.py:214); 2: none
+  int emo_bce;                  // 1: one-logit sigmoid + BCE emotion head (ec_hsic/ec_vi scripts) instead of the softmax CE
   Dropout d_emo, d_cau, d_pair;                // element index b*D + k (pair: b*2D + k)
   float alpha, mmd_eps;
   const float* label_sum_override; float n_override;   // global-batch pos_weight (DP); null/0 = local
@@ -173,9 +176,13 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     Z[i * zs + k] = a.z_global ? a.z_global[(long)s * D2 + off + k] : zl[s * D2 + off + k];
   }
   __syncthreads();
-  MmdCfg mc; mc.n1 = nm; mc.n2 = nm; mc.d = D; mc.zs = zs; mc.n_alphas = 1; mc.alphas[0] = a.alpha; mc.eps = a.mmd_eps;
-  const float mmd = mmd_forward_block(mc, Z, nrm, red, nullptr);
-  {   // d(-w_mmd * mmd)/dz for the local rows: 8 threads per row
+  float mmd = 0.f;                     // value of the disentanglement statistic (terms[1])
+  float dis_term = 0.f;                // its contribution to the loss
+  if (a.dis_mode == 0) {
+    MmdCfg mc; mc.n1 = nm; mc.n2 = nm; mc.d = D; mc.zs = zs; mc.n_alphas = 1; mc.alphas[0] = a.alpha; mc.eps = a.mmd_eps;
+    mmd = mmd_forward_block(mc, Z, nrm, red, nullptr);
+    dis_term = -a.w_mmd * mmd;
+    // d(-w_mmd * mmd)/dz for the local rows: 8 threads per row
     const int rows = 2 * B;
     const int grp = t & 7;
     for (int base = 0; base < rows; base += blockDim.x / 8) {
@@ -195,6 +202,18 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
         if (live && grp == 0) { const int side = rloc >= B, bl = rloc - side * B; dzl[bl * D2 + side * D + k] += v; }
       }
     }
+  } else if (a.dis_mode == 1) {        // HSIC between the local emotion (rows 0..B) and cause (rows B..2B) samples
+    HsicCfg hc; hc.m = B; hc.d = D; hc.xs = zs; hc.inv_sx = 1.0f; hc.inv_sy = 1.0f;
+    float* rk = Z + 2 * nm * zs;       // [B] row sums of K, then [B] of L (extra LDS reserved by the host)
+    float* rl = rk + B;
+    mmd = hsic_forward_block(hc, Z, Z + B * zs, nrm, nrm + B, rk, rl, red);
+    dis_term = a.w_mmd * mmd;
+    const float tk = red[60], tl = red[61];
+    for (int i = t; i < B; i += blockDim.x) {
+      float gx[32], gy[32];
+      hsic_backward_row(hc, Z, Z + B * zs, nrm, nrm + B, rk, rl, tk, tl, i, a.w_mmd, gx, gy);
+      for (int k = 0; k < D; ++k) { dzl[i * D2 + k] += gx[k]; dzl[i * D2 + D + k] += gy[k]; }
+    }
   }
   __syncthreads();
   // ---- classifier heads: one thread per sample
@@ -207,19 +226,30 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   float xp = 0.f, tp = 0.f;
   if (t < B) {
     const int b = t;
-    // emotion: CE(W (z_e * m) + b, label)
-    float lg[8]; float mx = -INFINITY;
-    for (int c = 0; c < a.EC; ++c) {
-      float s = a.emo_b[c];
-      for (int k = 0; k < D; ++k) s = fmaf(a.emo_w[c * D + k], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), s);
-      lg[c] = s; mx = fmaxf(mx, s);
+    if (!a.emo_bce) {
+      // emotion: CE(W (z_e * m) + b, label)
+      float lg[8]; float mx = -INFINITY;
+      for (int c = 0; c < a.EC; ++c) {
+        float s = a.emo_b[c];
+        for (int k = 0; k < D; ++k) s = fmaf(a.emo_w[c * D + k], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), s);
+        lg[c] = s; mx = fmaxf(mx, s);
+      }
+      float se = 0.f;
+      for (int c = 0; c < a.EC; ++c) se += expf(lg[c] - mx);
+      const float lse = mx + logf(se);
+      long lab = a.emo_labels[b]; lab = lab < 0 ? 0 : (lab >= a.EC ? a.EC - 1 : lab);
+      l_emo = lse - lg[lab];
+      for (int c = 0; c < a.EC; ++c) elog[b * 8 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * (a.w_emo / B);
+    } else {
+      // emotion, 1-logit variant: BCE(sigmoid(w (z_e * m) + b), smoothed label)   (drl_classifier_ec_hsic.py:455-470)
+      float se = a.emo_b[0];
+      for (int k = 0; k < D; ++k) se = fmaf(a.emo_w[k], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), se);
+      const float pe = 1.0f / (1.0f + expf(-se));
+      const float te = (float)a.emo_labels[b] * (1.f - a.ls) + a.ls;
+      l_emo = -(te * fmaxf(logf(pe), -100.f) + (1.f - te) * fmaxf(logf(1.f - pe), -100.f));
+      const float gpe = (pe - te) / fmaxf((1.f - pe) * pe, 1e-12f);
+      elog[b * 8] = gpe * pe * (1.f - pe) * (a.w_emo / B);
     }
-    float se = 0.f;
-    for (int c = 0; c < a.EC; ++c) se += expf(lg[c] - mx);
-    const float lse = mx + logf(se);
-    long lab = a.emo_labels[b]; lab = lab < 0 ? 0 : (lab >= a.EC ? a.EC - 1 : lab);
-    l_emo = lse - lg[lab];
-    for (int c = 0; c < a.EC; ++c) elog[b * 8 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * (a.w_emo / B);
     // cause: BCE(sigmoid(w (z_c * m) + b), smoothed)
     float s = a.cau_b[0];
     for (int k = 0; k < D; ++k) s = fmaf(a.cau_w[k], zl[b * D2 + D + k] * dropout_mult(a.d_cau, b * D + k), s);
@@ -305,7 +335,7 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   for (int e = t; e < B * D2; e += blockDim.x) a.dz[e] = dzl[e];
   if (t == 0) {
     a.terms[1] = mmd; a.terms[2] = l_emo; a.terms[3] = l_cau; a.terms[4] = l_pair; a.terms[5] = kle; a.terms[6] = klc;
-    a.terms[0] = a.w_mmd * (-mmd) + a.w_emo * l_emo + a.w_cau * l_cau + a.w_pair * l_pair + kle + klc;
+    a.terms[0] = dis_term + a.w_emo * l_emo + a.w_cau * l_cau + a.w_pair * l_pair + kle + klc;
     a.pair_dead[0] = dead ? 1.f : 0.f;
   }
 }
@@ -606,6 +636,10 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   c.pair_w = (const float*)a->pair_w; c.pair_b = (const float*)a->pair_b;
   c.emo_labels = (const long*)a->emo_labels; c.cau_labels = (const float*)a->cau_labels; c.pair_labels = (const float*)a->pair_labels;
   c.w_mmd = a->w_mmd; c.w_emo = a->w_emo; c.w_cau = a->w_cau; c.w_pair = a->w_pair; c.kl_w = a->kl_weight; c.ls = a->label_smoothing;
+  c.dis_mode = a->dis_mode; c.emo_bce = a->emo_bce;
+  if (c.dis_mode < 0 || c.dis_mode > 2) return set_error(CAREL_ERR_ARG, "carel_tail_losses: dis_mode must be 0 (MMD), 1 (HSIC) or 2 (none)");
+  if (c.emo_bce && a->e_classes != 1) return set_error(CAREL_ERR_ARG, "carel_tail_losses: the BCE emotion head has exactly one logit");
+  if (c.dis_mode == 1 && a->z_global) return set_error(CAREL_ERR_ARG, "carel_tail_losses: HSIC has no global-batch mode");
   c.d_emo = make_dropout(a->drop_seed, 100u, a->drop_p, a->drop_row_offset * (uint32_t)D);
   c.d_cau = make_dropout(a->drop_seed, 101u, a->drop_p, a->drop_row_offset * (uint32_t)D);
   c.d_pair = make_dropout(a->drop_seed, 102u, a->drop_p, a->drop_row_offset * (uint32_t)(2 * D));
@@ -619,7 +653,7 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   c.d_emo_w = (float*)a->d_emo_w; c.d_emo_b = (float*)a->d_emo_b; c.d_cau_w = (float*)a->d_cau_w; c.d_cau_b = (float*)a->d_cau_b;
   c.d_pair_w = (float*)a->d_pair_w; c.d_pair_b = (float*)a->d_pair_b; c.pair_dead = w.pair_dead;
   const int nm = c.z_global ? c.n_global : B;
-  const size_t lds = sizeof(float) * (64 + 64 + (size_t)2 * B * 2 * D + (size_t)B * 8 + (size_t)B * 2 + ((2 * nm + 3) & ~3) + (size_t)2 * nm * (D | 1));
+  const size_t lds = sizeof(float) * (64 + 64 + (size_t)2 * B * 2 * D + (size_t)B * 8 + (size_t)B * 2 + ((2 * nm + 3) & ~3) + (size_t)2 * nm * (D | 1) + 2 * (size_t)B);
   if (lds > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the single-workgroup tail (%zu B LDS)", lds);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)tail_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

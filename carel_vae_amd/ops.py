@@ -125,6 +125,13 @@ def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight,
     a.kl_weight, a.label_smoothing = kl_weight, opt.label_smoothing
     a.drop_p, a.drop_seed, a.drop_row_offset = drop
     a.mmd_alpha, a.mmd_eps = 0.1, 1e-5
+    mode = getattr(opt, "disentangle", "mmd")
+    if mode not in ("mmd", "hsic", "none"):
+        raise L.CarelError("opt.disentangle must be 'mmd', 'hsic' or 'none'")
+    a.dis_mode = {"mmd": 0, "hsic": 1, "none": 2}[mode]
+    if mode == "hsic":
+        a.w_mmd = getattr(opt, "hsic_loss_weight", 1.0)      # the HSIC script adds the statistic unweighted
+    a.emo_bce = int(getattr(opt, "emotion_head", "ce") == "bce")
     a.global_label_sum = None if global_label_sum is None else global_label_sum.data_ptr()
     a.global_n, a.global_row_offset = global_n, global_row_offset
     a.z_global = None if z_global is None else z_global.data_ptr()

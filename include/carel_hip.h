@@ -281,6 +281,10 @@ typedef struct carel_tail_args {
   float w_mmd, w_emo, w_cau, w_pair, kl_weight, label_smoothing;
   float drop_p; uint32_t drop_seed, drop_row_offset;
   float mmd_alpha, mmd_eps;
+  int32_t dis_mode;                  /* disentanglement term: 0 = -w_mmd * RBF-MMD (ref :231-233, :256);
+                                        1 = +w_mmd * HSIC(z_e, z_c) (drl_classifier_ec_hsic.py:214, :253; w_mmd = 1 there); 2 = none */
+  int32_t emo_bce;                   /* 1 = one-logit sigmoid + BCE emotion head of the ablation scripts
+                                        (drl_classifier_ec_hsic.py:455-470; e_classes must be 1, labels 0/1), 0 = softmax CE (ref :461-476) */
   const void* global_label_sum;      /* f32 [1] or NULL */
   int32_t global_n, global_row_offset;
   const void* z_global;              /* f32 [global_n, 2*ec_dim] or NULL */

@@ -394,7 +394,7 @@ def bce_logits_posw(x, t, pw):
 def tail_forward(P, pooled, emo_labels, cau_labels, pair_labels, bow, iteration: int, opt: Opt,
                  eps_e: torch.Tensor, eps_c: torch.Tensor, train: bool = False, seed: Optional[int] = None,
                  row_offset: int = 0, global_label_sum: Optional[float] = None,
-                 global_n: Optional[int] = None, disentangle: str = "mmd") -> Dict[str, torch.Tensor]:
+                 global_n: Optional[int] = None, disentangle: str = "mmd", emotion_head: str = "ce") -> Dict[str, torch.Tensor]:
     """Everything after `pooler_output` (:209-261).  Returns every term separately plus `loss`.
 
     eps_e / eps_c: the two `[ec_dim]` noise vectors of `sample_prior` (:350; one vector shared by the
@@ -417,8 +417,13 @@ def tail_forward(P, pooled, emo_labels, cau_labels, pair_labels, bow, iteration:
 
     # emotion head :461-476
     logit_e = drop(z_e, SITE_TAIL_EMO, D) @ P["emotion_classifier.weight"].t() + P["emotion_classifier.bias"]
-    lse = torch.logsumexp(logit_e, dim=1)
-    emo = (lse - logit_e.gather(1, emo_labels.view(-1, 1)).squeeze(1)).mean()
+    ls = opt.label_smoothing
+    if emotion_head == "bce":          # 1-logit head of drl_classifier_ec_hsic.py:455-470 / ec_vi
+        pe = torch.sigmoid(logit_e)
+        emo = bce_prob(pe, emo_labels.view(-1, 1).to(torch.float32) * (1 - ls) + ls / 1).mean()
+    else:
+        lse = torch.logsumexp(logit_e, dim=1)
+        emo = (lse - logit_e.gather(1, emo_labels.view(-1, 1)).squeeze(1)).mean()
     # cause head :478-492
     ls = opt.label_smoothing
     pc = torch.sigmoid(drop(z_c, SITE_TAIL_CAU, D) @ P["cause_classifier.weight"].t() + P["cause_classifier.bias"])

@@ -45,7 +45,7 @@ def hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, drop, **kw):
     dev = "cuda"
     W = {k: v.to(dev) for k, v in P.items()}
     G = {k: torch.full_like(v, float("nan")) for k, v in W.items()}
-    buf = ops.TailBuffers(B, S, 24, 6, V, dev)
+    buf = ops.TailBuffers(B, S, 24, opt.e_num_class, V, dev)
     labels = dict(emo=batch["emo_labels"].to(dev).view(-1).contiguous(), cau=batch["cau_labels"].to(dev).view(-1).contiguous(),
                   pair=batch["labels"].to(dev).view(-1).contiguous(), bow=batch["bow_reps"].to(dev).contiguous())
     xl = x_last.to(dev)
@@ -130,3 +130,30 @@ def test_pair_probs_matches_oracle():
     z = torch.cat((lat[:, :24] + eps_e * lat[:, 24:48].exp(), lat[:, 48:72] + eps_c * lat[:, 72:].exp()), dim=1)
     ref = torch.sigmoid(z @ P["pair_classifier.weight"].t() + P["pair_classifier.bias"]).squeeze(1)
     close(prob, ref, 1e-5, 1e-6, "pair prob")
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_hsic_variant_of_the_tail(train):
+    """Ablation head (config 5): +HSIC(z_e, z_c) instead of -30*MMD and the one-logit BCE emotion head of
+    drl_classifier_ec_hsic.py (:214, :253, :455-470), vs the oracle (whose HSIC is pinned to the reference's values)."""
+    B, S, V, it, seed = 32, 2, 200, 5, 17
+    cfg = O.EncoderConfig(layers=0, vocab_size=50)
+    opt = O.Opt(pair_bow_dim=V, e_num_class=1)
+    opt.disentangle, opt.emotion_head = "hsic", "bce"
+    P = {k: v for k, v in O.init_params(cfg, opt, seed=3).items() if k in TAIL_KEYS}
+    g = torch.Generator().manual_seed(4)
+    P["encoder.pooler.dense.weight"] = torch.randn((768, 768), generator=g) * 0.05
+    x_last = torch.randn((B * S, 768), generator=g)
+    batch = O.synthetic_batch(B, 8, O.EncoderConfig(layers=1, vocab_size=50), V, seed=6)
+    batch["emo_labels"] = (batch["emo_labels"] > 2).to(torch.int64)
+    eps_e, eps_c = torch.randn(24, generator=g), torch.randn(24, generator=g)
+    out, pooled, grads, dx = oracle_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, it, train, seed, disentangle="hsic", emotion_head="bce")
+    buf, G = hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, (opt.dropout if train else 0.0, seed, 0))
+    t = buf.terms.cpu().numpy()
+    for i, k in ((1, "mmd"), (2, "emo"), (3, "cau"), (4, "pair"), (7, "rec"), (8, "loss")):
+        np.testing.assert_allclose(t[i], float(out[k]), rtol=2e-4, atol=1e-5, err_msg=k)
+    for k in TAIL_KEYS:
+        ref = grads[k] if grads[k] is not None else torch.zeros_like(P[k])
+        scale = float(ref.abs().max()) + 1e-12
+        close(G[k], ref, 5e-4, 5e-5 * scale + 1e-9, k)
+    close(buf.dx_last, dx, 5e-4, 5e-5 * float(dx.abs().max()), "dx_last")
