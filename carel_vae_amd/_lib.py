@@ -119,6 +119,11 @@ class HsicArgs(C.Structure):
                 ("gx", C.c_void_p), ("gy", C.c_void_p)]
 
 
+class ViArgs(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("batch", C.c_int32), ("ec_dim", C.c_int32), ("net", C.c_void_p * 8), ("perm", C.c_void_p),
+                ("loss_out", C.c_void_p), ("d_net", C.c_void_p * 8), ("dz", C.c_void_p)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
 
@@ -154,6 +159,9 @@ SIGNATURES = {
     "carel_tail_latents": (C.c_int, [C.POINTER(TailArgs), C.c_void_p]),
     "carel_tail_losses": (C.c_int, [C.POINTER(TailArgs), C.c_void_p]),
     "carel_tail_backward": (C.c_int, [C.POINTER(TailArgs), C.c_void_p, C.c_void_p]),
+    "carel_tail_backward_dz": (C.c_int, [C.POINTER(TailArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_vi_aprx": (C.c_int, [C.POINTER(ViArgs), C.c_void_p]),
+    "carel_vi_upper": (C.c_int, [C.POINTER(ViArgs), C.c_void_p]),
     "carel_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "carel_tail_pair_dead_offset": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "carel_pair_probs": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -719,6 +719,24 @@ extern "C" int64_t carel_tail_pair_dead_offset(int32_t batch, int32_t ec_dim, in
 }
 
 extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_out_dev, void* stream_) {
+  return carel_tail_backward_dz(a, grad_out_dev, nullptr, stream_);
+}
+
+// dlat += [dz_e, dz_e*eps_e*exp(lv_e), dz_c, dz_c*eps_c*exp(lv_c)] for an extra gradient dz on the sampled embeddings
+__global__ __launch_bounds__(256) void tail_add_dz_kernel(const float* __restrict__ dz, const float* __restrict__ lat,
+                                                          const float* __restrict__ eps_e, const float* __restrict__ eps_c, int B, int D,
+                                                          float* __restrict__ dlat) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * 2 * D) return;
+  const int b = e / (2 * D), k = e - b * 2 * D, side = k >= D, kk = k - side * D;
+  const float g = dz[e];
+  const float ep = side ? eps_c[kk] : eps_e[kk];
+  const float lv = lat[(long)b * 4 * D + (2 * side + 1) * D + kk];
+  dlat[(long)b * 4 * D + 2 * side * D + kk] += g;
+  dlat[(long)b * 4 * D + (2 * side + 1) * D + kk] += g * ep * expf(lv);
+}
+
+extern "C" int carel_tail_backward_dz(const carel_tail_args* a, const void* grad_out_dev, const void* dz_extra, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = tail_check(a, "carel_tail_backward");
   if (rc) return rc;
@@ -727,6 +745,11 @@ extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_ou
   TailWork w = carve((float*)a->work, B, D, a->bow_dim);
   if (grad_out_dev) {
     hipLaunchKernelGGL(scale_inplace_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, w.dlat, (long)B * N, (const float*)grad_out_dev);
+  }
+  if (dz_extra) {
+    if (!a->lat || !a->eps_e || !a->eps_c) return set_error(CAREL_ERR_ARG, "carel_tail_backward_dz: lat / eps needed");
+    hipLaunchKernelGGL(tail_add_dz_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, stream, (const float*)dz_extra, (const float*)a->lat,
+                       (const float*)a->eps_e, (const float*)a->eps_c, B, D, w.dlat);
   }
   PtrSet4 hp; OutSet4 ho;
   for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = nullptr; ho.w[i] = (float*)a->d_head_w[i]; ho.b[i] = (float*)a->d_head_b[i]; }

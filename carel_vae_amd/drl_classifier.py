@@ -22,7 +22,7 @@ H, I_FF, NH = 768, 3072, 12
 DEFAULT_OPT = dict(language="zh", max_len=128, e_num_class=6, c_num_class=1, pair_num_class=1, ec_dim=24, bert_dim=768,
                    kl_ann_iterations=20000, epochs=20, batch_size=64, ec_kl_lambda=0.03, label_smoothing=0.1,
                    mmd_loss_weight=30.0, emo_mul_loss_weight=10.0, cau_mul_loss_weight=10.0, pair_mul_loss_weight=30.0,
-                   dropout=0.5, epsilon=1e-8, vae_lr=1e-5, pair_bow_dim=23771, self_iteration=50, self_epochs=10,
+                   dropout=0.5, epsilon=1e-8, vae_lr=1e-5, aprx_lr=0.003, pair_bow_dim=23771, self_iteration=50, self_epochs=10,
                    self_strategy="random", best_model_path="ECPE_model/best_cause_pair_model", model_id="carel")
 
 
@@ -154,13 +154,62 @@ class _TrainLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, call):
         ctx.model, ctx.call = model, call
+        ctx.set_materialize_grads(False)
         model._run_forward(call, training=True)
-        return call.buf.terms[8].clone()
+        # second output: the sampled embeddings [z_e | z_c]; further loss terms built on them (the CLUB bound of the VI
+        # ablation, or any torch expression) send their gradient back through `grad_z`
+        return call.buf.terms[8].clone(), call.buf.z.clone()
 
     @staticmethod
-    def backward(ctx, grad_out):
-        ctx.model._run_backward(ctx.call, grad_out)
+    def backward(ctx, grad_out, grad_z):
+        if grad_out is None:
+            grad_out = ctx.call.buf.terms.new_zeros(())
+        ctx.model._run_backward(ctx.call, grad_out, grad_z)
         return None, None, None
+
+
+class _AprxLoss(torch.autograd.Function):
+    """`get_ec_aprx_loss` of drl_classifier_ec_vi.py:422-427: loss of the approximation network p(e|c) on the sampled
+    embeddings; its backward fills ONLY the eight ec_mu / ec_log_var gradients.  (In the reference the term also sends a
+    gradient into the encoder through e_embedding, but `vae_and_cls_opt.zero_grad()` (:771) discards it before use.)"""
+
+    @staticmethod
+    def forward(ctx, anchor, model, z):
+        ctx.model = model
+        loss, ctx.grads = ops.vi_aprx(z, model._aprx_weights())
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.model
+        for k, gk in zip(m._aprx_names, ctx.grads):
+            view = m._grad_view(k)
+            p = m._named[k]
+            if p.grad is None:
+                view.copy_(gk * g)
+            else:
+                view.add_(gk * g)
+            p.grad = view
+        return None, None, None
+
+
+class _UpperLoss(torch.autograd.Function):
+    """`get_ec_upper_loss` (:429-440): CLUB upper bound of I(e; c) with the negatives e[randperm]."""
+
+    @staticmethod
+    def forward(ctx, e, c, model, perm):
+        D = e.shape[1]
+        z = torch.cat((e, c), dim=1).float().contiguous()
+        loss, dz = ops.vi_upper(z, model._aprx_weights(), perm)
+        ctx.save_for_backward(dz)
+        ctx.D = D
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dz, = ctx.saved_tensors
+        dz = dz * g
+        return dz[:, :ctx.D], dz[:, ctx.D:], None, None
 
 
 class _MMDFn(torch.autograd.Function):
@@ -266,6 +315,12 @@ class DrlClassifier(nn.Module):
         self.pair_classifier = _Holder((opt.pair_num_class, opt.ec_dim * 2))
         self.decoder = _Holder((opt.pair_bow_dim, opt.ec_dim * 2))
         self.dropout = nn.Dropout(opt.dropout)       # probability holder; the mask is drawn in-kernel
+        self._aprx_names = []
+        if getattr(opt, "disentangle", "mmd") == "vi":      # approximation network p(e|c), drl_classifier_ec_vi.py:156-163
+            D = opt.ec_dim
+            self.ec_mu = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D))
+            self.ec_log_var = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D), nn.Tanh())
+            self._aprx_names = [f"{n}.{i}.{t}" for n in ("ec_mu", "ec_log_var") for i in (0, 2) for t in ("weight", "bias")]
         gen = None
         if seed is not None:
             gen = torch.Generator().manual_seed(seed)
@@ -304,6 +359,7 @@ class DrlClassifier(nn.Module):
         n_opt_names = len(order)
         order += ["emotion_mu.weight", "emotion_mu.bias", "emotion_log_var.weight", "emotion_log_var.bias",
                   "cause_mu.weight", "cause_mu.bias", "cause_log_var.weight", "cause_log_var.bias"]
+        order += self._aprx_names            # own optimiser (ref ec_vi :873), fp32 only
         assert set(order) == set(named), "parameter inventory mismatch"
         return order, n_opt_names, named
 
@@ -350,10 +406,34 @@ class DrlClassifier(nn.Module):
 
     def get_params(self):
         """Reference order (:292-295): encoder, decoder, emotion / cause / pair classifiers.  The four latent
-        heads are deliberately absent (they are never updated in the reference)."""
-        return (list(self.encoder.parameters()) + list(self.decoder.parameters()) +
-                list(self.emotion_classifier.parameters()) + list(self.cause_classifier.parameters()) +
-                list(self.pair_classifier.parameters()))
+        heads are deliberately absent (they are never updated in the reference).
+        With opt.disentangle == "vi": the pair (ec_aprx_params, other_params) of drl_classifier_ec_vi.py:291-302."""
+        other = (list(self.encoder.parameters()) + list(self.decoder.parameters()) +
+                 list(self.emotion_classifier.parameters()) + list(self.cause_classifier.parameters()) +
+                 list(self.pair_classifier.parameters()))
+        if self._aprx_names:
+            return list(self.ec_mu.parameters()) + list(self.ec_log_var.parameters()), other
+        return other
+
+    def _aprx_weights(self):
+        if not self._aprx_names:
+            raise L.CarelError("the approximation network exists only with opt.disentangle == 'vi'")
+        return [self._named[k].data for k in self._aprx_names]
+
+    def get_ec_aprx_loss(self, e_embedding, c_embedding):
+        """drl_classifier_ec_vi.py:422-427 (the cause embedding is detached there; only the network gets a gradient)."""
+        z = torch.cat((e_embedding.detach(), c_embedding.detach()), dim=1).float().contiguous()
+        if not torch.is_grad_enabled():
+            return ops.vi_aprx(z, self._aprx_weights())[0].reshape(())
+        return _AprxLoss.apply(self._flat.new_zeros((), requires_grad=True), self, z)
+
+    def get_ec_upper_loss(self, e_embedding, c_embedding, random_index=None):
+        """drl_classifier_ec_vi.py:429-440.  random_index (extension): the permutation to use instead of a fresh
+        torch.randperm(batch) (drawn on the host generator like the reference)."""
+        n = e_embedding.shape[0]
+        perm = torch.randperm(n) if random_index is None else random_index
+        perm = perm.to(e_embedding.device, torch.int32).contiguous()
+        return _UpperLoss.apply(e_embedding, c_embedding, self, perm)
 
     # ------------------------------------------------------------------ helpers
     def _require_cuda(self):
@@ -361,8 +441,12 @@ class DrlClassifier(nn.Module):
             raise L.CarelError("DrlClassifier parameters are on %s; call .to('cuda') first -- the HIP kernels are the only "
                                "implementation of the step path (no CPU fallback)." % (None if self._flat is None else self._flat.device))
 
+    def _versions(self):
+        aprx = set(self._aprx_names)         # fp32 only: an update of the approximation net never stales the bf16 shadow
+        return sum(p._version for k, p in self._named.items() if k not in aprx)
+
     def _refresh_shadow(self):
-        vers = sum(p._version for p in self._named.values())
+        vers = self._versions()
         if self._shadow_versions != vers:
             L.check(L.load().carel_cast_f32_to_bf16(self._flat.data_ptr(), self._shadow.data_ptr(), self._flat.numel(),
                                                     L.current_stream()), "carel_cast_f32_to_bf16")
@@ -370,7 +454,7 @@ class DrlClassifier(nn.Module):
 
     def mark_shadow_fresh(self):
         """Called by the fused optimiser, which rewrites the bf16 shadow itself."""
-        self._shadow_versions = sum(p._version for p in self._named.values())
+        self._shadow_versions = self._versions()
 
     def _w(self, key, bf16=False):
         off = self._offs[key]
@@ -598,7 +682,7 @@ class DrlClassifier(nn.Module):
         c.ea, c.ta, c.ws = ea, ta, ws
         c.keep = (W, G, xl)
 
-    def _run_backward(self, c, grad_out):
+    def _run_backward(self, c, grad_out, grad_z=None):
         lib = L.load()
         st = L.current_stream()
         named = self._named
@@ -608,7 +692,7 @@ class DrlClassifier(nn.Module):
         go = grad_out.to(torch.float32).reshape(1).contiguous()      # device scalar, never read on the host
         ea = c.ea
         ea.dx = c.buf.dx_last.data_ptr()          # [Bp*S (or packed n_tokens), 768]; cleared + CLS rows written by the tail backward
-        ops.tail_backward(c.ta, go)
+        ops.tail_backward(c.ta, go, None if grad_z is None else grad_z.to(torch.float32).contiguous())
         # classifier / decoder gradients were produced for grad_output = 1: one contiguous range of the flat buffer
         lo = self._offs["decoder.weight"]
         ops.scale_(self._flat_grad[lo:self._pair_hi], go)
@@ -628,8 +712,10 @@ class DrlClassifier(nn.Module):
     def _bind_grads(self):
         if self._grad_views is None:
             self._grad_views = {k: self._grad_view(k) for k in self._order}
+        aprx = self._aprx_names
         for k, p in self._named.items():
-            p.grad = self._grad_views[k]
+            if k not in aprx:               # the approximation net's gradients belong to _AprxLoss.backward
+                p.grad = self._grad_views[k]
 
     # ------------------------------------------------------------------ public API (reference surface)
     def forward(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration,
@@ -640,11 +726,29 @@ class DrlClassifier(nn.Module):
         c = self._make_call(input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration,
                             training=torch.is_grad_enabled(), seq_lengths=seq_lengths)
         self._last_call = c
+        vi = bool(self._aprx_names)
+        D = self.opt.ec_dim
         if torch.is_grad_enabled():
             anchor = self._flat.new_zeros((), requires_grad=True)
-            return _TrainLoss.apply(anchor, self, c)
+            loss, z = _TrainLoss.apply(anchor, self, c)
+            c.z_out = z
+            if vi:          # drl_classifier_ec_vi.py:263: (sampled_emotion_emb, sampled_cause_emb, ec_aprx_loss, vae_and_classifier_loss)
+                z_e, z_c = z[:, :D], z[:, D:]
+                return z_e, z_c, self.get_ec_aprx_loss(z_e, z_c), loss
+            return loss
         self._run_forward(c, training=False)
-        return c.buf.terms[8].clone()
+        loss = c.buf.terms[8].clone()
+        if vi:
+            z = c.buf.z.clone()
+            return z[:, :D], z[:, D:], self.get_ec_aprx_loss(z[:, :D], z[:, D:]), loss
+        return loss
+
+    def sampled_embeddings(self):
+        """(z_e, z_c) of the most recent training forward, connected to autograd: any extra loss term built on them
+        back-propagates into the encoder together with the returned loss (extension; the VI variant returns them itself)."""
+        z = self._last_call.z_out
+        D = self.opt.ec_dim
+        return z[:, :D], z[:, D:]
 
     def forward_terms(self, *args, **kw):
         """Added introspection entry point: the loss plus every term and the latent means (no autograd)."""

@@ -126,9 +126,9 @@ def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight,
     a.drop_p, a.drop_seed, a.drop_row_offset = drop
     a.mmd_alpha, a.mmd_eps = 0.1, 1e-5
     mode = getattr(opt, "disentangle", "mmd")
-    if mode not in ("mmd", "hsic", "none"):
-        raise L.CarelError("opt.disentangle must be 'mmd', 'hsic' or 'none'")
-    a.dis_mode = {"mmd": 0, "hsic": 1, "none": 2}[mode]
+    if mode not in ("mmd", "hsic", "none", "vi"):
+        raise L.CarelError("opt.disentangle must be 'mmd', 'hsic', 'vi' or 'none'")
+    a.dis_mode = {"mmd": 0, "hsic": 1, "none": 2, "vi": 2}[mode]      # vi: the CLUB term is added outside the tail (vi_upper)
     if mode == "hsic":
         a.w_mmd = getattr(opt, "hsic_loss_weight", 1.0)      # the HSIC script adds the statistic unweighted
     a.emo_bce = int(getattr(opt, "emotion_head", "ce") == "bce")
@@ -162,10 +162,56 @@ def tail_losses(a):
     L.check(L.load().carel_tail_losses(C.byref(a), L.current_stream()), "carel_tail_losses")
 
 
-def tail_backward(a, grad_out=None):
-    """grad_out: device f32 scalar tensor (upstream gradient of the loss) or None for 1."""
-    L.check(L.load().carel_tail_backward(C.byref(a), None if grad_out is None else grad_out.data_ptr(), L.current_stream()),
-            "carel_tail_backward")
+def tail_backward(a, grad_out=None, dz_extra=None):
+    """grad_out: device f32 scalar tensor (upstream gradient of the loss) or None for 1.
+    dz_extra: optional f32 [B, 2*ec_dim] additional gradient on the sampled embeddings (not scaled by grad_out)."""
+    if dz_extra is not None:
+        _chk_cuda(dz_extra)
+        if dz_extra.dtype != torch.float32 or not dz_extra.is_contiguous() or dz_extra.numel() != a.batch * 2 * a.ec_dim:
+            raise L.CarelError("dz_extra must be a contiguous f32 [batch, 2*ec_dim] tensor")
+    L.check(L.load().carel_tail_backward_dz(C.byref(a), None if grad_out is None else grad_out.data_ptr(),
+                                            None if dz_extra is None else dz_extra.data_ptr(), L.current_stream()),
+            "carel_tail_backward_dz")
+
+
+def _vi_args(z, net):
+    _chk_cuda(z, *net)
+    if z.dtype != torch.float32 or not z.is_contiguous() or z.dim() != 2 or z.shape[1] % 2:
+        raise L.CarelError("z must be a contiguous f32 [batch, 2*ec_dim] tensor")
+    D = z.shape[1] // 2
+    shapes = [(D, D), (D,), (D, D), (D,)] * 2
+    if len(net) != 8 or any(tuple(w.shape) != sh or w.dtype != torch.float32 or not w.is_contiguous() for w, sh in zip(net, shapes)):
+        raise L.CarelError("the approximation network is 8 contiguous f32 tensors: (w1 [D,D], b1 [D], w2 [D,D], b2 [D]) x (mu, log_var)")
+    a = L.ViArgs()
+    a.z, a.batch, a.ec_dim = z.data_ptr(), z.shape[0], D
+    for i, w in enumerate(net):
+        a.net[i] = w.data_ptr()
+    return a
+
+
+def vi_aprx(z, net):
+    """-> (loss [1], [8 gradients of the approximation network]); drl_classifier_ec_vi.py:422-427."""
+    a = _vi_args(z, net)
+    loss = torch.empty(1, device=z.device, dtype=torch.float32)
+    grads = [torch.empty_like(w) for w in net]
+    a.loss_out = loss.data_ptr()
+    for i, g in enumerate(grads):
+        a.d_net[i] = g.data_ptr()
+    L.check(L.load().carel_vi_aprx(C.byref(a), L.current_stream()), "carel_vi_aprx")
+    return loss, grads
+
+
+def vi_upper(z, net, perm):
+    """-> (CLUB upper bound [1], d bound / d z [B, 2D]); drl_classifier_ec_vi.py:429-440; perm: int32 [B] device tensor."""
+    a = _vi_args(z, net)
+    _chk_cuda(perm)
+    if perm.dtype != torch.int32 or perm.numel() != z.shape[0]:
+        raise L.CarelError("perm must be an int32 [batch] tensor")
+    loss = torch.empty(1, device=z.device, dtype=torch.float32)
+    dz = torch.empty_like(z)
+    a.perm, a.loss_out, a.dz = perm.data_ptr(), loss.data_ptr(), dz.data_ptr()
+    L.check(L.load().carel_vi_upper(C.byref(a), L.current_stream()), "carel_vi_upper")
+    return loss, dz
 
 
 def scale_(x, scale_dev):

@@ -1,6 +1,7 @@
 """The reference's training driver around the hot path: `train`, `generate_self_train_data`, `save_ckp`,
 `load_ckp` (drl_classifier_ec_mmd_final_mul.py :603-628, :734-799, :802-922), same signatures and control
-flow; `opt` is an explicit keyword instead of a module global.  The step body (:823-845) is unchanged: the
+flow; `opt` is an explicit keyword instead of a module global.  With two optimisers it runs the VI ablation's
+two-phase step (drl_classifier_ec_vi.py :723-790).  The step body (:823-845) is unchanged: the
 model/optimiser objects it calls are carel_vae_amd.DrlClassifier and FusedAdam (or any torch optimiser).
 """
 import os
@@ -86,7 +87,8 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
     """ref :802-922.  One epoch = every batch through forward / zero_grad / backward / step (:823-845), then one
     evaluation pass with `get_pair_preds`, checkpointing the best F1."""
     opt = opt if opt is not None else model.opt
-    vae_and_cls_opt = optimizers[0]
+    vi = len(optimizers) == 2       # VI ablation (drl_classifier_ec_vi.py:723-725): [ec_aprx_opt, vae_and_cls_opt]
+    ec_aprx_opt, vae_and_cls_opt = optimizers if vi else (None, optimizers[0])
     max_p = max_r = max_f1 = 0.0
     self_p = self_r = self_f1 = 0.0
     if self_train:
@@ -106,11 +108,20 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
             emo = batch["emo_labels"].to(device, dtype=torch.long)
             cau = batch["cau_labels"].to(device, dtype=torch.float)
             bow = batch["bow_reps"].to(device, dtype=torch.float)
-            loss = model(ids, att, tt, emo, cau, labels, bow, iteration)
+            if vi:                  # two-phase step, drl_classifier_ec_vi.py:754-774
+                e_embedding, c_embedding, ec_aprx_loss, loss = model(ids, att, tt, emo, cau, labels, bow, iteration)
+                ec_aprx_opt.zero_grad()
+                ec_aprx_loss.backward(retain_graph=True)
+                ec_aprx_opt.step()
+                Rj_loss = model.get_ec_upper_loss(e_embedding, c_embedding)
+                beta = min(1, (epoch - 1) * 0.1)
+                loss += beta * Rj_loss
+            else:
+                loss = model(ids, att, tt, emo, cau, labels, bow, iteration)
             vae_and_cls_opt.zero_grad()
             loss.backward()
             vae_and_cls_opt.step()
-            running_loss += loss.item()
+            running_loss += loss.item() + (ec_aprx_loss.item() if vi else 0.0)
             if iteration % 10 == 9:
                 log("[%d, %5d] training loss: %.4f" % (epoch, iteration + 1, running_loss / 10))
                 running_loss = 0.0

@@ -308,6 +308,9 @@ int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_d
 int carel_tail_latents(const carel_tail_args* args, void* stream);
 int carel_tail_losses(const carel_tail_args* args, void* stream);
 int carel_tail_backward(const carel_tail_args* args, const void* grad_out_dev_f32, void* stream);
+/* same, plus an additional upstream gradient on the sampled embeddings z (f32 [B, 2*ec_dim], NOT scaled by grad_out):
+ * lets further loss terms defined on z_e / z_c (e.g. the CLUB bound of the VI ablation) reach the encoder */
+int carel_tail_backward_dz(const carel_tail_args* args, const void* grad_out_dev_f32, const void* dz_extra_f32, void* stream);
 /* x[i] *= *scale_dev  (device scalar; used to apply loss.backward()'s grad_output without a host sync) */
 int carel_scale_f32(void* x_f32, int64_t n, const void* scale_dev_f32, void* stream);
 /* offset (in floats, inside `work`) of the flag carel_tail_losses sets to 1.0 when the pair loss was
@@ -374,6 +377,26 @@ typedef struct carel_hsic_args {
 } carel_hsic_args;
 int carel_hsic_fwd(const carel_hsic_args* args, void* stream);
 int carel_hsic_bwd(const carel_hsic_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * VI / CLUB head (ablation script drl_classifier_ec_vi.py).  z = [e | c] f32 [B, 2*ec_dim] are the sampled emotion /
+ * cause embeddings; net[8] = approximation network p(e|c): ec_mu.0.weight, ec_mu.0.bias, ec_mu.2.weight, ec_mu.2.bias,
+ * ec_log_var.0.weight, .0.bias, .2.weight, .2.bias (:156-163).
+ *   carel_vi_aprx : get_ec_aprx_loss (:422-427) on c.detach() -> loss_out and d_net[8] (gradients of the net only)
+ *   carel_vi_upper: get_ec_upper_loss (:429-440) with negatives e[perm] -> loss_out and dz = d loss / d z [B, 2*ec_dim]
+ *                   (feed it to carel_tail_backward's dz_extra, scaled by beta)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_vi_args {
+  const void* z;
+  int32_t batch, ec_dim;             /* ec_dim <= 32 */
+  const void* net[8];
+  const void* perm;                  /* int32 [B], upper only */
+  void* loss_out;                    /* f32 [1] */
+  void* d_net[8];                    /* aprx only */
+  void* dz;                          /* upper only, f32 [B, 2*ec_dim] (overwritten) */
+} carel_vi_args;
+int carel_vi_aprx(const carel_vi_args* args, void* stream);
+int carel_vi_upper(const carel_vi_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Hardware-layout self test (MFMA fragment maps, transposed LDS reads, LDS-DMA staging) used by

@@ -76,6 +76,7 @@ class Opt:
     dropout: float = 0.5
     epsilon: float = 1e-8
     vae_lr: float = 1e-5
+    aprx_lr: float = 0.003          # drl_classifier_ec_vi.py:51 (VI ablation only)
     pair_bow_dim: int = 23771
     self_iteration: int = 50
     self_epochs: int = 10
@@ -484,6 +485,67 @@ def pair_preds(P, ids, att, tt, cfg, opt, eps_e, eps_c, quant: Quant = None):
     z = torch.cat((mu_e + eps_e * lv_e.exp(), mu_c + eps_c * lv_c.exp()), dim=1)
     prob = torch.sigmoid(z @ P["pair_classifier.weight"].t() + P["pair_classifier.bias"])
     return prob
+
+
+# --------------------------------------------------------------------------------------------
+# VI / CLUB head of the ablation script drl_classifier_ec_vi.py (approximation network p(e|c))
+# --------------------------------------------------------------------------------------------
+
+VI_KEYS = tuple(f"{n}.{i}.{t}" for n in ("ec_mu", "ec_log_var") for i in (0, 2) for t in ("weight", "bias"))
+
+
+def init_vi_params(opt: Opt, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """nn.Linear-style uniform(+-1/sqrt(fan_in)) weights for ec_mu / ec_log_var (ec_vi :156-163), RandomState stream."""
+    rs = np.random.RandomState(seed)
+    D = opt.ec_dim
+    bound = 1.0 / math.sqrt(D)
+    return {k: torch.from_numpy(rs.uniform(-bound, bound, size=(D, D) if k.endswith("weight") else (D,)).astype(np.float32))
+            for k in VI_KEYS}
+
+
+def vi_net(P, c):
+    """get_ec_emb (ec_vi :343-348): mu = Linear-ReLU-Linear, log_var = tanh(Linear-ReLU-Linear)."""
+    def mlp(n):
+        h = torch.relu(c @ P[n + ".0.weight"].t() + P[n + ".0.bias"])
+        return h @ P[n + ".2.weight"].t() + P[n + ".2.bias"]
+    return mlp("ec_mu"), torch.tanh(mlp("ec_log_var"))
+
+
+def vi_aprx_loss(P, z_e, z_c):
+    """get_ec_aprx_loss (ec_vi :422-427); the cause embedding is detached."""
+    mu, lv = vi_net(P, z_c.detach())
+    return -((-(mu - z_e) ** 2 / lv.exp() - lv).sum(dim=1).mean(dim=0))
+
+
+def vi_upper_loss(P, z_e, z_c, perm):
+    """get_ec_upper_loss (ec_vi :429-440) with random_index = perm."""
+    mu, lv = vi_net(P, z_c)
+    positive = -(mu - z_e) ** 2 / lv.exp()
+    negative = -(mu - z_e[perm.long()]) ** 2 / lv.exp()
+    return (positive.sum(dim=-1) - negative.sum(dim=-1)).mean() / 2.
+
+
+def vi_train_step(P, batch, iteration, epoch, cfg, opt, eps_e, eps_c, perm, st_vae: "AdamState", st_aprx: "AdamState",
+                  quant: Quant = None, train=False, seed=None):
+    """The two-phase step of ec_vi :754-774: Adam(aprx_lr) on the approximation net with the aprx loss, then
+    vae loss + beta * CLUB bound (with the UPDATED net) -> Adam(vae_lr) on get_params()[1].
+    Returns (P, dict(aprx=, vae=, upper=, total=))."""
+    leaf = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    out = forward_terms(leaf, batch, iteration, cfg, opt, eps_e, eps_c, train=train, seed=seed, quant=quant,
+                        disentangle="none", emotion_head="bce")
+    aprx = vi_aprx_loss(leaf, out["z_e"], out["z_c"])
+    g_aprx = torch.autograd.grad(aprx, [leaf[k] for k in VI_KEYS], retain_graph=True)
+    P = dict(P)
+    P = adam_step(P, dict(zip(VI_KEYS, g_aprx)), list(VI_KEYS), st_aprx, lr=opt.aprx_lr)
+    net = {k: P[k] for k in VI_KEYS}
+    upper = vi_upper_loss(net, out["z_e"], out["z_c"], perm)
+    beta = min(1.0, (epoch - 1) * 0.1)
+    total = out["loss"] + beta * upper
+    keys = optimised_keys(cfg, opt)
+    gs = torch.autograd.grad(total, [leaf[k] for k in keys], allow_unused=True)
+    P = adam_step(P, dict(zip(keys, gs)), keys, st_vae, lr=opt.vae_lr)
+    return P, dict(aprx=aprx.detach(), vae=out["loss"].detach(), upper=upper.detach(), total=total.detach(),
+                   z_e=out["z_e"].detach(), z_c=out["z_c"].detach())
 
 
 # --------------------------------------------------------------------------------------------

@@ -122,3 +122,38 @@ def test_kl_anneal_matches_reference_formula():
     # (tanh((it - 30000)/6666.67) + 1) * 0.03, host double (:515-523)
     assert abs(O.kl_anneal_weight(0, opt) - 7.4e-6) < 1e-6
     assert O.kl_anneal_weight(10, opt) > O.kl_anneal_weight(0, opt)
+
+
+def test_vi_club_two_phase_steps(golden_dir):
+    """VI ablation (drl_classifier_ec_vi.py): approximation-net loss, CLUB bound, beta ramp, two optimisers -- against
+    the reference class run by tests/golden/gen_golden_vi.py."""
+    cfg, opt = O.EncoderConfig(layers=2, vocab_size=900), O.Opt(pair_bow_dim=211, dropout=0.0, e_num_class=1)
+    z, batch = load(golden_dir, "vi_small")
+    B, S, L, vocab, V, wseed, bseed, steps = (int(v) for v in z["meta"])
+    P = {**O.init_params(cfg, opt, seed=wseed), **O.init_vi_params(opt, seed=wseed + 1)}
+    st_vae, st_aprx = O.AdamState(), O.AdamState()
+    for s in range(steps):
+        eps_e, eps_c = torch.from_numpy(z[f"eps_e_{s}"]), torch.from_numpy(z[f"eps_c_{s}"])
+        perm = torch.from_numpy(z[f"perm_{s}"])
+        P0 = P
+        P, out = O.vi_train_step(P, batch, 5 + s, int(z["epochs"][s]), cfg, opt, eps_e, eps_c, perm, st_vae, st_aprx)
+        np.testing.assert_allclose(out["z_e"].numpy(), z[f"z_e_{s}"], atol=3e-5, rtol=1e-4)
+        np.testing.assert_allclose(out["z_c"].numpy(), z[f"z_c_{s}"], atol=3e-5, rtol=1e-4)
+        for k in ("aprx", "vae", "upper", "total"):
+            np.testing.assert_allclose(float(out[k]), float(z[f"{k}_{s}"]), rtol=3e-5, atol=2e-6, err_msg=f"{k} step {s}")
+        if s == 0:
+            leaf = {k: P0[k].clone().requires_grad_(True) for k in O.VI_KEYS}
+            O.vi_aprx_loss(leaf, out["z_e"], out["z_c"]).backward()
+            for k in O.VI_KEYS:
+                np.testing.assert_allclose(leaf[k].grad.numpy(), z["ga_" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+        if s == 1:
+            ze, zc = out["z_e"].clone().requires_grad_(True), out["z_c"].clone().requires_grad_(True)
+            O.vi_upper_loss({k: P[k] for k in O.VI_KEYS}, ze, zc, perm).backward()
+            np.testing.assert_allclose(ze.grad.numpy(), z["dz_e_1"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(zc.grad.numpy(), z["dz_c_1"], rtol=1e-4, atol=1e-6)
+    lr_a, lr_v = opt.aprx_lr, opt.vae_lr
+    for k in z.files:
+        if k.startswith("w_"):
+            pk = k[2:]
+            got = P[pk].numpy() if pk in O.VI_KEYS else gslice(P[pk])
+            np.testing.assert_allclose(got, z[k], atol=(0.6 * lr_a if pk in O.VI_KEYS else 0.6 * lr_v), rtol=0, err_msg=pk)

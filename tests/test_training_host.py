@@ -72,3 +72,32 @@ def test_generate_self_train_data_random_strategy():
     assert list(out.columns) == ["pair", "label", "emotion"]
     assert list(out["label"]) == [1, 0, 1, 0]          # the single-pair document yields nothing (ref :782)
     assert out["pair"][0] == "p1" and out["pair"][2] == "p5"   # highest predicted score per document
+
+
+class TinyViModel(TinyModel):
+    """Stand-in with the VI ablation's surface: forward -> (e, c, aprx_loss, vae_loss), get_ec_upper_loss."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Parameter(torch.ones(2))
+        self.betas = []
+
+    def forward(self, ids, att, tt, emo, cau, labels, bow, iteration):
+        loss = super().forward(ids, att, tt, emo, cau, labels, bow, iteration)
+        e = self.w[:2] * 1.0
+        return e, e.detach() + 1.0, (self.a * e.detach()).pow(2).sum(), loss
+
+    def get_ec_upper_loss(self, e, c):
+        return (e * c).sum()
+
+
+def test_train_loop_vi_two_phase(tmp_path):
+    opt = make_opt(epochs=3, best_model_path=str(tmp_path / "ckpt"), model_id="vi")
+    model = TinyViModel()
+    aprx_opt = torch.optim.SGD([model.a], lr=0.1)
+    main_opt = torch.optim.SGD([model.w], lr=0.1)
+    a0 = model.a.detach().clone()
+    T.train(list(batches(8, 4)), list(batches(6, 6)), model, [aprx_opt, main_opt], "cpu", num_unpred_pairs=0, opt=opt, log=lambda *_: None)
+    assert model.calls == [0, 1] * 3
+    assert not torch.equal(model.a.detach(), a0)            # the approximation optimiser stepped
+    assert float(model.w.abs().sum()) > 0.0                 # and so did the main one
