@@ -27,22 +27,38 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
+  // blockIdx.y: contiguous group of samples (more waves in flight than one wave per column)
+  const int bg = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * bg, b1 = min(B, b0 + bg);
   const float* w = ps.w[n / seg] + (long)(n % seg) * TH;
   const float bias = ps.b[n / seg] ? ps.b[n / seg][n % seg] : 0.f;
   float4 wv[TNV];
 #pragma unroll
   for (int i = 0; i < TNV; ++i) wv[i] = *(const float4*)(w + (i * 64 + lane) * 4);
-  for (int b = 0; b < B; ++b) {
-    const float* x = row_idx ? in + (long)row_idx[b] * TH : in + (long)b * in_stride;
-    float s = 0.f;
+  for (int b = b0; b < b1; b += 4) {        // four samples per trip: independent loads and reductions
+    float s[4];
 #pragma unroll
-    for (int i = 0; i < TNV; ++i) {
-      const float4 xv = *(const float4*)(x + (i * 64 + lane) * 4);
-      s += (xv.x * wv[i].x + xv.y * wv[i].y) + (xv.z * wv[i].z + xv.w * wv[i].w);
+    for (int u = 0; u < 4; ++u) {
+      const int bb = min(b + u, b1 - 1);
+      const float* x = row_idx ? in + (long)row_idx[bb] * TH : in + (long)bb * in_stride;
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < TNV; ++i) {
+        const float4 xv = *(const float4*)(x + (i * 64 + lane) * 4);
+        t += (xv.x * wv[i].x + xv.y * wv[i].y) + (xv.z * wv[i].z + xv.w * wv[i].w);
+      }
+      s[u] = t;
     }
-    s = wave_sum(s) + bias;
-    if (ACT == 1) s = tanhf(s);
-    if (lane == 0) out[(long)b * out_stride + n] = s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], off, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v = s[u] + bias;
+      if (ACT == 1) v = tanhf(v);
+      if (lane == 0 && b + u < b1) out[(long)(b + u) * out_stride + n] = v;
+    }
   }
 }
 
@@ -57,15 +73,24 @@ __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
   float sb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float g = dY[(long)b * dy_stride + n];
-    sb += g;
-    const float* x = row_idx ? X + (long)row_idx[b] * TH : X + (long)b * x_stride;
+  for (int b = 0; b < B; b += 4) {          // loads of four samples in flight; accumulation order stays b = 0, 1, 2, ...
+    float g[4]; float4 xv[4][TNV];
 #pragma unroll
-    for (int i = 0; i < TNV; ++i) {
-      const float4 xv = *(const float4*)(x + (i * 64 + lane) * 4);
-      acc[i].x = fmaf(g, xv.x, acc[i].x); acc[i].y = fmaf(g, xv.y, acc[i].y);
-      acc[i].z = fmaf(g, xv.z, acc[i].z); acc[i].w = fmaf(g, xv.w, acc[i].w);
+    for (int u = 0; u < 4; ++u) {
+      const int bb = min(b + u, B - 1);
+      g[u] = (b + u < B) ? dY[(long)bb * dy_stride + n] : 0.f;
+      const float* x = row_idx ? X + (long)row_idx[bb] * TH : X + (long)bb * x_stride;
+#pragma unroll
+      for (int i = 0; i < TNV; ++i) xv[u][i] = *(const float4*)(x + (i * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sb += g[u];
+#pragma unroll
+      for (int i = 0; i < TNV; ++i) {
+        acc[i].x = fmaf(g[u], xv[u][i].x, acc[i].x); acc[i].y = fmaf(g[u], xv[u][i].y, acc[i].y);
+        acc[i].z = fmaf(g[u], xv[u][i].z, acc[i].z); acc[i].w = fmaf(g[u], xv[u][i].w, acc[i].w);
+      }
     }
   }
   float* w = os.w[n / seg] + (long)(n % seg) * TH;
@@ -89,19 +114,29 @@ __global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
   const int n0 = blockIdx.y * DG_CHUNK, n1 = min(N, n0 + DG_CHUNK);
-  for (int n = n0; n < n1; ++n) {
-    float g = dY[(long)b * dy_stride + n];
-    if (MODE == 1) {
-      const float yy = y[(long)b * N + n];
-      g *= (1.0f - yy * yy);
-      if (lane == 0) dpre[(long)b * N + n] = g;
-    }
-    const float* w = ps.w[n / seg] + (long)(n % seg) * TH;
+  for (int nb = n0; nb < n1; nb += 4) {     // four weight rows in flight; accumulation order stays n = n0, n0+1, ...
+    float g[4]; float4 wv[4][TNV];
 #pragma unroll
-    for (int i = 0; i < TNV; ++i) {
-      const float4 wv = *(const float4*)(w + (i * 64 + lane) * 4);
-      acc[i].x = fmaf(g, wv.x, acc[i].x); acc[i].y = fmaf(g, wv.y, acc[i].y);
-      acc[i].z = fmaf(g, wv.z, acc[i].z); acc[i].w = fmaf(g, wv.w, acc[i].w);
+    for (int u = 0; u < 4; ++u) {
+      const int n = min(nb + u, n1 - 1);
+      float gg = (nb + u < n1) ? dY[(long)b * dy_stride + n] : 0.f;
+      if (MODE == 1) {
+        const float yy = y[(long)b * N + n];
+        gg *= (1.0f - yy * yy);
+        if (lane == 0 && nb + u < n1) dpre[(long)b * N + n] = gg;
+      }
+      g[u] = gg;
+      const float* w = ps.w[n / seg] + (long)(n % seg) * TH;
+#pragma unroll
+      for (int i = 0; i < TNV; ++i) wv[u][i] = *(const float4*)(w + (i * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < TNV; ++i) {
+        acc[i].x = fmaf(g[u], wv[u][i].x, acc[i].x); acc[i].y = fmaf(g[u], wv[u][i].y, acc[i].y);
+        acc[i].z = fmaf(g[u], wv[u][i].z, acc[i].z); acc[i].w = fmaf(g[u], wv[u][i].w, acc[i].w);
+      }
     }
   }
   float* o = part + ((long)blockIdx.y * B + b) * TH;
@@ -145,22 +180,32 @@ struct TailCore {
   float* dlat_direct;           // [B, 4D]  KL part of d(loss)/d lat
   float* d_emo_w; float* d_emo_b; float* d_cau_w; float* d_cau_b; float* d_pair_w; float* d_pair_b;
   float* pair_dead;             // [1]: 1.0 if the pair loss was replaced by 0 (ref :510-511)
+  long long* prof;              // diagnostics (carel_tail_profile): phase time stamps, or null
 };
+#define TAIL_STAMP(i) do { if (a.prof && threadIdx.x == 0) a.prof[i] = (long long)wall_clock64(); } while (0)
+
+static long long* g_tail_prof = nullptr;
 
 __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;                 // 64
   float* sc = red + 64;                          // 64 scalars
-  const int B = a.B, D = a.D, D2 = 2 * a.D;
+  const int B = a.B, D = a.D, D2 = 2 * a.D, D4 = 4 * a.D;
   float* zl = sc + 64;                           // [B][2D] sampled latents
   float* dzl = zl + B * D2;                      // [B][2D] gradient accumulator
   float* elog = dzl + B * D2;                    // [B][8] emotion dlogits
   float* gx = elog + B * 8;                      // [B][2]  cause / pair dlogit
+  float* mlt = gx + B * 2;                       // [B][4D] dropout multipliers: emotion [D] | cause [D] | pair [2D]
+  float* lg = mlt + B * D4;                      // [B][16] head logits: emotion classes, then cause, then pair
+  float* hw = lg + B * 16;                       // head weights: emo_w [EC*D], emo_b [EC], cau_w [D], cau_b, pair_w [2D], pair_b
+  const int n_emo = a.EC * D;
+  const int o_eb = n_emo, o_cw = o_eb + a.EC, o_cb = o_cw + D, o_pw = o_cb + 1, o_pb = o_pw + D2, n_hw = o_pb + 1;
   const int nm = a.z_global ? a.n_global : B;    // samples per side in the MMD
-  float* nrm = gx + B * 2;                       // [2 nm]
+  float* nrm = hw + ((n_hw + 3) & ~3);           // [2 nm]
   float* Z = nrm + ((2 * nm + 3) & ~3);          // MMD samples [2 nm][D|1]
   const int zs = D | 1;
   const int t = threadIdx.x;
+  TAIL_STAMP(0);
 
   for (int e = t; e < B * D2; e += blockDim.x) {
     const int b = e / D2, k = e - b * D2;
@@ -168,6 +213,13 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     const float z = (k < D) ? row[k] + a.eps_e[k] * expf(row[D + k]) : row[2 * D + (k - D)] + a.eps_c[k - D] * expf(row[3 * D + (k - D)]);
     zl[e] = z; dzl[e] = 0.f; a.z[e] = z;
   }
+  for (int e = t; e < B * D4; e += blockDim.x) {
+    const int b = e / D4, k = e - b * D4;
+    mlt[e] = k < D ? dropout_mult(a.d_emo, b * D + k) : (k < D2 ? dropout_mult(a.d_cau, b * D + (k - D)) : dropout_mult(a.d_pair, b * D2 + (k - D2)));
+  }
+  for (int e = t; e < n_hw; e += blockDim.x)
+    hw[e] = e < o_eb ? a.emo_w[e] : e < o_cw ? a.emo_b[e - o_eb] : e < o_cb ? a.cau_w[e - o_cw] : e < o_pw ? a.cau_b[0]
+          : e < o_pb ? a.pair_w[e - o_pw] : a.pair_b[0];
   __syncthreads();
   // ---- MMD samples: rows [0,nm) emotion, [nm,2nm) cause
   for (int e = t; e < 2 * nm * D; e += blockDim.x) {
@@ -176,30 +228,38 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     Z[i * zs + k] = a.z_global ? a.z_global[(long)s * D2 + off + k] : zl[s * D2 + off + k];
   }
   __syncthreads();
+  TAIL_STAMP(1);
   float mmd = 0.f;                     // value of the disentanglement statistic (terms[1])
   float dis_term = 0.f;                // its contribution to the loss
   if (a.dis_mode == 0) {
     MmdCfg mc; mc.n1 = nm; mc.n2 = nm; mc.d = D; mc.zs = zs; mc.n_alphas = 1; mc.alphas[0] = a.alpha; mc.eps = a.mmd_eps;
-    mmd = mmd_forward_block(mc, Z, nrm, red, nullptr);
-    dis_term = -a.w_mmd * mmd;
-    // d(-w_mmd * mmd)/dz for the local rows: 8 threads per row
-    const int rows = 2 * B;
-    const int grp = t & 7;
-    for (int base = 0; base < rows; base += blockDim.x / 8) {
-      const int rloc = base + (t >> 3);
-      float g[32];
-      const bool live = rloc < rows;
-      if (live) {
-        const int side = rloc >= B, bl = rloc - side * B;
-        const int i = side * nm + a.row_offset * (a.z_global ? 1 : 0) + bl;
-        mmd_backward_row(mc, Z, nrm, i, -a.w_mmd * a.mmd_grad_scale, g, grp, 8);
-      } else {
-        for (int k = 0; k < D; ++k) g[k] = 0.f;
-      }
-      for (int k = 0; k < D; ++k) {
-        float v = g[k];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-        if (live && grp == 0) { const int side = rloc >= B, bl = rloc - side * B; dzl[bl * D2 + side * D + k] += v; }
+    if (!a.z_global && D == 24) {      // the configuration of every reference script: one fused forward + backward sweep
+      mmd = mmd_forward_backward_block<24>(mc, Z, nrm, red, -a.w_mmd * a.mmd_grad_scale, dzl, D2);
+      dis_term = -a.w_mmd * mmd;
+      TAIL_STAMP(2);
+    } else {
+      mmd = mmd_forward_block(mc, Z, nrm, red, nullptr);
+      dis_term = -a.w_mmd * mmd;
+      TAIL_STAMP(2);
+      // d(-w_mmd * mmd)/dz for the local rows: 8 threads per row
+      const int rows = 2 * B;
+      const int grp = t & 7;
+      for (int base = 0; base < rows; base += blockDim.x / 8) {
+        const int rloc = base + (t >> 3);
+        float g[32];
+        const bool live = rloc < rows;
+        if (live) {
+          const int side = rloc >= B, bl = rloc - side * B;
+          const int i = side * nm + a.row_offset * (a.z_global ? 1 : 0) + bl;
+          mmd_backward_row(mc, Z, nrm, i, -a.w_mmd * a.mmd_grad_scale, g, grp, 8);
+        } else {
+          for (int k = 0; k < D; ++k) g[k] = 0.f;
+        }
+        for (int k = 0; k < D; ++k) {
+          float v = g[k];
+          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+          if (live && grp == 0) { const int side = rloc >= B, bl = rloc - side * B; dzl[bl * D2 + side * D + k] += v; }
+        }
       }
     }
   } else if (a.dis_mode == 1) {        // HSIC between the local emotion (rows 0..B) and cause (rows B..2B) samples
@@ -216,66 +276,75 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     }
   }
   __syncthreads();
-  // ---- classifier heads: one thread per sample
+  TAIL_STAMP(3);
+  // ---- classifier heads: 16 threads per sample, one per logit (emotion classes, cause, pair)
+  for (int e = t; e < B * 16; e += blockDim.x) {
+    const int b = e >> 4, h = e & 15;
+    if (h < a.EC) {
+      float s = hw[o_eb + h];
+      for (int k = 0; k < D; ++k) s = fmaf(hw[h * D + k], zl[b * D2 + k] * mlt[b * D4 + k], s);
+      lg[e] = s;
+    } else if (h == a.EC) {
+      float s = hw[o_cb];
+      for (int k = 0; k < D; ++k) s = fmaf(hw[o_cw + k], zl[b * D2 + D + k] * mlt[b * D4 + D + k], s);
+      lg[e] = s;
+    } else if (h == a.EC + 1) {
+      float s = hw[o_pb];
+      for (int k = 0; k < D2; ++k) s = fmaf(hw[o_pw + k], zl[b * D2 + k] * mlt[b * D4 + D2 + k], s);
+      lg[e] = s;
+    }
+  }
   float l_emo = 0.f, l_cau = 0.f, l_pair = 0.f, ysum = 0.f;
   if (t < B) ysum = a.pair_labels[t];
-  ysum = block_sum(t < B ? ysum : 0.f, red);
+  ysum = block_sum(t < B ? ysum : 0.f, red);        // (its barriers also publish lg)
   const float ntot = a.label_sum_override ? a.n_override : (float)B;
   const float ytot = a.label_sum_override ? a.label_sum_override[0] : ysum;
   const float pw = (ntot - ytot) / ytot;        // inf when there is no positive in the batch
   float xp = 0.f, tp = 0.f;
-  if (t < B) {
-    const int b = t;
+  for (int b = t; b < B; b += blockDim.x) {
     if (!a.emo_bce) {
       // emotion: CE(W (z_e * m) + b, label)
-      float lg[8]; float mx = -INFINITY;
-      for (int c = 0; c < a.EC; ++c) {
-        float s = a.emo_b[c];
-        for (int k = 0; k < D; ++k) s = fmaf(a.emo_w[c * D + k], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), s);
-        lg[c] = s; mx = fmaxf(mx, s);
-      }
+      float mx = -INFINITY;
+      for (int c = 0; c < a.EC; ++c) mx = fmaxf(mx, lg[b * 16 + c]);
       float se = 0.f;
-      for (int c = 0; c < a.EC; ++c) se += expf(lg[c] - mx);
+      for (int c = 0; c < a.EC; ++c) se += expf(lg[b * 16 + c] - mx);
       const float lse = mx + logf(se);
       long lab = a.emo_labels[b]; lab = lab < 0 ? 0 : (lab >= a.EC ? a.EC - 1 : lab);
-      l_emo = lse - lg[lab];
-      for (int c = 0; c < a.EC; ++c) elog[b * 8 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * (a.w_emo / B);
+      l_emo += lse - lg[b * 16 + lab];
+      for (int c = 0; c < a.EC; ++c) elog[b * 8 + c] = (expf(lg[b * 16 + c] - lse) - (c == lab ? 1.f : 0.f)) * (a.w_emo / B);
     } else {
       // emotion, 1-logit variant: BCE(sigmoid(w (z_e * m) + b), smoothed label)   (drl_classifier_ec_hsic.py:455-470)
-      float se = a.emo_b[0];
-      for (int k = 0; k < D; ++k) se = fmaf(a.emo_w[k], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), se);
-      const float pe = 1.0f / (1.0f + expf(-se));
+      const float pe = 1.0f / (1.0f + expf(-lg[b * 16]));
       const float te = (float)a.emo_labels[b] * (1.f - a.ls) + a.ls;
-      l_emo = -(te * fmaxf(logf(pe), -100.f) + (1.f - te) * fmaxf(logf(1.f - pe), -100.f));
+      l_emo += -(te * fmaxf(logf(pe), -100.f) + (1.f - te) * fmaxf(logf(1.f - pe), -100.f));
       const float gpe = (pe - te) / fmaxf((1.f - pe) * pe, 1e-12f);
       elog[b * 8] = gpe * pe * (1.f - pe) * (a.w_emo / B);
     }
     // cause: BCE(sigmoid(w (z_c * m) + b), smoothed)
-    float s = a.cau_b[0];
-    for (int k = 0; k < D; ++k) s = fmaf(a.cau_w[k], zl[b * D2 + D + k] * dropout_mult(a.d_cau, b * D + k), s);
-    const float pc = 1.0f / (1.0f + expf(-s));
+    const float pc = 1.0f / (1.0f + expf(-lg[b * 16 + a.EC]));
     const float tc = a.cau_labels[b] * (1.f - a.ls) + a.ls;
-    l_cau = -(tc * fmaxf(logf(pc), -100.f) + (1.f - tc) * fmaxf(logf(1.f - pc), -100.f));
+    l_cau += -(tc * fmaxf(logf(pc), -100.f) + (1.f - tc) * fmaxf(logf(1.f - pc), -100.f));
     const float gp = (pc - tc) / fmaxf((1.f - pc) * pc, 1e-12f);
     gx[b * 2] = gp * pc * (1.f - pc) * (a.w_cau / B);
     // pair: BCEWithLogits(w (z * m) + b, smoothed, pos_weight)
-    xp = a.pair_b[0];
-    for (int k = 0; k < D2; ++k) xp = fmaf(a.pair_w[k], zl[b * D2 + k] * dropout_mult(a.d_pair, b * D2 + k), xp);
+    xp = lg[b * 16 + a.EC + 1];
     tp = a.pair_labels[b] * (1.f - a.ls) + a.ls;
     const float lw = (pw - 1.f) * tp + 1.f;
-    l_pair = (1.f - tp) * xp + lw * (log1pf(expf(-fabsf(xp))) + fmaxf(-xp, 0.f));
+    l_pair += (1.f - tp) * xp + lw * (log1pf(expf(-fabsf(xp))) + fmaxf(-xp, 0.f));
   }
   l_emo = block_sum(l_emo, red) / B;
   l_cau = block_sum(l_cau, red) / B;
   l_pair = block_sum(l_pair, red) / B;
   const bool dead = isinf(l_pair);
   if (dead) l_pair = 0.f;
-  if (t < B) {
-    const float lw = (pw - 1.f) * tp + 1.f;
-    const float sg = 1.0f / (1.0f + expf(-xp));
-    gx[t * 2 + 1] = dead ? 0.f : ((1.f - tp) - lw * (1.f - sg)) * (a.w_pair / B);
+  for (int b = t; b < B; b += blockDim.x) {
+    const float xb = lg[b * 16 + a.EC + 1], tb = a.pair_labels[b] * (1.f - a.ls) + a.ls;
+    const float lw = (pw - 1.f) * tb + 1.f;
+    const float sg = 1.0f / (1.0f + expf(-xb));
+    gx[b * 2 + 1] = dead ? 0.f : ((1.f - tb) - lw * (1.f - sg)) * (a.w_pair / B);
   }
   __syncthreads();
+  TAIL_STAMP(4);
   // ---- KL (:525-534) and its direct gradient on lat
   float kle = 0.f, klc = 0.f;
   for (int e = t; e < B * D; e += blockDim.x) {
@@ -290,41 +359,42 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   }
   kle = block_sum(kle, red) / B * a.kl_w;
   klc = block_sum(klc, red) / B * a.kl_w;
+  TAIL_STAMP(5);
   // ---- dz from the three heads, and the head parameter gradients
   for (int e = t; e < B * D2; e += blockDim.x) {
     const int b = e / D2, k = e - b * D2;
-    float g = a.pair_w[k] * gx[b * 2 + 1] * dropout_mult(a.d_pair, b * D2 + k);
+    float g = hw[o_pw + k] * gx[b * 2 + 1] * mlt[b * D4 + D2 + k];
     if (k < D) {
       float s = 0.f;
-      for (int c = 0; c < a.EC; ++c) s = fmaf(a.emo_w[c * D + k], elog[b * 8 + c], s);
-      g += s * dropout_mult(a.d_emo, b * D + k);
+      for (int c = 0; c < a.EC; ++c) s = fmaf(hw[c * D + k], elog[b * 8 + c], s);
+      g += s * mlt[b * D4 + k];
     } else {
-      g += a.cau_w[k - D] * gx[b * 2] * dropout_mult(a.d_cau, b * D + (k - D));
+      g += hw[o_cw + (k - D)] * gx[b * 2] * mlt[b * D4 + k];
     }
     dzl[e] += g;
   }
+  TAIL_STAMP(6);
   // parameter gradients: thread per parameter element, loop over the batch (fixed order)
-  const int n_emo = a.EC * D;
-  for (int e = t; e < n_emo + a.EC + D + 1 + D2 + 1; e += blockDim.x) {
+  for (int e = t; e < n_hw; e += blockDim.x) {
     float s = 0.f;
-    if (e < n_emo) {
+    if (e < o_eb) {
       const int c = e / D, k = e - c * D;
-      for (int b = 0; b < B; ++b) s = fmaf(elog[b * 8 + c], zl[b * D2 + k] * dropout_mult(a.d_emo, b * D + k), s);
+      for (int b = 0; b < B; ++b) s = fmaf(elog[b * 8 + c], zl[b * D2 + k] * mlt[b * D4 + k], s);
       a.d_emo_w[e] = s;
-    } else if (e < n_emo + a.EC) {
-      const int c = e - n_emo;
+    } else if (e < o_cw) {
+      const int c = e - o_eb;
       for (int b = 0; b < B; ++b) s += elog[b * 8 + c];
       a.d_emo_b[c] = s;
-    } else if (e < n_emo + a.EC + D) {
-      const int k = e - n_emo - a.EC;
-      for (int b = 0; b < B; ++b) s = fmaf(gx[b * 2], zl[b * D2 + D + k] * dropout_mult(a.d_cau, b * D + k), s);
+    } else if (e < o_cb) {
+      const int k = e - o_cw;
+      for (int b = 0; b < B; ++b) s = fmaf(gx[b * 2], zl[b * D2 + D + k] * mlt[b * D4 + D + k], s);
       a.d_cau_w[k] = s;
-    } else if (e == n_emo + a.EC + D) {
+    } else if (e == o_cb) {
       for (int b = 0; b < B; ++b) s += gx[b * 2];
       a.d_cau_b[0] = s;
-    } else if (e < n_emo + a.EC + D + 1 + D2) {
-      const int k = e - (n_emo + a.EC + D + 1);
-      for (int b = 0; b < B; ++b) s = fmaf(gx[b * 2 + 1], zl[b * D2 + k] * dropout_mult(a.d_pair, b * D2 + k), s);
+    } else if (e < o_pb) {
+      const int k = e - o_pw;
+      for (int b = 0; b < B; ++b) s = fmaf(gx[b * 2 + 1], zl[b * D2 + k] * mlt[b * D4 + D2 + k], s);
       a.d_pair_w[k] = s;
     } else {
       for (int b = 0; b < B; ++b) s += gx[b * 2 + 1];
@@ -332,6 +402,7 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     }
   }
   __syncthreads();
+  TAIL_STAMP(7);
   for (int e = t; e < B * D2; e += blockDim.x) a.dz[e] = dzl[e];
   if (t == 0) {
     a.terms[1] = mmd; a.terms[2] = l_emo; a.terms[3] = l_cau; a.terms[4] = l_pair; a.terms[5] = kle; a.terms[6] = klc;
@@ -346,8 +417,9 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
 // registers, the batch's latents in LDS).  Three passes (row max/sum, loss + softmax-backward dot,
 // gradients); partial results are combined in fixed order so the result is run-to-run reproducible.
 // ------------------------------------------------------------------------------------------
-constexpr int DEC_J = 128;
+constexpr int DEC_J = 128;          // vocabulary entries per workgroup
 constexpr int DEC_MAXD2 = 64;
+constexpr int DEC_MAXG = 4;         // sample groups per workgroup (threads = DEC_J * groups)
 
 struct DecArgs {
   int B, D2, V;
@@ -366,55 +438,78 @@ template <int CD2>
 __device__ __forceinline__ float dec_logit(const float* wr, const float* zrow, int D2rt, float bias) {
   const int D2 = CD2 ? CD2 : D2rt;
   float s = bias;
+  if (CD2 && (CD2 & 3) == 0) {
 #pragma unroll
-  for (int k = 0; k < D2; ++k) s = fmaf(wr[k], zrow[k], s);
+    for (int k = 0; k < D2; k += 4) {
+      const float4 zv = *(const float4*)(zrow + k);          // LDS broadcast read, 16 B
+      s = fmaf(wr[k], zv.x, s); s = fmaf(wr[k + 1], zv.y, s); s = fmaf(wr[k + 2], zv.z, s); s = fmaf(wr[k + 3], zv.w, s);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < D2; ++k) s = fmaf(wr[k], zrow[k], s);
+  }
   return s;
 }
 
-// CD2 > 0: 2*ec_dim known at compile time (weights stay in registers); CD2 == 0: generic run-time width
+// CD2 > 0: 2*ec_dim known at compile time (weights stay in registers); CD2 == 0: generic run-time width.
+// Thread t: entry tj = t % DEC_J of the chunk, sample group g = t / DEC_J (G = blockDim.x / DEC_J groups, each a
+// contiguous range of ceil(B/G) samples): 4x the waves of a thread-per-entry layout, bow values prefetched four samples
+// ahead.  Per-group results are combined in fixed order, so the outputs are run-to-run reproducible.
 template <int PASS, int CD2>
-__global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
+__global__ __launch_bounds__(DEC_J * DEC_MAXG) void decoder_kernel(DecArgs a) {
   const int D2 = CD2 ? CD2 : a.D2;
+  const int ws = D2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* zl = (float*)smem_raw;                       // [B][D2]
-  float* red = zl + a.B * D2;                       // 16
-  float* dl = red + 16;                               // [B][DEC_J] staging tile (pass 3: dlogits)
-  float* wl = dl + a.B * DEC_J;                       // PASS 3: [DEC_J][D2+1]  (pass 2: second tile)
-  const int t = threadIdx.x, j = blockIdx.x * DEC_J + t;
+  float* red = zl + a.B * D2;                         // 16
+  float* wl = red + 16;                               // [DEC_J][D2+1] weights of the chunk
+  float* tile = wl + DEC_J * ws;                      // [B][DEC_J] per-(sample, entry) values (pass 3: dlogits)
+  float* tile2 = tile + a.B * DEC_J;                  // pass 2: second tile; pass 3: [G-1][DEC_J][D2+1] dW partials + [G-1][DEC_J] db
+  const int t = threadIdx.x, nthr = blockDim.x, G = nthr / DEC_J;
+  const int tj = t & (DEC_J - 1), g = t / DEC_J;
+  const int j0 = blockIdx.x * DEC_J, j = j0 + tj;
   const bool live = j < a.V;
-  for (int e = t; e < a.B * D2; e += DEC_J) zl[e] = a.z[e];
-  float wr[CD2 ? CD2 : DEC_MAXD2];
-  _Pragma("unroll") for (int k = 0; k < D2; ++k) wr[k] = live ? a.w[(long)j * D2 + k] : 0.f;
-  const float bias = live ? a.b[j] : 0.f;
+  const int Bg = (a.B + G - 1) / G, b0 = g * Bg, b1 = min(a.B, b0 + Bg);
+  for (int e = t; e < a.B * D2; e += nthr) zl[e] = a.z[e];
+  {   // coalesced load of the chunk's weights, then each thread takes its row
+    const int nrow = min(DEC_J, a.V - j0);
+    for (int e = t; e < nrow * D2; e += nthr) { const int r = e / D2, k = e - r * D2; wl[r * ws + k] = a.w[(long)j0 * D2 + e]; }
+  }
   __syncthreads();
-  // Passes 1 and 2 stage the per-(sample, entry) values of the chunk in an LDS tile [B][DEC_J] and reduce every
-  // sample's row with wave shuffles (each of the 2 waves takes every other sample) -- no per-sample block barriers.
-  float* tile = dl;                                     // [B][DEC_J]
-  const int lane = t & 63, wv = t >> 6;
+  float wr[CD2 ? CD2 : DEC_MAXD2];
+  _Pragma("unroll") for (int k = 0; k < D2; ++k) wr[k] = live ? wl[tj * ws + k] : 0.f;
+  const float bias = live ? a.b[j] : 0.f;
+  const int lane = t & 63, wv = t >> 6, nwv = nthr >> 6;
   if (PASS == 1) {
-    for (int b = 0; b < a.B; ++b) tile[b * DEC_J + t] = live ? dec_logit<CD2>(wr, zl + b * D2, D2, bias) : -INFINITY;
+    for (int b = b0; b < b1; ++b) tile[b * DEC_J + tj] = live ? dec_logit<CD2>(wr, zl + b * D2, D2, bias) : -INFINITY;
     __syncthreads();
-    for (int b = wv; b < a.B; b += DEC_J / 64) {
+    for (int b = wv; b < a.B; b += nwv) {
       const float x0 = tile[b * DEC_J + lane], x1 = tile[b * DEC_J + 64 + lane];
       const float m = wave_max(fmaxf(x0, x1));
       const float s2 = wave_sum(expf(x0 - m) + expf(x1 - m));            // exp(-inf - m) = 0 for dead entries
       if (lane == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = m; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = s2; }
     }
   } else if (PASS == 2) {
-    float* tile2 = tile + a.B * DEC_J;
-    for (int b = 0; b < a.B; ++b) {
-      float le = 0.f, dt = 0.f;
-      if (live) {
-        const float lp = dec_logit<CD2>(wr, zl + b * D2, D2, bias) - a.rowstat[b * 4] - a.rowstat[b * 4 + 1];
-        const float p = expf(lp);
-        const float tg = a.bow[(long)b * a.V + j] * (1.f - a.ls) + a.ls / a.V;
-        le = -(tg * fmaxf(lp, -100.f) + (1.f - tg) * fmaxf(log1pf(-p), -100.f));
-        dt = p * ((p - tg) / fmaxf((1.f - p) * p, 1e-12f));
+    for (int bb = b0; bb < b1; bb += 4) {
+      float bw[4];
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) bw[u] = (live && bb + u < b1) ? a.bow[(long)(bb + u) * a.V + j] : 0.f;
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {
+        const int b = bb + u;
+        if (b < b1) {
+          float le = 0.f, dt = 0.f;
+          if (live) {
+            const float lp = dec_logit<CD2>(wr, zl + b * D2, D2, bias) - a.rowstat[b * 4] - a.rowstat[b * 4 + 1];
+            const float p = expf(lp);
+            const float tg = bw[u] * (1.f - a.ls) + a.ls / a.V;
+            le = -(tg * fmaxf(lp, -100.f) + (1.f - tg) * fmaxf(log1pf(-p), -100.f));
+            dt = p * ((p - tg) / fmaxf((1.f - p) * p, 1e-12f));
+          }
+          tile[b * DEC_J + tj] = le; tile2[b * DEC_J + tj] = dt;
+        }
       }
-      tile[b * DEC_J + t] = le; tile2[b * DEC_J + t] = dt;
     }
     __syncthreads();
-    for (int b = wv; b < a.B; b += DEC_J / 64) {
+    for (int b = wv; b < a.B; b += nwv) {
       const float le = wave_sum(tile[b * DEC_J + lane] + tile[b * DEC_J + 64 + lane]);
       const float dt = wave_sum(tile2[b * DEC_J + lane] + tile2[b * DEC_J + 64 + lane]);
       if (lane == 0) { a.part[((long)blockIdx.x * a.B + b) * 2] = le; a.part[((long)blockIdx.x * a.B + b) * 2 + 1] = dt; }
@@ -423,31 +518,47 @@ __global__ __launch_bounds__(DEC_J) void decoder_kernel(DecArgs a) {
     float dwr[CD2 ? CD2 : DEC_MAXD2];
     _Pragma("unroll") for (int k = 0; k < D2; ++k) dwr[k] = 0.f;
     float dbj = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-      float g = 0.f;
-      if (live) {
-        const float lp = dec_logit<CD2>(wr, zl + b * D2, D2, bias) - a.rowstat[b * 4] - a.rowstat[b * 4 + 1];
-        const float p = expf(lp);
-        const float tg = a.bow[(long)b * a.V + j] * (1.f - a.ls) + a.ls / a.V;
-        const float gp = (p - tg) / fmaxf((1.f - p) * p, 1e-12f);
-        g = p * (gp - a.rowstat[b * 4 + 2]) * a.gscale;
-        _Pragma("unroll") for (int k = 0; k < D2; ++k) dwr[k] = fmaf(g, zl[b * D2 + k], dwr[k]);
-        dbj += g;
+    for (int bb = b0; bb < b1; bb += 4) {
+      float bw[4];
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) bw[u] = (live && bb + u < b1) ? a.bow[(long)(bb + u) * a.V + j] : 0.f;
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {
+        const int b = bb + u;
+        if (b < b1) {
+          float gg = 0.f;
+          if (live) {
+            const float lp = dec_logit<CD2>(wr, zl + b * D2, D2, bias) - a.rowstat[b * 4] - a.rowstat[b * 4 + 1];
+            const float p = expf(lp);
+            const float tg = bw[u] * (1.f - a.ls) + a.ls / a.V;
+            const float gp = (p - tg) / fmaxf((1.f - p) * p, 1e-12f);
+            gg = p * (gp - a.rowstat[b * 4 + 2]) * a.gscale;
+            _Pragma("unroll") for (int k = 0; k < D2; ++k) dwr[k] = fmaf(gg, zl[b * D2 + k], dwr[k]);
+            dbj += gg;
+          }
+          tile[b * DEC_J + tj] = gg;
+        }
       }
-      dl[b * DEC_J + t] = g;
     }
-    const int ws = D2 + 1;
-    _Pragma("unroll") for (int k = 0; k < D2; ++k) wl[t * ws + k] = wr[k];
-    if (live) {
+    float* dwp = tile2;                               // [G-1][DEC_J][ws]
+    float* dbp = dwp + (G - 1) * DEC_J * ws;          // [G-1][DEC_J]
+    if (g > 0) {
+      _Pragma("unroll") for (int k = 0; k < D2; ++k) dwp[((g - 1) * DEC_J + tj) * ws + k] = dwr[k];
+      dbp[(g - 1) * DEC_J + tj] = dbj;
+    }
+    __syncthreads();
+    if (g == 0 && live) {
+      for (int q = 0; q < G - 1; ++q) {               // fixed order: group 0 + group 1 + ...
+        _Pragma("unroll") for (int k = 0; k < D2; ++k) dwr[k] += dwp[(q * DEC_J + tj) * ws + k];
+        dbj += dbp[q * DEC_J + tj];
+      }
       _Pragma("unroll") for (int k = 0; k < D2; ++k) a.dw[(long)j * D2 + k] = dwr[k];
       a.db[j] = dbj;
     }
-    __syncthreads();
-    // dz_part[chunk][b][k] = sum_{j in chunk} dl[b][j] * W[j][k]
-    for (int e = t; e < a.B * D2; e += DEC_J) {
+    // dz_part[chunk][b][k] = sum_{j in chunk} dlogit[b][j] * W[j][k]
+    for (int e = t; e < a.B * D2; e += nthr) {
       const int b = e / D2, k = e - b * D2;
+      const int nrow = min(DEC_J, a.V - j0);
       float s = 0.f;
-      for (int jj = 0; jj < DEC_J; ++jj) s = fmaf(dl[b * DEC_J + jj], wl[jj * ws + k], s);
+      for (int jj = 0; jj < nrow; ++jj) s = fmaf(tile[b * DEC_J + jj], wl[jj * ws + k], s);
       a.dz_part[(long)blockIdx.x * a.B * D2 + e] = s;
     }
   }
@@ -596,11 +707,12 @@ extern "C" int carel_tail_latents(const carel_tail_args* a, void* stream_) {
   if (rc) return rc;
   PtrSet4 pp; for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; }
   pp.w[0] = (const float*)a->pooler_w; pp.b[0] = (const float*)a->pooler_b;
-  hipLaunchKernelGGL(rowvec_linear_kernel<1>, dim3(TH / 4), dim3(256), 0, stream, (const float*)a->x_last_f32,
+  auto sample_groups = [&](int ncols) { int g = (1024 + ncols - 1) / ncols; const int mx = (a->batch + 3) / 4; g = g > mx ? mx : g; return g < 1 ? 1 : g; };
+  hipLaunchKernelGGL(rowvec_linear_kernel<1>, dim3(TH / 4, sample_groups(TH)), dim3(256), 0, stream, (const float*)a->x_last_f32,
                      (long)a->seq_len * TH, (const int*)a->cls_rows, a->batch, TH, TH, pp, (float*)a->pooled, (long)TH);
   PtrSet4 hp; for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = (const float*)a->head_b[i]; }
   const int N = 4 * a->ec_dim;
-  hipLaunchKernelGGL(rowvec_linear_kernel<0>, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)a->pooled, (long)TH,
+  hipLaunchKernelGGL(rowvec_linear_kernel<0>, dim3((N + 3) / 4, sample_groups(N)), dim3(256), 0, stream, (const float*)a->pooled, (long)TH,
                      (const int*)nullptr, a->batch, N, a->ec_dim, hp, (float*)a->lat, (long)N);
   return check_launch("tail latents");
 }
@@ -653,12 +765,15 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   c.d_emo_w = (float*)a->d_emo_w; c.d_emo_b = (float*)a->d_emo_b; c.d_cau_w = (float*)a->d_cau_w; c.d_cau_b = (float*)a->d_cau_b;
   c.d_pair_w = (float*)a->d_pair_w; c.d_pair_b = (float*)a->d_pair_b; c.pair_dead = w.pair_dead;
   const int nm = c.z_global ? c.n_global : B;
-  const size_t lds = sizeof(float) * (64 + 64 + (size_t)2 * B * 2 * D + (size_t)B * 8 + (size_t)B * 2 + ((2 * nm + 3) & ~3) + (size_t)2 * nm * (D | 1) + 2 * (size_t)B);
+  const int n_hw = a->e_classes * D + a->e_classes + D + 1 + 2 * D + 1;
+  const size_t lds = sizeof(float) * (64 + 64 + (size_t)2 * B * 2 * D + (size_t)B * 8 + (size_t)B * 2 + (size_t)B * 4 * D + (size_t)B * 16 +
+                                      ((n_hw + 3) & ~3) + ((2 * nm + 3) & ~3) + (size_t)2 * nm * (D | 1) + 2 * (size_t)B);
   if (lds > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the single-workgroup tail (%zu B LDS)", lds);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)tail_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
+  c.prof = g_tail_prof;
   hipLaunchKernelGGL(tail_core_kernel, dim3(1), dim3(1024), lds, stream, c);
   if ((rc = check_launch("tail_core_kernel"))) return rc;
 
@@ -667,10 +782,12 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   d.bow = (const float*)a->bow; d.ls = a->label_smoothing; d.part = w.part; d.rowstat = w.rowstat; d.dz_part = w.dz_part;
   d.dw = (float*)a->d_dec_w; d.db = (float*)a->d_dec_b; d.gscale = 1.0f / ((float)B * (float)V);
   const int chunks = (V + DEC_J - 1) / DEC_J;
-  const size_t lds0 = sizeof(float) * ((size_t)B * 2 * D + 16);
-  const size_t lds1 = lds0 + sizeof(float) * (size_t)B * DEC_J;
-  const size_t lds2 = lds0 + sizeof(float) * 2 * (size_t)B * DEC_J;
-  const size_t lds3 = lds0 + sizeof(float) * ((size_t)B * DEC_J + (size_t)DEC_J * (2 * D + 1));
+  // LDS: z + red + weights + tile [B][DEC_J] (+ pass 2: second tile; pass 3: the other groups' dW/db partials)
+  const size_t lds0 = sizeof(float) * ((size_t)B * 2 * D + 16 + (size_t)DEC_J * (2 * D + 1) + (size_t)B * DEC_J);
+  int G = DEC_MAXG;
+  auto lds3_of = [&](int g) { return lds0 + sizeof(float) * (size_t)(g - 1) * DEC_J * (2 * D + 2); };
+  while (G > 1 && (lds3_of(G) > 160 * 1024 || (B + G - 1) / G < 4)) G >>= 1;
+  const size_t lds1 = lds0, lds2 = lds0 + sizeof(float) * (size_t)B * DEC_J, lds3 = lds3_of(G);
   const size_t ldsmax = lds2 > lds3 ? lds2 : lds3;
   if (ldsmax > 160 * 1024) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: batch too large for the decoder kernel");
   if (ldsmax > 64 * 1024) {
@@ -682,8 +799,8 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   }
 #define DEC_LAUNCH(PASS, LDS)                                                                              \
   do {                                                                                                  \
-    if (2 * D == 48) hipLaunchKernelGGL((decoder_kernel<PASS, 48>), dim3(chunks), dim3(DEC_J), LDS, stream, d); \
-    else hipLaunchKernelGGL((decoder_kernel<PASS, 0>), dim3(chunks), dim3(DEC_J), LDS, stream, d);      \
+    if (2 * D == 48) hipLaunchKernelGGL((decoder_kernel<PASS, 48>), dim3(chunks), dim3(DEC_J * G), LDS, stream, d); \
+    else hipLaunchKernelGGL((decoder_kernel<PASS, 0>), dim3(chunks), dim3(DEC_J * G), LDS, stream, d);      \
   } while (0)
   DEC_LAUNCH(1, lds1);
   hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 1, w.rowstat);
@@ -717,6 +834,8 @@ extern "C" int64_t carel_tail_pair_dead_offset(int32_t batch, int32_t ec_dim, in
   TailWork w = carve((float*)nullptr + 1, batch, ec_dim, bow_dim);   // offsets relative to a fake base
   return (int64_t)(w.pair_dead - ((float*)nullptr + 1));
 }
+
+extern "C" int carel_tail_profile(void* dev_i64_x16) { g_tail_prof = (long long*)dev_i64_x16; return CAREL_OK; }
 
 extern "C" int carel_tail_backward(const carel_tail_args* a, const void* grad_out_dev, void* stream_) {
   return carel_tail_backward_dz(a, grad_out_dev, nullptr, stream_);

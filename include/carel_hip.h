@@ -307,6 +307,9 @@ typedef struct carel_tail_args {
 int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim);
 int carel_tail_latents(const carel_tail_args* args, void* stream);
 int carel_tail_losses(const carel_tail_args* args, void* stream);
+/* Measurement aid: while a device buffer of 16 int64 is registered, the fused loss kernel of carel_tail_losses writes
+ * 100 MHz time stamps at its phase boundaries into it (NULL switches it off). */
+int carel_tail_profile(void* dev_i64_x16);
 int carel_tail_backward(const carel_tail_args* args, const void* grad_out_dev_f32, void* stream);
 /* same, plus an additional upstream gradient on the sampled embeddings z (f32 [B, 2*ec_dim], NOT scaled by grad_out):
  * lets further loss terms defined on z_e / z_c (e.g. the CLUB bound of the VI ablation) reach the encoder */
