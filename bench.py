@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-ecpe", action="store_true", help="skip the secondary ECPE-shaped leg")
     ap.add_argument("--no-varlen", action="store_true", help="run padded positions through the encoder like the reference does")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="weight-gradient GEMMs on the main stream (serial kernels: the run to put under rocprofv3 --kernel-trace)")
     return ap.parse_args()
 
 
@@ -127,6 +129,7 @@ def main():
         lengths.append(b["attention_masks"].sum(1).tolist())     # known on the host before the H2D copy (as in a DataLoader)
         batches.append({k: v.to(dev) for k, v in b.items()})
     model.varlen = not a.no_varlen
+    model.overlap_wgrad = not a.no_overlap
 
     def step(i):
         b = batches[i % len(batches)]
@@ -166,14 +169,18 @@ def main():
     log("timed region done: %.3f ms/step" % (1e3 * dt / a.steps))
     # roofline leg: the SAME step, 3 more times, with HIP events bracketing every GEMM launch on its stream.  It is kept
     # out of the timed region because the event markers between kernels cost ~5 % of step time (no kernel overlap at the
-    # boundaries); the per-launch average agrees with `rocprofv3 --kernel-trace --stats` (profiles/).
+    # boundaries), and it runs the kernels SERIALLY (weight gradients back on the main stream): with two streams the
+    # brackets of concurrent kernels overlap and a per-kernel duration stops meaning anything.  The per-launch average
+    # agrees with `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-overlap --no-ecpe` (profiles/).
     nprof = 3
+    model.overlap_wgrad = False
     L.check(lib.carel_profile_gemm(1, 200 * nprof))
     for i in range(nprof):
         step(a.warmup + a.steps + i)
     torch.cuda.synchronize()
     ev_timed = read_gemm_events()
     L.check(lib.carel_profile_gemm(0, 0))
+    model.overlap_wgrad = not a.no_overlap
     pairs_per_s = world * a.batch * a.steps / dt
 
     # ---- secondary line: the same step on ECPE-shaped batches (SURVEY 8(d) shape-B: ~77 % padding), padding skipped ----
@@ -222,6 +229,7 @@ def main():
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "launches_per_step": n_t / nprof, "avg_launch_us": 1e3 * ms_t / n_t, "alg_gflop_per_launch": fl_t / n_t / 1e9,
                 "gemm_ms_per_step": ms_t / nprof,
+                "note": "per-kernel durations from a serial replay of the step (wgrad_side_stream off); the timed region overlaps them",
                 "whole_step_frac_of_peak": (world * a.batch * FLOP_PER_PAIR * a.steps / dt) / (world * PEAK_BF16_TFLOPS * 1e12)}
 
     out = {"metric": "clause-pairs/sec (training step)", "value": pairs_per_s, "unit": "clause-pairs/s", "n_gpus": world,
@@ -232,7 +240,8 @@ def main():
                       "global_batch": world * a.batch, "seq_len": 128, "parallelism": "dp%d" % world,
                       "attended_tokens_per_pair": sum(sum(l) for l in lengths) / (len(lengths) * a.batch),
                       "padding_skipped": bool(model.varlen and a.shape == "B"),
-                      "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam"},
+                      "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
+                      "wgrad_side_stream": bool(model.overlap_wgrad)},
            "roofline": roof, "ecpe_shaped": ecpe, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):

@@ -108,6 +108,7 @@ class EncoderArgs(C.Structure):
                 ("layers", C.POINTER(LayerParams)), ("act", C.c_void_p), ("scratch", C.c_void_p),
                 ("n_tokens", C.c_int32), ("tok_row", C.c_void_p), ("cu_seqlens", C.c_void_p),
                 ("n_cls", C.c_int32), ("cls_rows", C.c_void_p), ("cls_orig_rows", C.c_void_p),
+                ("overlap_wgrad", C.c_int32),
                 ("layer_grads", C.POINTER(LayerGrads)),
                 ("d_word_emb", C.c_void_p), ("d_pos_emb", C.c_void_p), ("d_type_emb", C.c_void_p),
                 ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p)]

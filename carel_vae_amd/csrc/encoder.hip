@@ -58,15 +58,16 @@ LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
   return r;
 }
 
-struct Scratch { char* dy; char* dyb; char* du; char* dctx; char* dqkv; char* slabs; char* part; };
-struct ScratchLayout { size_t o_dy, o_dyb, o_du, o_dctx, o_dqkv, o_slabs, o_part, total; };
+struct Scratch { char* dy; char* dyb; char* dyb2; char* du; char* dctx; char* dqkv; char* slabs; char* ws; char* part; };
+struct ScratchLayout { size_t o_dy, o_dyb, o_dyb2, o_du, o_dctx, o_dqkv, o_slabs, o_ws, o_part, ws_bytes, total; };
 
-// split-K factor of the weight-gradient GEMMs (K = tokens).  Measured at T = 8192 (tools/bench_gemm.py):
-// 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 8 (with the 1x8 XCD patch order: 66 us vs
-// 82 us at 4, which pays for the 6 us longer slab reduction).
+// split-K factor of the weight-gradient GEMMs (K = tokens).  Measured at T = 8192 in the whole step with the
+// weight gradients on the side stream: 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 4
+// (stand-alone the FFN shape is faster at 8, 66 vs 82 us, but beside the dgrad chain the CUs are filled anyway and
+// half the slab traffic wins: 10.33 vs 10.58 ms per step).
 int wgrad_splits(long T, int M, int N) {
   const int tiles = (M / 128) * (N / 128);
-  const int want = (tiles < 64 || tiles >= 128) ? 8 : 4;
+  const int want = tiles < 64 ? 8 : 4;
   int s = 1;
   while (s < want && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
   return s;
@@ -77,13 +78,15 @@ ScratchLayout scratch_layout(long B, long S) {
   ScratchLayout s; size_t o = 0;
   s.o_dy = o; o += al(T * EH * 4);
   s.o_dyb = o; o += al(T * EH * 2);
+  s.o_dyb2 = o; o += al(T * EH * 2);        // LN1-backward output, so that the FFN2 weight gradient may still read dyb (side stream)
   s.o_du = o; o += al(T * EI * 2);
   s.o_dctx = o; o += al(T * EH * 2);
   s.o_dqkv = o; o += al(T * 3 * EH * 2);
   size_t slab = 0;
   const int shapes[4][2] = {{EH, EI}, {EI, EH}, {EH, EH}, {3 * EH, EH}};
   for (auto& sh : shapes) { size_t n = (size_t)wgrad_splits((long)T, sh[0], sh[1]) * ((size_t)sh[0] * sh[1] + sh[0]) * 4; slab = n > slab ? n : slab; }
-  s.o_slabs = o; o += al(slab);
+  s.o_slabs = o; o += al(slab);             // weight-gradient slabs (side stream when overlapping)
+  s.o_ws = o; o += al(slab); s.ws_bytes = al(slab);      // split-K workspace of the forward / data-gradient GEMMs (main stream)
   size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;
   const size_t cs = ((T + 255) / 256) * EI * 4;
   part = part > cs ? part : cs;
@@ -93,8 +96,8 @@ ScratchLayout scratch_layout(long B, long S) {
 }
 
 Scratch scratch_of(const ScratchLayout& l, char* b) {
-  Scratch s; s.dy = b + l.o_dy; s.dyb = b + l.o_dyb; s.du = b + l.o_du; s.dctx = b + l.o_dctx; s.dqkv = b + l.o_dqkv;
-  s.slabs = b + l.o_slabs; s.part = b + l.o_part;
+  Scratch s; s.dy = b + l.o_dy; s.dyb = b + l.o_dyb; s.dyb2 = b + l.o_dyb2; s.du = b + l.o_du; s.dctx = b + l.o_dctx; s.dqkv = b + l.o_dqkv;
+  s.slabs = b + l.o_slabs; s.ws = b + l.o_ws; s.part = b + l.o_part;
   return s;
 }
 
@@ -119,6 +122,24 @@ int enc_check(const carel_encoder_args* a, const char* who) {
       return set_error(CAREL_ERR_ARG, "%s: packing needs tok_row, cu_seqlens and n_tokens (multiple of 128, <= batch*seq_len)", who);
   }
   return CAREL_OK;
+}
+
+// One low-priority stream + a few events per device, created on first use and kept for the life of the process.
+struct SideStream { static constexpr int NEV = 6; hipStream_t stream; hipEvent_t ev[NEV]; bool ok; };
+SideStream* side_stream() {
+  static SideStream per_dev[16];
+  static bool made[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!made[dev]) {
+    SideStream& s = per_dev[dev];
+    int lo = 0, hi = 0;
+    s.ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+           hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) == hipSuccess;     // lo = lowest priority
+    for (int i = 0; i < SideStream::NEV && s.ok; ++i) s.ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
+    made[dev] = true;
+  }
+  return per_dev[dev].ok ? &per_dev[dev] : nullptr;
 }
 
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
@@ -188,8 +209,8 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   char* xb = base + l.o_xb;
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
   const ScratchLayout sl = scratch_layout(B, S);
-  char* ws = a->scratch ? (char*)a->scratch + sl.o_slabs : nullptr;       // split-K workspace for small (packed) batches
-  const size_t ws_bytes = a->scratch ? sl.o_part - sl.o_slabs : 0;
+  char* ws = a->scratch ? (char*)a->scratch + sl.o_ws : nullptr;          // split-K workspace for small (packed) batches
+  const size_t ws_bytes = a->scratch ? sl.ws_bytes : 0;
   LayerAct la = layer_act(l, base, 0, a->inference);
   carel_embed_args e = embed_args_of(a, l, la);
   if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
@@ -243,7 +264,24 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const carel_layer_grads& g = a->layer_grads[layer];
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
   const ScratchLayout sl = scratch_layout(B, S);
-  const size_t ws_bytes = sl.o_part - sl.o_slabs;
+  const size_t ws_bytes = sl.ws_bytes;
+  // Weight gradients on a second stream (a->overlap_wgrad): each dW GEMM + slab reduction is forked behind the kernel
+  // that produced its dY operand and runs beside the data-gradient chain, LayerNorm and attention backward kernels;
+  // everything is joined before this call returns (so the caller may all-reduce this layer's gradients right away).
+  SideStream* sd = nullptr;
+  if (a->overlap_wgrad) {
+    sd = side_stream();
+    if (!sd) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: could not create the side stream / events");
+  }
+  void* wstream = sd ? (void*)sd->stream : stream;
+  int nfork = 0;
+  auto fork = [&]() -> int {      // side stream waits for everything enqueued on `stream` so far
+    if (!sd) return CAREL_OK;
+    hipEvent_t ev = sd->ev[nfork++];
+    if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->stream, ev, 0) != hipSuccess)
+      return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event fork failed");
+    return CAREL_OK;
+  };
   // Row-wise half of the layer.  Last layer with dead-row elimination: only the n_cls [CLS] rows exist (compact).
   const bool cls_only = a->n_cls > 0 && layer + 1 == a->n_layers;
   const long R = cls_only ? (long)a->n_cls : T;
@@ -254,29 +292,32 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
                                        rmap, s.dy, s.dyb, g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
+  if ((rc = fork())) return rc;
+  if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream))) return rc;
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
                       nullptr, la.u, 0, 0, 0, 0.f, stream, s.part))) return rc;
   if ((rc = carel_partial_reduce_f32(s.part, g.ffn1_b, EI, (int)(R / 128), 0, stream))) return rc;
-  if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, stream))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
+  if ((rc = fork())) return rc;
+  if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream))) return rc;
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
-                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
-  if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, stream))) return rc;
-  // LN1 backward
+                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
+  // LN1 backward (its bf16 output goes to a second buffer: the FFN2 weight gradient may still be reading dyb)
   if ((rc = carel_layernorm_bwd_packed(a->dx, la.h1, la.st1, w.ln1_g, R, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout,
-                                       rmap, s.dy, s.dyb, g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
+                                       rmap, s.dy, s.dyb2, g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
-  void* dctx_rows = cls_only ? (void*)s.du : (void*)s.dctx;       // compact result parks in the (free) du buffer
-  if ((rc = gemm_call(s.dyb, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
+  void* dctx_rows = cls_only ? (void*)s.dqkv : (void*)s.dctx;     // compact result parks in the (still free) dqkv buffer
+  if ((rc = fork())) return rc;
+  if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream))) return rc;
+  if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
                       nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
-  if ((rc = wgrad_call(s.dyb, ctx_rows, R, EH, EH, s.slabs, g.out_w, stream))) return rc;
   if (cls_only) {
     // expand the compact [CLS] gradients to token rows: dctx (attention backward input) and the residual-path
     // gradient dh1 (added by the QKV dgrad epilogue) are zero everywhere else
     hipError_t he = hipMemsetAsync(s.dctx, 0, (size_t)T * EH * 2, (hipStream_t)stream);
     if (he == hipSuccess) he = hipMemsetAsync(a->dx, 0, (size_t)T * EH * 4, (hipStream_t)stream);
     if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
-    if ((rc = scatter_rows(nullptr, s.du, a->cls_rows, (int)R, nullptr, s.dctx, (hipStream_t)stream))) return rc;
+    if ((rc = scatter_rows(nullptr, s.dqkv, a->cls_rows, (int)R, nullptr, s.dctx, (hipStream_t)stream))) return rc;
     if ((rc = scatter_rows(s.dy, nullptr, a->cls_rows, (int)R, a->dx, nullptr, (hipStream_t)stream))) return rc;
   }
   const void* dh1_full = cls_only ? (const void*)a->dx : (const void*)s.dy;      // in-place residual add is safe (same thread)
@@ -294,9 +335,16 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   }
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
+  if ((rc = fork())) return rc;
+  if ((rc = wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, wstream, g.qkv_b))) return rc;
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
-                      dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.slabs, ws_bytes))) return rc;
-  return wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, stream, g.qkv_b);
+                      dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
+  if (sd) {        // join
+    hipEvent_t ev = sd->ev[SideStream::NEV - 1];
+    if (hipEventRecord(ev, sd->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess)
+      return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event join failed");
+  }
+  return CAREL_OK;
 }
 
 // Backward of the embedding block: a->dx = d(loss)/d(embedding output).  d_word_emb / d_pos_emb are

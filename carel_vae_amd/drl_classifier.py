@@ -328,6 +328,7 @@ class DrlClassifier(nn.Module):
         self.dropout_base_seed = 0x5EED
         self.varlen = True                   # skip padded positions (results identical; see _pack_info)
         self.cls_only_last = True            # last layer's row-wise half on the [CLS] rows only (results identical)
+        self.overlap_wgrad = True            # weight-gradient GEMMs on a second stream beside the dgrad chain (results identical)
         self._fwd_count = 0
         self._noise = None
         self._ws = {}
@@ -525,6 +526,7 @@ class DrlClassifier(nn.Module):
             a.n_tokens, a.tok_row, a.cu_seqlens = pack.n_tokens, pack.tok_row.data_ptr(), pack.cu.data_ptr()
         if cls is not None:
             a.n_cls, a.cls_rows, a.cls_orig_rows = cls.n_cls, cls.rows.data_ptr(), cls.orig.data_ptr()
+        a.overlap_wgrad = int(self.overlap_wgrad)
         c = self.cfg
         a.batch, a.seq_len, a.n_layers, a.hidden, a.heads, a.intermediate = B, S, c.layers, H, NH, I_FF
         a.vocab_size, a.max_pos, a.type_vocab, a.roberta, a.pad_id, a.inference = (c.vocab_size, c.max_pos, c.type_vocab,

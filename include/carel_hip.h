@@ -232,6 +232,11 @@ typedef struct carel_encoder_args {
    * index), -1 for filler.  The final hidden states (carel_encoder_x_last) are then the n_cls compact rows, and dx is
    * read as n_cls compact rows by the backward of the last layer.  n_cls = 0 disables. */
   int32_t n_cls; const void* cls_rows; const void* cls_orig_rows;
+  /* 1: carel_encoder_backward_layer enqueues the weight-gradient GEMMs (and their slab reductions) on a library-owned
+   * low-priority second stream, forked by events behind the kernel that produced each dY and joined before the call
+   * returns, so that they run beside the data-gradient chain and the memory-bound LayerNorm / attention backward
+   * kernels.  Results are identical (same kernels, same summation order).  0: everything on `stream`. */
+  int32_t overlap_wgrad;
   const carel_layer_grads* layer_grads;     /* HOST array [n_layers] */
   void* d_word_emb; void* d_pos_emb; void* d_type_emb; void* d_emb_ln_g; void* d_emb_ln_b;
   void* dx;

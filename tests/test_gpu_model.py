@@ -299,3 +299,36 @@ def test_cls_only_last_layer_equals_full_computation(golden_dir, name):
     worst = {k: relnorm(g1[k], g0[k]) for k in g0 if float(g0[k].norm()) > 1e-6 and not k.endswith("key.bias")}
     bad = {k: v for k, v in worst.items() if v > 2e-2}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name,varlen,cls_only", [("zh_small", False, False), ("zh_ragged", True, True), ("zh_full12", True, True)])
+def test_wgrad_side_stream_is_bitwise_identical(golden_dir, name, varlen, cls_only):
+    """Weight-gradient GEMMs forked onto the second stream: same kernels, same summation order -> identical bits.
+    Three forward/backward passes back to back (a missing event dependency would show up as a stale or torn operand).
+    Only the embedding tables are exempt from torch.equal: their backward scatters with float atomics."""
+    cfg, opt = CASES[name]
+    opt = O.Opt(**{**vars(opt), "dropout": 0.5})
+    z, batch = load(golden_dir, name)
+    B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
+    res = {}
+    for flag in (False, True):
+        model, P = build(cfg, opt, wseed, train_dropout=True)
+        model.train()
+        model.overlap_wgrad, model.varlen, model.cls_only_last = flag, varlen, cls_only
+        out = []
+        for s in range(3):
+            model.set_noise(torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"]))
+            loss = model(*call(model, batch, it0 + s))
+            for p in model.parameters():
+                p.grad = None
+            loss.backward()
+            out.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+        torch.cuda.synchronize()
+        res[flag] = out
+    for (l0, g0), (l1, g1) in zip(res[False], res[True]):
+        assert l0 == l1
+        for k in g0:
+            if "embeddings.word" in k or "embeddings.position" in k or "embeddings.token_type" in k:
+                assert relnorm(g1[k], g0[k]) < 1e-5, k
+            else:
+                assert torch.equal(g0[k], g1[k]), k
