@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-ecpe", action="store_true", help="skip the secondary ECPE-shaped leg")
     ap.add_argument("--no-varlen", action="store_true", help="run padded positions through the encoder like the reference does")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
+    ap.add_argument("--no-adam-in-backward", action="store_true",
+                    help="run the whole fused Adam in optim.step() instead of layer by layer beside the backward pass")
     ap.add_argument("--no-overlap", action="store_true",
                     help="weight-gradient GEMMs on the main stream (serial kernels: the run to put under rocprofv3 --kernel-trace)")
     return ap.parse_args()
@@ -120,7 +122,7 @@ def main():
     if world > 1 or force_dp:
         from carel_vae_amd.dp import DataParallel
         dp = DataParallel(model)
-    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr)
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=not (a.no_adam_in_backward or a.no_overlap))
 
     ocfg = O.EncoderConfig()
     batches, lengths = [], []
@@ -174,6 +176,7 @@ def main():
     # agrees with `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-overlap --no-ecpe` (profiles/).
     nprof = 3
     model.overlap_wgrad = False
+    hook, model._adam_hook = model._adam_hook, None
     L.check(lib.carel_profile_gemm(1, 200 * nprof))
     for i in range(nprof):
         step(a.warmup + a.steps + i)
@@ -181,6 +184,7 @@ def main():
     ev_timed = read_gemm_events()
     L.check(lib.carel_profile_gemm(0, 0))
     model.overlap_wgrad = not a.no_overlap
+    model._adam_hook = hook
     pairs_per_s = world * a.batch * a.steps / dt
 
     # ---- secondary line: the same step on ECPE-shaped batches (SURVEY 8(d) shape-B: ~77 % padding), padding skipped ----
@@ -241,7 +245,8 @@ def main():
                       "attended_tokens_per_pair": sum(sum(l) for l in lengths) / (len(lengths) * a.batch),
                       "padding_skipped": bool(model.varlen and a.shape == "B"),
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
-                      "wgrad_side_stream": bool(model.overlap_wgrad)},
+                      "wgrad_side_stream": bool(model.overlap_wgrad),
+                      "adam_in_backward": bool(getattr(optim, "_aux", None) is not None and dp is None)},
            "roofline": roof, "ecpe_shaped": ecpe, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):

@@ -14,6 +14,12 @@ int check_launch(const char* what);
 int gather_rows(const void* in_f32, const void* in_bf16, const void* idx, int n, void* out_f32, void* out_bf16, hipStream_t stream);
 int scatter_rows(const void* in_f32, const void* in_bf16, const void* idx, int n, void* out_f32, void* out_bf16, hipStream_t stream);
 
+// LayerNorm backward in two launches that may go to different streams (ln.hip; see carel_layernorm_bwd_packed)
+int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const void* gamma, int64_t rows, uint32_t drop_seed, uint32_t drop_site,
+                       uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32, void* dy_bf16, void* partials,
+                       hipStream_t stream);
+int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);
+
 inline Dropout make_dropout(uint32_t seed, uint32_t site, float p, uint32_t idx_offset) {
   Dropout d;
   d.key = mix32(seed + site * 0x9E3779B9u);

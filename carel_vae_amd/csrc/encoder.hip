@@ -58,8 +58,8 @@ LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
   return r;
 }
 
-struct Scratch { char* dy; char* dyb; char* dyb2; char* du; char* dctx; char* dqkv; char* slabs; char* ws; char* part; };
-struct ScratchLayout { size_t o_dy, o_dyb, o_dyb2, o_du, o_dctx, o_dqkv, o_slabs, o_ws, o_part, ws_bytes, total; };
+struct Scratch { char* dy; char* dyb; char* dyb2; char* du; char* dctx; char* dqkv; char* slabs; char* ws; char* part; char* part2; char* part3; };
+struct ScratchLayout { size_t o_dy, o_dyb, o_dyb2, o_du, o_dctx, o_dqkv, o_slabs, o_ws, o_part, o_part2, o_part3, ws_bytes, total; };
 
 // split-K factor of the weight-gradient GEMMs (K = tokens).  Measured at T = 8192 in the whole step with the
 // weight gradients on the side stream: 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 4
@@ -90,14 +90,16 @@ ScratchLayout scratch_layout(long B, long S) {
   size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;
   const size_t cs = ((T + 255) / 256) * EI * 4;
   part = part > cs ? part : cs;
-  s.o_part = o; o += al(part);
+  s.o_part = o; o += al(part);              // LN2-backward partials (and the embedding backward's)
+  s.o_part2 = o; o += al(part);             // DGELU column-sum partials      } three buffers: their reductions run on the side
+  s.o_part3 = o; o += al(part);             // LN1-backward partials          } stream while the main stream moves on
   s.total = o;
   return s;
 }
 
 Scratch scratch_of(const ScratchLayout& l, char* b) {
   Scratch s; s.dy = b + l.o_dy; s.dyb = b + l.o_dyb; s.dyb2 = b + l.o_dyb2; s.du = b + l.o_du; s.dctx = b + l.o_dctx; s.dqkv = b + l.o_dqkv;
-  s.slabs = b + l.o_slabs; s.ws = b + l.o_ws; s.part = b + l.o_part;
+  s.slabs = b + l.o_slabs; s.ws = b + l.o_ws; s.part = b + l.o_part; s.part2 = b + l.o_part2; s.part3 = b + l.o_part3;
   return s;
 }
 
@@ -125,7 +127,7 @@ int enc_check(const carel_encoder_args* a, const char* who) {
 }
 
 // One low-priority stream + a few events per device, created on first use and kept for the life of the process.
-struct SideStream { static constexpr int NEV = 6; hipStream_t stream; hipEvent_t ev[NEV]; bool ok; };
+struct SideStream { static constexpr int NEV = 6; hipStream_t stream; hipStream_t aux; hipEvent_t ev[NEV]; bool ok; };
 SideStream* side_stream() {
   static SideStream per_dev[16];
   static bool made[16];
@@ -135,7 +137,8 @@ SideStream* side_stream() {
     SideStream& s = per_dev[dev];
     int lo = 0, hi = 0;
     s.ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-           hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) == hipSuccess;     // lo = lowest priority
+           hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) == hipSuccess &&     // lo = lowest priority
+           hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, lo) == hipSuccess;
     for (int i = 0; i < SideStream::NEV && s.ok; ++i) s.ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
     made[dev] = true;
   }
@@ -173,6 +176,12 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
 }
 
 }  // namespace
+
+extern "C" void* carel_side_stream(int32_t which) {
+  SideStream* sd = side_stream();
+  if (!sd) { set_error(CAREL_ERR_HIP, "carel_side_stream: could not create the side streams"); return nullptr; }
+  return which == 0 ? (void*)sd->stream : (void*)sd->aux;
+}
 
 extern "C" int64_t carel_encoder_act_bytes(int32_t batch, int32_t seq_len, int32_t n_layers, int32_t inference) {
   return (int64_t)act_layout(batch, seq_len, n_layers, inference).total;
@@ -288,26 +297,28 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const void* rmap = cls_only ? a->cls_orig_rows : a->tok_row;
   const void* ctx_rows = cls_only ? (const void*)((char*)a->act + l.o_cctx) : (const void*)la.ctx;
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
-  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h2, la.st2, w.ln2_g, R, EH, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout,
-                                       rmap, s.dy, s.dyb, g.ln2_g, g.ln2_b, g.ffn2_b, s.part, stream))) return rc;
+  if ((rc = layernorm_bwd_rows(a->dx, la.h2, la.st2, w.ln2_g, R, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb,
+                               s.part, (hipStream_t)stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
   if ((rc = fork())) return rc;
+  if ((rc = layernorm_bwd_reduce(s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b, (hipStream_t)wstream))) return rc;
   if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream))) return rc;
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
-                      nullptr, la.u, 0, 0, 0, 0.f, stream, s.part))) return rc;
-  if ((rc = carel_partial_reduce_f32(s.part, g.ffn1_b, EI, (int)(R / 128), 0, stream))) return rc;
+                      nullptr, la.u, 0, 0, 0, 0.f, stream, s.part2))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
   if ((rc = fork())) return rc;
+  if ((rc = carel_partial_reduce_f32(s.part2, g.ffn1_b, EI, (int)(R / 128), 0, wstream))) return rc;
   if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream))) return rc;
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
                       nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
   // LN1 backward (its bf16 output goes to a second buffer: the FFN2 weight gradient may still be reading dyb)
-  if ((rc = carel_layernorm_bwd_packed(a->dx, la.h1, la.st1, w.ln1_g, R, EH, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout,
-                                       rmap, s.dy, s.dyb2, g.ln1_g, g.ln1_b, g.out_b, s.part, stream))) return rc;
+  if ((rc = layernorm_bwd_rows(a->dx, la.h1, la.st1, w.ln1_g, R, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb2,
+                               s.part3, (hipStream_t)stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
   void* dctx_rows = cls_only ? (void*)s.dqkv : (void*)s.dctx;     // compact result parks in the (still free) dqkv buffer
   if ((rc = fork())) return rc;
+  if ((rc = layernorm_bwd_reduce(s.part3, R, g.ln1_g, g.ln1_b, g.out_b, (hipStream_t)wstream))) return rc;
   if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream))) return rc;
   if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
                       nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;

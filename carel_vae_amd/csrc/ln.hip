@@ -295,17 +295,27 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
 }
 
 // out[c] (+)= sum_p partials[p][c]   (c < n, p < nparts): 16 columns x 16 row-lanes per block, fixed order
+// Column sums of partials [nparts][n]: PR_COLS columns x 8 part-lanes per block (128-byte segments, four loads in
+// flight per thread), fixed summation order.  Returns the sum in the threads of part-lane 0; c = column.
+constexpr int PR_COLS = 32;
 __device__ __forceinline__ float partial_colsum16(const float* __restrict__ partials, int n, int nparts, float* lds, int& c) {
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  c = blockIdx.x * 16 + cl;
-  float s = 0.f;
-  if (c < n) for (int p = rl; p < nparts; p += 16) s += partials[(long)p * n + c];
-  lds[threadIdx.x] = s;
+  const int cl = threadIdx.x & (PR_COLS - 1), rl = threadIdx.x / PR_COLS;      // rl in [0, 8)
+  c = blockIdx.x * PR_COLS + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    int p = rl;
+    for (; p + 24 < nparts; p += 32) {
+      s0 += partials[(long)p * n + c]; s1 += partials[(long)(p + 8) * n + c];
+      s2 += partials[(long)(p + 16) * n + c]; s3 += partials[(long)(p + 24) * n + c];
+    }
+    for (; p < nparts; p += 8) s0 += partials[(long)p * n + c];
+  }
+  lds[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   float t = 0.f;
   if (rl == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t += lds[r * 16 + cl];
+    for (int r = 0; r < 256 / PR_COLS; ++r) t += lds[r * PR_COLS + cl];
   }
   return t;
 }
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
   __shared__ float lds[256];
   int c;
   const float t = partial_colsum16(partials, n, nparts, lds, c);
-  if ((threadIdx.x >> 4) == 0 && c < n) out[c] = accumulate ? out[c] + t : t;
+  if (threadIdx.x < PR_COLS && c < n) out[c] = accumulate ? out[c] + t : t;
 }
 
 // same reduction, but column c goes to outs.p[c / seg][c % seg] (null pointers are skipped)
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void partial_reduce_seg_kernel(const float* __
   __shared__ float lds[256];
   int c;
   const float t = partial_colsum16(partials, n, nparts, lds, c);
-  if ((threadIdx.x >> 4) == 0 && c < n) {
+  if (threadIdx.x < PR_COLS && c < n) {
     float* o = outs.p[c / seg];
     if (o) o[c % seg] = t;
   }
@@ -470,7 +480,7 @@ extern "C" int carel_embed_ln_bwd(const carel_embed_args* a, const void* dx0, vo
   if (rc) return rc;
   SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dtype_;
   so.p[3] = e.type_vocab > 1 ? (float*)dtype_ + H : nullptr;
-  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((slots * H + 15) / 16), dim3(256), 0, stream, (const float*)partials,
+  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((slots * H + PR_COLS - 1) / PR_COLS), dim3(256), 0, stream, (const float*)partials,
                      so, H, slots * H, nblk);
   return check_launch("partial_reduce_seg_kernel");
 }
@@ -496,23 +506,38 @@ extern "C" int carel_layernorm_bwd(const void* dy, const void* h, const void* st
                                     dy_bf16, dgamma, dbeta, dbias, partials, stream_);
 }
 
+// internal: the row kernel on `stream`, the reduction of its partials on `reduce_stream` (the caller orders the two
+// streams: encoder.hip forks the side stream between the calls); reduce_stream == stream is the plain serial form.
+namespace carel {
+int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const void* gamma, int64_t rows, uint32_t drop_seed, uint32_t drop_site,
+                       uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32, void* dy_bf16, void* partials,
+                       hipStream_t stream) {
+  if (!dy || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_bwd: bad arguments");
+  const int nblk = carel_layernorm_bwd_blocks(rows);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
+                     (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
+                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials);
+  return check_launch("ln_bwd_kernel");
+}
+int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream) {
+  const int nblk = carel_layernorm_bwd_blocks(rows);
+  SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dbias; so.p[3] = nullptr;
+  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((3 * H + PR_COLS - 1) / PR_COLS), dim3(256), 0, stream, (const float*)partials, so,
+                     H, 3 * H, nblk);
+  return check_launch("partial_reduce_seg_kernel");
+}
+}  // namespace carel
+
 extern "C" int carel_layernorm_bwd_packed(const void* dy, const void* h, const void* stats, const void* gamma, int64_t rows,
                                           int32_t hidden, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset,
                                           float drop_p, const void* drop_row_map, void* dh_f32, void* dy_bf16, void* dgamma,
                                           void* dbeta, void* dbias, void* partials, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (hidden != H) return set_error(CAREL_ERR_SHAPE, "carel_layernorm_bwd: hidden must be %d", H);
-  if (!dy || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_bwd: bad arguments");
-  const int nblk = carel_layernorm_bwd_blocks(rows);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
-                     (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
-                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials);
-  int rc = check_launch("ln_bwd_kernel");
+  int rc = layernorm_bwd_rows(dy, h, stats, gamma, rows, drop_seed, drop_site, drop_idx_offset, drop_p, drop_row_map, dh_f32, dy_bf16,
+                              partials, stream);
   if (rc) return rc;
-  SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dbias; so.p[3] = nullptr;
-  hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((3 * H + 15) / 16), dim3(256), 0, stream, (const float*)partials, so,
-                     H, 3 * H, nblk);
-  return check_launch("partial_reduce_seg_kernel");
+  return layernorm_bwd_reduce(partials, rows, dgamma, dbeta, dbias, stream);
 }
 
 extern "C" int carel_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t n, void* out_f32, int32_t accumulate,
@@ -525,7 +550,7 @@ extern "C" int carel_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_
                      (long)rows, n, (float*)partials);
   int rc = check_launch("colsum_bf16_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, (const float*)partials, (float*)out_f32, n,
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + PR_COLS - 1) / PR_COLS), dim3(256), 0, stream, (const float*)partials, (float*)out_f32, n,
                      chunks, accumulate);
   return check_launch("partial_reduce_kernel");
 }
@@ -533,6 +558,6 @@ extern "C" int carel_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_
 extern "C" int carel_partial_reduce_f32(const void* partials, void* out, int32_t n, int32_t nparts, int32_t accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!partials || !out || n <= 0 || nparts <= 0) return set_error(CAREL_ERR_ARG, "carel_partial_reduce_f32: bad arguments");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, (const float*)partials, (float*)out, n, nparts, accumulate);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((n + PR_COLS - 1) / PR_COLS), dim3(256), 0, stream, (const float*)partials, (float*)out, n, nparts, accumulate);
   return check_launch("partial_reduce_kernel");
 }

@@ -333,6 +333,7 @@ class DrlClassifier(nn.Module):
         self._noise = None
         self._ws = {}
         self._dp = None                     # set by carel_vae_amd.dp.DataParallel
+        self._adam_hook = None              # set by FusedAdam(fuse_into_backward=True)
         self._flat = None
         self._flatten()
 
@@ -659,6 +660,8 @@ class DrlClassifier(nn.Module):
         return self._flat_grad[o:o + p.numel()].view(p.shape)
 
     def _run_forward(self, c, training):
+        if self._adam_hook is not None:
+            self._adam_hook._join()          # weight updates still in flight on the auxiliary stream
         self._refresh_shadow()
         train_drop = self.training          # dropout follows module mode (model.train() / .eval()), like nn.Dropout
         ws = self._workspace(c.Bp, c.S, inference=not training)
@@ -704,6 +707,8 @@ class DrlClassifier(nn.Module):
             L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
             if self._dp is not None:
                 self._dp.layer_done(l)
+            elif self._adam_hook is not None and not accumulate:
+                self._adam_hook._layer_ready(l)
         L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
         if self._dp is not None:
             self._dp.backward_done()
@@ -818,9 +823,16 @@ class DrlClassifier(nn.Module):
 class FusedAdam:
     """`torch.optim.Adam(model.get_params(), lr)` (ref :936) as ONE HIP kernel over the flat buffer.
     Same defaults and update order; also rewrites the bf16 shadow weights the GEMMs read.  The reference's
-    optimiser object is only used through zero_grad()/step() (:840-842), which this class provides."""
+    optimiser object is only used through zero_grad()/step() (:840-842), which this class provides.
 
-    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8):
+    fuse_into_backward=True (opt-in): the update of encoder layer l is enqueued on the library's auxiliary stream as
+    soon as `loss.backward()` has finished that layer's gradients, so the memory-bound optimiser pass runs beside the
+    remaining backward GEMMs; `step()` then only updates what is left (embeddings, pooler, heads) and joins.  Same
+    arithmetic, same results -- but the weights move during backward(), so it requires the reference's call pattern
+    zero_grad() -> backward() -> step() (no gradient accumulation, no use of the gradients to decide whether to step);
+    it is ignored under DataParallel (the gradients must be averaged first)."""
+
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fuse_into_backward=False):
         model._require_cuda()
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.step_count = 0
@@ -828,29 +840,67 @@ class FusedAdam:
         self.exp_avg = torch.zeros(n, device=model._flat.device, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.grad_scale = 1.0
-        self.param_groups = [dict(params=model.get_params(), lr=lr, betas=betas, eps=eps)]
+        self.param_groups = [dict(params=model.get_params() if not model._aprx_names else model.get_params()[1], lr=lr, betas=betas, eps=eps)]
+        self._done = []                  # [lo, hi) ranges already updated for the coming step()
+        self._aux = None
+        if fuse_into_backward:
+            ptr = L.load().carel_side_stream(1)
+            if not ptr:
+                raise L.CarelError("carel_side_stream: " + L.load().carel_last_error().decode("utf8", "replace"))
+            self._aux = torch.cuda.ExternalStream(ptr, device=model._flat.device)
+            self._ev = torch.cuda.Event()
+            offs, nl = model._offs, model.cfg.layers
+            starts = [offs[f"encoder.encoder.layer.{l}.attention.self.query.weight"] for l in range(nl)]
+            starts.append(offs["encoder.pooler.dense.weight"])
+            self._layer_ranges = [(starts[l], starts[l + 1]) for l in range(nl)]
+            model._adam_hook = self
 
     def zero_grad(self, set_to_none=True):
         for p in self.model._named.values():
             p.grad = None
 
-    def step(self):
+    def _launch(self, lo, hi, stream, with_skip):
         m = self.model
-        self.step_count += 1
         a = L.AdamArgs()
-        a.param, a.grad = m._flat.data_ptr(), m._flat_grad.data_ptr()
-        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
-        a.shadow_bf16 = m._shadow.data_ptr()
-        a.n, a.step = m._n_opt, self.step_count
+        a.param, a.grad = m._flat.data_ptr() + 4 * lo, m._flat_grad.data_ptr() + 4 * lo
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo
+        a.shadow_bf16 = m._shadow.data_ptr() + 2 * lo
+        a.n, a.step = hi - lo, self.step_count + 1
         a.lr, a.beta1, a.beta2, a.eps = self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps
         a.grad_scale = self.grad_scale
+        a.skip_lo, a.skip_hi, a.skip_flag = 0, 0, None
         call = getattr(m, "_last_call", None)
-        a.skip_lo, a.skip_hi = m._pair_lo, m._pair_hi
-        a.skip_flag = None
-        if call is not None:      # the pair head keeps its weights/moments when its loss term was replaced by 0
+        if with_skip and call is not None and lo <= m._pair_lo and m._pair_hi <= hi:
+            # the pair head keeps its weights/moments when its loss term was replaced by 0
+            a.skip_lo, a.skip_hi = m._pair_lo - lo, m._pair_hi - lo
             off = L.load().carel_tail_pair_dead_offset(call.B, m.opt.ec_dim, m.opt.pair_bow_dim)
             a.skip_flag = call.buf.work.data_ptr() + off * 4
-        L.check(L.load().carel_adam_step(C.byref(a), L.current_stream()), "carel_adam_step")
+        L.check(L.load().carel_adam_step(C.byref(a), stream), "carel_adam_step")
+
+    def _layer_ready(self, layer):
+        """Called by the model's backward when encoder layer `layer` has all its gradients (main stream)."""
+        lo, hi = self._layer_ranges[layer]
+        self._ev.record()
+        self._aux.wait_event(self._ev)
+        self._launch(lo, hi, C.c_void_p(self._aux.cuda_stream), with_skip=False)
+        self._done.append((lo, hi))
+
+    def _join(self):
+        if self._aux is not None and self._done:
+            torch.cuda.current_stream().wait_stream(self._aux)
+
+    def step(self):
+        m = self.model
+        lo = 0
+        for dlo, dhi in sorted(self._done):             # whatever backward() has not updated yet
+            if dlo > lo:
+                self._launch(lo, dlo, L.current_stream(), with_skip=True)
+            lo = max(lo, dhi)
+        if lo < m._n_opt:
+            self._launch(lo, m._n_opt, L.current_stream(), with_skip=True)
+        self._join()
+        self._done = []
+        self.step_count += 1
         m.mark_shadow_fresh()
 
     def state_dict(self):

@@ -242,6 +242,10 @@ typedef struct carel_encoder_args {
   void* dx;
 } carel_encoder_args;
 
+/* The library's two low-priority streams of the current device (created on first use, never destroyed):
+ * 0 = the weight-gradient stream used by overlap_wgrad, 1 = an auxiliary stream the host side uses for work that may
+ * trail the backward pass (the per-layer Adam updates of FusedAdam(fuse_into_backward=True)).  NULL on failure. */
+void* carel_side_stream(int32_t which);
 int64_t carel_encoder_act_bytes(int32_t batch, int32_t seq_len, int32_t n_layers, int32_t inference);
 int64_t carel_encoder_scratch_bytes(int32_t batch, int32_t seq_len);
 /* device pointer (inside act) of the final hidden states, f32 [B*S, 768] */
