@@ -127,7 +127,7 @@ int enc_check(const carel_encoder_args* a, const char* who) {
 }
 
 // One low-priority stream + a few events per device, created on first use and kept for the life of the process.
-struct SideStream { static constexpr int NEV = 6; hipStream_t stream; hipStream_t aux; hipEvent_t ev[NEV]; bool ok; };
+struct SideStream { static constexpr int NEV = 6; hipStream_t stream; hipStream_t aux; hipStream_t peer; hipEvent_t ev[NEV]; bool ok; };
 SideStream* side_stream() {
   static SideStream per_dev[16];
   static bool made[16];
@@ -138,7 +138,8 @@ SideStream* side_stream() {
     int lo = 0, hi = 0;
     s.ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
            hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) == hipSuccess &&     // lo = lowest priority
-           hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, lo) == hipSuccess;
+           hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, lo) == hipSuccess &&
+           hipStreamCreateWithFlags(&s.peer, hipStreamNonBlocking) == hipSuccess;               // default priority: the second forward chain
     for (int i = 0; i < SideStream::NEV && s.ok; ++i) s.ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
     made[dev] = true;
   }
@@ -207,36 +208,38 @@ static carel_embed_args embed_args_of(const carel_encoder_args* a, const ActLayo
   return e;
 }
 
-extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) {
-  int rc = enc_check(a, "carel_encoder_forward");
-  if (rc) return rc;
-  if (!a->word_emb || !a->pos_emb || !a->type_emb || !a->emb_ln_g || !a->emb_ln_b) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: null embedding tensor");
-  const long B = a->batch, S = a->seq_len, T = n_rows_of(a);     // T = rows actually processed (packed or dense)
+// Layers [l0, l1) of the forward pass for the samples [b0, b0 + nb).  Dense mode: their rows [b0*S, (b0+nb)*S) of every
+// activation buffer; packed mode and the [CLS]-only last layer exist for the whole batch only (b0 = 0, nb = batch).
+static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, long nb, void* stream, char* ws, size_t ws_bytes) {
+  int rc;
+  const long B = a->batch, S = a->seq_len;
+  const bool whole = b0 == 0 && nb == B;
+  const long T = whole ? n_rows_of(a) : nb * S;                  // rows processed by this call
+  const long r0 = b0 * S;                                        // first row (dense)
   const ActLayout l = act_layout(B, S, a->n_layers, a->inference);
   char* base = (char*)a->act;
-  char* xa = base + l.o_xa;
-  char* xb = base + l.o_xb;
-  const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
-  const ScratchLayout sl = scratch_layout(B, S);
-  char* ws = a->scratch ? (char*)a->scratch + sl.o_ws : nullptr;          // split-K workspace for small (packed) batches
-  const size_t ws_bytes = a->scratch ? sl.ws_bytes : 0;
-  LayerAct la = layer_act(l, base, 0, a->inference);
-  carel_embed_args e = embed_args_of(a, l, la);
-  if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
-  for (int i = 0; i < a->n_layers; ++i) {
+  char* xa = base + l.o_xa + (size_t)r0 * EH * 4;
+  char* xb = base + l.o_xb + (size_t)r0 * EH * 4;
+  const uint32_t hoff = (a->drop_row_offset + (uint32_t)b0) * (uint32_t)(S * EH), aoff = (a->drop_row_offset + (uint32_t)b0) * (uint32_t)(ENH * S * S);
+  for (int i = l0; i < l1; ++i) {
     const carel_layer_params& w = a->layers[i];
-    la = layer_act(l, base, i, a->inference);
+    LayerAct la = layer_act(l, base, i, a->inference);
+    la.xin_bf16 += (size_t)r0 * EH * 2; la.qkv += (size_t)r0 * 3 * EH * 2; la.lse += (size_t)b0 * ENH * S * 4; la.ctx += (size_t)r0 * EH * 2;
+    la.h1 += (size_t)r0 * EH * 4; la.st1 += (size_t)r0 * 2 * 4; la.x1_bf16 += (size_t)r0 * EH * 2; la.u += (size_t)r0 * EI * 2;
+    la.g += (size_t)r0 * EI * 2; la.h2 += (size_t)r0 * EH * 4; la.st2 += (size_t)r0 * 2 * 4;
     if ((rc = gemm_call(la.xin_bf16, w.qkv_w, EH, EH, (int)T, 3 * EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_BF16, 1, la.qkv, nullptr, nullptr,
                         w.qkv_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     carel_attn_args at;
-    at.qkv = la.qkv; at.attention_mask = a->attention_mask; at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
-    at.batch = (int)B; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
+    at.qkv = la.qkv; at.attention_mask = a->attention_mask ? (const void*)((const long*)a->attention_mask + b0 * S) : nullptr;
+    at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
+    at.batch = (int)nb; at.seq_len = (int)S; at.heads = ENH; at.head_dim = 64;
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
-    at.cu_seqlens = a->cu_seqlens;
+    at.cu_seqlens = whole ? a->cu_seqlens : nullptr;
     if ((rc = carel_attention_fwd(&at, stream))) return rc;
     const bool cls_only = a->n_cls > 0 && i + 1 == a->n_layers;
+    if (cls_only && !whole) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: internal: [CLS]-only layer on a partial batch");
     long R = T;                                  // rows of the row-wise half of this layer
-    const void* Actx = la.ctx; const void* res1 = xa; const void* rmap = a->tok_row;
+    const void* Actx = la.ctx; const void* res1 = xa; const void* rmap = whole ? a->tok_row : nullptr;
     if (cls_only) {                              // only the [CLS] rows of the last layer are ever read
       R = a->n_cls;
       char* cctx = base + l.o_cctx; char* cxres = base + l.o_cxres;
@@ -250,10 +253,41 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
                         w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes))) return rc;
-    void* next_bf16 = nullptr;
-    if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16;
+    char* next_bf16 = nullptr;
+    if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16 + (size_t)r0 * EH * 2;
     if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, xa, next_bf16, la.st2, stream))) return rc;
   }
+  return CAREL_OK;
+}
+
+extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) {
+  int rc = enc_check(a, "carel_encoder_forward");
+  if (rc) return rc;
+  if (!a->word_emb || !a->pos_emb || !a->type_emb || !a->emb_ln_g || !a->emb_ln_b) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: null embedding tensor");
+  const long B = a->batch, S = a->seq_len;
+  const ActLayout l = act_layout(B, S, a->n_layers, a->inference);
+  const ScratchLayout sl = scratch_layout(B, S);
+  char* ws = a->scratch ? (char*)a->scratch + sl.o_ws : nullptr;          // split-K workspace for small (packed) batches
+  const size_t ws_bytes = a->scratch ? sl.ws_bytes : 0;
+  LayerAct la = layer_act(l, (char*)a->act, 0, a->inference);
+  carel_embed_args e = embed_args_of(a, l, la);
+  if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
+  // Samples are independent through the whole encoder: with a->overlap_wgrad (dense rows, even batch) the two halves of
+  // the batch run as two chains, one on `stream`, one on a peer stream of the same priority, so that each chain's launch gaps, tile-count
+  // tails and memory-bound kernels are filled by the other's GEMMs.  The (optionally [CLS]-only) last layer runs whole.
+  const long hb = B / 2;
+  const int lsplit = a->n_cls > 0 ? a->n_layers - 1 : a->n_layers;
+  SideStream* sd = nullptr;
+  if (a->overlap_wgrad && !a->tok_row && (B & 1) == 0 && (hb * S) % 128 == 0 && lsplit >= 1 && a->scratch) sd = side_stream();
+  if (!sd) return forward_layers(a, 0, a->n_layers, 0, B, stream, ws, ws_bytes);
+  if (hipEventRecord(sd->ev[0], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->peer, sd->ev[0], 0) != hipSuccess)
+    return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event fork failed");
+  char* ws2 = (char*)a->scratch + sl.o_slabs;                    // the weight-gradient slabs are idle during the forward pass
+  if ((rc = forward_layers(a, 0, lsplit, hb, hb, (void*)sd->peer, ws2, sl.ws_bytes))) return rc;
+  if ((rc = forward_layers(a, 0, lsplit, 0, hb, stream, ws, ws_bytes))) return rc;
+  if (hipEventRecord(sd->ev[1], sd->peer) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, sd->ev[1], 0) != hipSuccess)
+    return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event join failed");
+  if (lsplit < a->n_layers) return forward_layers(a, lsplit, a->n_layers, 0, B, stream, ws, ws_bytes);
   return CAREL_OK;
 }
 
