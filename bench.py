@@ -246,7 +246,7 @@ def main():
                       "padding_skipped": bool(model.varlen and a.shape == "B"),
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
                       "wgrad_side_stream": bool(model.overlap_wgrad),
-                      "adam_in_backward": bool(getattr(optim, "_aux", None) is not None and dp is None)},
+                      "adam_in_backward": bool(getattr(optim, "_aux", None) is not None)},
            "roofline": roof, "ecpe_shaped": ecpe, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):

@@ -630,6 +630,16 @@ __global__ __launch_bounds__(256) void tail_dlat_kernel(const float* __restrict_
   dlat[(long)b * 4 * D + (2 * side + 1) * D + kk] = (dlat_direct[(long)b * 4 * D + (2 * side + 1) * D + kk] + g * ep * expf(lv)) * gout;
 }
 
+// z = [mu_e + eps_e * exp(lv_e) | mu_c + eps_c * exp(lv_c)]   (sample_prior :345-351; same expression as in tail_core_kernel)
+__global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__ lat, const float* __restrict__ eps_e,
+                                                       const float* __restrict__ eps_c, int B, int D, float* __restrict__ z) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * 2 * D) return;
+  const int b = e / (2 * D), k = e - b * 2 * D;
+  const float* row = lat + (long)b * 4 * D;
+  z[e] = (k < D) ? row[k] + eps_e[k] * expf(row[D + k]) : row[2 * D + (k - D)] + eps_c[k - D] * expf(row[3 * D + (k - D)]);
+}
+
 // eval-mode pair probabilities (get_pair_preds :265-282): sigmoid(w . [mu_e + eps_e e^lv_e, mu_c + eps_c e^lv_c] + b)
 __global__ __launch_bounds__(256) void pair_prob_kernel(const float* __restrict__ lat, const float* __restrict__ eps_e,
                                                         const float* __restrict__ eps_c, const float* __restrict__ w,
@@ -714,6 +724,9 @@ extern "C" int carel_tail_latents(const carel_tail_args* a, void* stream_) {
   const int N = 4 * a->ec_dim;
   hipLaunchKernelGGL(rowvec_linear_kernel<0>, dim3((N + 3) / 4, sample_groups(N)), dim3(256), 0, stream, (const float*)a->pooled, (long)TH,
                      (const int*)nullptr, a->batch, N, a->ec_dim, hp, (float*)a->lat, (long)N);
+  if (a->eps_e && a->eps_c && a->z)      // the sampled embeddings, for callers that exchange them before carel_tail_losses (data parallel)
+    hipLaunchKernelGGL(sample_z_kernel, dim3((a->batch * 2 * a->ec_dim + 255) / 256), dim3(256), 0, stream, (const float*)a->lat,
+                       (const float*)a->eps_e, (const float*)a->eps_c, a->batch, a->ec_dim, (float*)a->z);
   return check_launch("tail latents");
 }
 

@@ -30,13 +30,15 @@ class FlatGradReducer:
         self.pending = []
 
     def reduce(self, name):
+        """Start the all-reduce of one bucket; returns its work handle (None for an empty bucket)."""
         lo, hi = self.buckets[name]
         if hi <= lo:
-            return
+            return None
         view = self.flat[lo:hi]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         work = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self.pending.append((work, view))
+        return work
 
     def wait(self):
         for work, view in self.pending:
@@ -100,7 +102,10 @@ class DataParallel:
         self.reducer.reduce("tail")
 
     def layer_done(self, layer):
-        self.reducer.reduce(f"layer{layer}")
+        """-> work handle of the layer's all-reduce when the averaged gradients need no further host-side step (RCCL's
+        AVG), else None (gloo: the division happens in backward_done)."""
+        work = self.reducer.reduce(f"layer{layer}")
+        return work if self.reducer.use_avg else None
 
     def backward_done(self):
         self.reducer.reduce("embeddings")

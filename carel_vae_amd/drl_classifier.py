@@ -705,10 +705,9 @@ class DrlClassifier(nn.Module):
             self._dp.tail_done()
         for l in range(self.cfg.layers - 1, -1, -1):
             L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
-            if self._dp is not None:
-                self._dp.layer_done(l)
-            elif self._adam_hook is not None and not accumulate:
-                self._adam_hook._layer_ready(l)
+            work = self._dp.layer_done(l) if self._dp is not None else None
+            if self._adam_hook is not None and not accumulate and (self._dp is None or work is not None):
+                self._adam_hook._layer_ready(l, after=work)
         L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
         if self._dp is not None:
             self._dp.backward_done()
@@ -829,8 +828,8 @@ class FusedAdam:
     soon as `loss.backward()` has finished that layer's gradients, so the memory-bound optimiser pass runs beside the
     remaining backward GEMMs; `step()` then only updates what is left (embeddings, pooler, heads) and joins.  Same
     arithmetic, same results -- but the weights move during backward(), so it requires the reference's call pattern
-    zero_grad() -> backward() -> step() (no gradient accumulation, no use of the gradients to decide whether to step);
-    it is ignored under DataParallel (the gradients must be averaged first)."""
+    zero_grad() -> backward() -> step() (no gradient accumulation, no use of the gradients to decide whether to step).
+    Under DataParallel (RCCL) each layer's update additionally waits for that layer's gradient all-reduce."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fuse_into_backward=False):
         model._require_cuda()
@@ -877,11 +876,16 @@ class FusedAdam:
             a.skip_flag = call.buf.work.data_ptr() + off * 4
         L.check(L.load().carel_adam_step(C.byref(a), stream), "carel_adam_step")
 
-    def _layer_ready(self, layer):
-        """Called by the model's backward when encoder layer `layer` has all its gradients (main stream)."""
+    def _layer_ready(self, layer, after=None):
+        """Called by the model's backward when encoder layer `layer` has all its gradients on the main stream; under
+        DataParallel `after` is the work handle of the layer's gradient all-reduce (RCCL), which the update waits for."""
         lo, hi = self._layer_ranges[layer]
-        self._ev.record()
-        self._aux.wait_event(self._ev)
+        if after is not None:
+            with torch.cuda.stream(self._aux):
+                after.wait()                 # stream-side wait: the auxiliary stream blocks until the collective is done
+        else:
+            self._ev.record()
+            self._aux.wait_event(self._ev)
         self._launch(lo, hi, C.c_void_p(self._aux.cuda_stream), with_skip=False)
         self._done.append((lo, hi))
 

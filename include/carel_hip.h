@@ -314,6 +314,8 @@ typedef struct carel_tail_args {
 } carel_tail_args;
 
 int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim);
+/* pooled, lat and -- when eps_e / eps_c / z are given -- the sampled embeddings z (so that a data-parallel caller can
+ * all-gather z before carel_tail_losses, which recomputes the same z) */
 int carel_tail_latents(const carel_tail_args* args, void* stream);
 int carel_tail_losses(const carel_tail_args* args, void* stream);
 /* Measurement aid: while a device buffer of 16 int64 is registered, the fused loss kernel of carel_tail_losses writes
