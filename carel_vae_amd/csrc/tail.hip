@@ -173,6 +173,7 @@ struct TailCore {
   float alpha, mmd_eps;
   const float* label_sum_override; float n_override;   // global-batch pos_weight (DP); null/0 = local
   const float* z_global; int n_global, row_offset; float mmd_grad_scale;  // global-batch MMD (DP)
+  int rank_stride;              // floats between consecutive ranks' blocks of B rows in z_global (B*2D when dense)
   // outputs
   float* z;                     // [B, 2D]
   float* terms;                 // [16]: 0 partial loss (everything but rec), 1 mmd, 2 emo, 3 cau, 4 pair, 5 kl_e, 6 kl_c
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   for (int e = t; e < 2 * nm * D; e += blockDim.x) {
     const int i = e / D, k = e - i * D;
     const int s = i < nm ? i : i - nm, off = i < nm ? 0 : D;
-    Z[i * zs + k] = a.z_global ? a.z_global[(long)s * D2 + off + k] : zl[s * D2 + off + k];
+    Z[i * zs + k] = a.z_global ? a.z_global[(long)(s / B) * a.rank_stride + (long)(s % B) * D2 + off + k] : zl[s * D2 + off + k];
   }
   __syncthreads();
   TAIL_STAMP(1);
@@ -771,6 +772,9 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   c.alpha = a->mmd_alpha; c.mmd_eps = a->mmd_eps;
   c.label_sum_override = (const float*)a->global_label_sum; c.n_override = (float)a->global_n;
   c.z_global = (const float*)a->z_global; c.n_global = a->global_n; c.row_offset = a->global_row_offset;
+  c.rank_stride = a->global_rank_stride > 0 ? a->global_rank_stride : B * 2 * D;
+  if (c.z_global && a->global_rank_stride > 0 && (a->global_rank_stride < B * 2 * D || c.n_global % B))
+    return set_error(CAREL_ERR_ARG, "carel_tail_losses: global_rank_stride needs global_n to be a multiple of batch and stride >= batch*2*ec_dim");
   c.mmd_grad_scale = a->mmd_grad_scale > 0.f ? a->mmd_grad_scale : 1.f;
   if (c.z_global && (c.n_global < 2 || c.row_offset < 0 || c.row_offset + B > c.n_global))
     return set_error(CAREL_ERR_ARG, "carel_tail_losses: inconsistent global batch description");

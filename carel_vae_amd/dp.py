@@ -60,6 +60,9 @@ class DataParallel:
         self.global_batch_terms = global_batch_terms
         model._dp = self
         dist.broadcast(model._flat, src=0, group=group)        # identical replicas
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(model._flat.device)
+        dist.broadcast(seed, src=0, group=group)
+        self._noise_seed, self._noise_gen = int(seed.item()), None
         model._shadow_versions = None
         self.reducer = FlatGradReducer(model._flat_grad, self._buckets(model), group)
 
@@ -83,20 +86,33 @@ class DataParallel:
         n = eps_e.numel()
         return both[:n].contiguous(), both[n:].contiguous()
 
+    def draw_noise(self, n, device):
+        """The two reparameterisation noise vectors, identical on every rank WITHOUT a collective: a per-device generator
+        seeded once (at construction) with a seed broadcast from rank 0."""
+        if self._noise_gen is None or self._noise_gen.device != torch.device(device):
+            self._noise_gen = torch.Generator(device=device)
+            self._noise_gen.manual_seed(self._noise_seed)
+        return (torch.randn(n, device=device, generator=self._noise_gen), torch.randn(n, device=device, generator=self._noise_gen))
+
     def fill_global(self, ta, call):
-        """All-gather the sampled latents and all-reduce the label sum; point the tail at them."""
+        """ONE all-gather carries the sampled latents and each rank's label sum; point the tail at the result."""
         if not self.global_batch_terms:
             return
         z = call.buf.z
-        z_all = torch.empty((self.world * z.shape[0], z.shape[1]), device=z.device, dtype=z.dtype)
-        dist.all_gather_into_tensor(z_all, z, group=self.group)
-        ysum = call.labels["pair"].sum().reshape(1)
-        dist.all_reduce(ysum, op=dist.ReduceOp.SUM, group=self.group)
-        ta.z_global, ta.global_n = z_all.data_ptr(), z_all.shape[0]
+        n = z.numel()
+        stride = n + 16                                  # 16 spare floats per rank; [n] = the rank's label sum
+        mine = torch.empty(stride, device=z.device, dtype=z.dtype)
+        mine[:n] = z.reshape(-1)
+        mine[n:] = call.labels["pair"].sum()
+        flat = torch.empty(self.world * stride, device=z.device, dtype=z.dtype)
+        dist.all_gather_into_tensor(flat, mine, group=self.group)
+        gathered = flat.view(self.world, stride)
+        ysum = gathered[:, n].sum().reshape(1)
+        ta.z_global, ta.global_n, ta.global_rank_stride = gathered.data_ptr(), self.world * z.shape[0], stride
         ta.global_row_offset = self.rank * z.shape[0]
         ta.global_label_sum = ysum.data_ptr()
         ta.mmd_grad_scale = float(self.world)       # gradients are averaged over ranks afterwards
-        call.dp_keep = (z_all, ysum)
+        call.dp_keep = (gathered, ysum)
 
     def tail_done(self):
         self.reducer.reduce("tail")

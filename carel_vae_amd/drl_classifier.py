@@ -610,10 +610,10 @@ class DrlClassifier(nn.Module):
             self._noise = None
             return e.to(dev, torch.float32).contiguous(), c.to(dev, torch.float32).contiguous()
         D = self.opt.ec_dim
+        if self._dp is not None:                     # same draws on every rank, no collective
+            return self._dp.draw_noise(D, dev)
         eps_e = torch.randn(D, device=dev)           # emotion first, then cause (ref :215-216)
         eps_c = torch.randn(D, device=dev)
-        if self._dp is not None:
-            eps_e, eps_c = self._dp.broadcast_noise(eps_e, eps_c)
         return eps_e, eps_c
 
     # ------------------------------------------------------------------ forward / backward bodies

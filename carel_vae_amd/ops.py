@@ -100,7 +100,7 @@ class TailBuffers:
 
 
 def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight, *, grads=None, drop=(0.0, 0, 0),
-              global_label_sum=None, global_n=0, global_row_offset=0, z_global=None, mmd_grad_scale=1.0, cls_rows=None,
+              global_label_sum=None, global_n=0, global_row_offset=0, z_global=None, mmd_grad_scale=1.0, global_rank_stride=0, cls_rows=None,
               n_rows=0):
     """W / grads: dicts keyed by the reference's state_dict names (tail part)."""
     a = L.TailArgs()
@@ -136,6 +136,7 @@ def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight,
     a.global_n, a.global_row_offset = global_n, global_row_offset
     a.z_global = None if z_global is None else z_global.data_ptr()
     a.mmd_grad_scale = mmd_grad_scale
+    a.global_rank_stride = global_rank_stride
     a.pooled, a.lat, a.z, a.terms, a.work = (buf.pooled.data_ptr(), buf.lat.data_ptr(), buf.z.data_ptr(),
                                              buf.terms.data_ptr(), buf.work.data_ptr())
     a.dx_last_f32 = buf.dx_last.data_ptr()

@@ -298,6 +298,8 @@ typedef struct carel_tail_args {
   int32_t global_n, global_row_offset;
   const void* z_global;              /* f32 [global_n, 2*ec_dim] or NULL */
   float mmd_grad_scale;
+  int32_t global_rank_stride;        /* 0: z_global is dense; else floats between the blocks of `batch` rows contributed by
+                                        consecutive ranks (lets one all-gather carry z plus a few extra floats per rank) */
   /* outputs */
   void* pooled;                      /* f32 [B, 768] */
   void* lat;                         /* f32 [B, 4*ec_dim] */

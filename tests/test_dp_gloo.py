@@ -48,14 +48,23 @@ def _worker(rank, world, port, q):
         ok_buckets = b["embeddings"] == (0, 64) and b["layer0"] == (64, 192) and b["layer1"] == (192, 320) and b["tail"] == (320, total)
         e, c = dp.broadcast_noise(torch.full((24,), float(rank)), torch.full((24,), 10.0 + rank))
         ok_noise = bool((e == 0).all() and (c == 10).all())
+        # collective-free noise: every rank draws the same vectors from a generator seeded by rank 0's broadcast seed
+        torch.manual_seed(1234 + rank)                # the global streams differ per rank; the shared generator must not
+        e1, c1 = dp.draw_noise(24, "cpu")
+        e2, c2 = dp.draw_noise(24, "cpu")
+        both = [torch.empty(96) for _ in range(world)]
+        dist.all_gather(both, torch.cat((e1, c1, e2, c2)))
+        ok_noise = ok_noise and all(torch.equal(b, both[0]) for b in both) and not torch.equal(e1, e2) and not torch.equal(e1, c1)
         B = 4
         call = SimpleNamespace(buf=SimpleNamespace(z=torch.full((B, 48), float(rank))), labels={"pair": torch.ones(B) * (rank == 0)})
         ta = L.TailArgs()
         dp.fill_global(ta, call)
-        z_all, ysum = call.dp_keep
+        gathered, ysum = call.dp_keep            # [world, B*48 + 16]: rank r's z, then its label sum
         ok_global = (ta.global_n == world * B and ta.global_row_offset == rank * B and ta.mmd_grad_scale == float(world)
-                     and float(ysum) == B and bool((z_all[:B] == 0).all()) and bool((z_all[B:] == 1).all())
-                     and ta.z_global == z_all.data_ptr())
+                     and ta.global_rank_stride == B * 48 + 16 and gathered.shape == (world, B * 48 + 16)
+                     and float(ysum) == B and bool((gathered[0, :B * 48] == 0).all()) and bool((gathered[1, :B * 48] == 1).all())
+                     and float(gathered[0, B * 48]) == B and float(gathered[1, B * 48]) == 0.0
+                     and ta.z_global == gathered.data_ptr())
         dp.tail_done(); dp.layer_done(1); dp.layer_done(0); dp.backward_done()
         ok_avg = bool(torch.allclose(model._flat_grad, torch.full((total,), (1.0 + 2.0) / 2)))
         ok_rows = dp.row_offset(B) == rank * B

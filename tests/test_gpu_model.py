@@ -337,41 +337,41 @@ def test_wgrad_side_stream_is_bitwise_identical(golden_dir, name, varlen, cls_on
 @pytest.mark.parametrize("name", ["zh_small", "zh_allneg"])
 def test_adam_fused_into_backward_equals_plain_step(golden_dir, name):
     """FusedAdam(fuse_into_backward=True) applies each encoder layer's update on the auxiliary stream while the backward
-    pass is still running; the trajectory must equal the plain zero_grad / backward / step one.  After the first step
-    (no history) everything but the atomically scattered embedding tables must be bit-identical; later steps are judged
-    against the run-to-run spread of the plain mode itself (Adam turns the embedding backward's rounding noise into
-    +-lr steps wherever a gradient is ~0)."""
+    pass is still running; the result must equal the plain zero_grad / backward / step one.  After the first step (no
+    history) everything but the atomically scattered embedding tables must be bit-identical; after the second step
+    (moments and step count carried over) the runs may differ by the rounding noise of that scatter only.  Longer
+    trajectories are not comparable: maximising the MMD makes the dynamics expansive, and two runs of the SAME mode
+    drift apart by 1e-4 in the loss within four steps."""
     cfg, opt = CASES[name]
     opt = O.Opt(**{**vars(opt), "dropout": 0.3})
     z, batch = load(golden_dir, name)
     B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
     res = {}
-    for tag, fused in (("plain", False), ("plain2", False), ("fused", True)):
+    for fused in (False, True):
         model, P = build(cfg, opt, wseed, train_dropout=True)
         model.train()
         optim = M.FusedAdam(model, lr=1e-5, fuse_into_backward=fused)
-        losses, first = [], None
-        for s in range(4):
+        losses, snaps = [], []
+        for s in range(2):
             model.set_noise(torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"]))
             loss = model(*call(model, batch, it0 + s))
             optim.zero_grad()
             loss.backward()
             optim.step()
             losses.append(float(loss.detach()))
-            if s == 0:
-                torch.cuda.synchronize()
-                first = {k: p.detach().clone() for k, p in model.named_parameters()}
-        torch.cuda.synchronize()
-        assert optim._done == []
-        res[tag] = (losses, first, {k: p.detach().clone() for k, p in model.named_parameters()})
+            torch.cuda.synchronize()
+            snaps.append({k: p.detach().clone() for k, p in model.named_parameters()})
+        assert optim._done == [] and optim.step_count == 2
+        res[fused] = (losses, snaps, optim.exp_avg.clone(), optim.exp_avg_sq.clone())
     noisy = ("embeddings.word", "embeddings.position", "embeddings.token_type")
-    for k, w in res["plain"][1].items():
+    moved = 0
+    for k, w in res[False][1][0].items():
         if not any(n in k for n in noisy):
-            assert torch.equal(w, res["fused"][1][k]), k
-        assert not torch.equal(w, P[k].cuda()) or k.startswith(O.UNOPTIMISED_PREFIXES) or (name == "zh_allneg" and k.startswith("pair_classifier")), k
-    spread = max(abs(a - b) for a, b in zip(res["plain"][0], res["plain2"][0]))
-    for a, b in zip(res["plain"][0], res["fused"][0]):
-        assert abs(a - b) <= 5 * spread + 1e-5 * max(abs(a), 1.0), (res["plain"][0], res["plain2"][0], res["fused"][0])
-    wspread = max(relnorm(res["plain2"][2][k], res["plain"][2][k]) for k in res["plain"][2])
-    for k in res["plain"][2]:
-        assert relnorm(res["fused"][2][k], res["plain"][2][k]) <= 5 * wspread + 1e-7, k
+            assert torch.equal(w, res[True][1][0][k]), k
+        moved += int(not torch.equal(w, P[k].cuda()))
+    assert moved >= len(res[False][1][0]) - 12         # everything optimised did move (latent heads / dead pair head stay)
+    for a, b in zip(res[False][0], res[True][0]):
+        assert abs(a - b) <= 1e-5 * max(abs(a), 1.0), (res[False][0], res[True][0])
+    for k in res[False][1][1]:
+        assert relnorm(res[True][1][1][k], res[False][1][1][k]) <= 1e-6, k
+    assert relnorm(res[True][2], res[False][2]) < 1e-4 and relnorm(res[True][3], res[False][3]) < 1e-4

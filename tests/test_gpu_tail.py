@@ -85,8 +85,10 @@ def test_tail_matches_oracle(B, V, train, allneg):
     close(buf.dx_last, dx, 2e-4, 2e-5 * scale, "dx_last")
 
 
-def test_tail_global_batch_hooks():
-    """Two shards of a 32-sample batch with the DP hooks == the oracle on the unsharded batch."""
+@pytest.mark.parametrize("strided", [False, True])
+def test_tail_global_batch_hooks(strided):
+    """Two shards of a 32-sample batch with the DP hooks == the oracle on the unsharded batch.  strided: the gathered
+    latents in the layout of DataParallel.fill_global (each rank's z followed by 16 spare floats)."""
     B, S, V, it, seed, R = 32, 2, 300, 3, 9, 2
     cfg, opt, P, x_last, batch, eps_e, eps_c = setup(B, S, V, seed=5)
     out, pooled, grads, dx = oracle_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, it, True, seed)
@@ -102,12 +104,19 @@ def test_tail_global_batch_hooks():
         buf, _ = hip_tail(P, xl, sb, eps_e, eps_c, opt, Bl, S, V, it, (opt.dropout, seed, r * Bl))
         zs.append(buf.z.clone())
     zg = torch.cat(zs, dim=0).contiguous()
+    stride = 0
+    if strided:
+        stride = Bl * 48 + 16
+        packed = torch.full((R, stride), float("nan"), device="cuda")
+        for r in range(R):
+            packed[r, :Bl * 48] = zs[r].reshape(-1)
+        zg = packed
     ysum = batch["labels"].sum().reshape(1).cuda()
     tot = {k: torch.zeros_like(v) for k, v in P.items()}
     loss = 0.0
     for r, (sb, xl) in enumerate(shards):
         buf, G = hip_tail(P, xl, sb, eps_e, eps_c, opt, Bl, S, V, it, (opt.dropout, seed, r * Bl), global_label_sum=ysum,
-                          global_n=B, global_row_offset=r * Bl, z_global=zg, mmd_grad_scale=float(R))
+                          global_n=B, global_row_offset=r * Bl, z_global=zg, mmd_grad_scale=float(R), global_rank_stride=stride)
         for k in tot:
             tot[k] += G[k].cpu() / R          # gradient averaging over ranks
         t = buf.terms.cpu().numpy()
