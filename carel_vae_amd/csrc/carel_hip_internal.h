@@ -20,6 +20,9 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        hipStream_t stream);
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);
 
+int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,
+                    void* partials, void* row_scratch, hipStream_t stream);
+
 inline Dropout make_dropout(uint32_t seed, uint32_t site, float p, uint32_t idx_offset) {
   Dropout d;
   d.key = mix32(seed + site * 0x9E3779B9u);

@@ -407,5 +407,6 @@ extern "C" int carel_encoder_backward_embeddings(const carel_encoder_args* a, vo
   hipError_t he = hipMemsetAsync(a->d_word_emb, 0, (size_t)a->vocab_size * EH * 4, (hipStream_t)stream);
   if (he == hipSuccess) he = hipMemsetAsync(a->d_pos_emb, 0, (size_t)a->max_pos * EH * 4, (hipStream_t)stream);
   if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_embeddings: memset: %s", hipGetErrorString(he));
-  return carel_embed_ln_bwd(&e, a->dx, a->d_word_emb, a->d_pos_emb, a->d_type_emb, a->d_emb_ln_g, a->d_emb_ln_b, s.part, stream);
+  // s.dy (f32 [T, 768]) is free here: scratch for the fixed-order position-table reduction
+  return embed_ln_bwd_ex(&e, a->dx, a->d_word_emb, a->d_pos_emb, a->d_type_emb, a->d_emb_ln_g, a->d_emb_ln_b, s.part, s.dy, (hipStream_t)stream);
 }

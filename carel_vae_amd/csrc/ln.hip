@@ -237,12 +237,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   write_partials(lds, accBias, dst + 2 * H, lane, wave);
 }
 
+// dpos[s][c] = sum_b rows[(b*S + s)][c]   (dense BERT positions; one thread per 4 columns, fixed order over the batch)
+__global__ __launch_bounds__(256) void pos_reduce_kernel(const float* __restrict__ rows, int B, int S, float* __restrict__ dpos) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= (long)S * H) return;
+  float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; b += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (b + u < B) ? *(const float4*)(rows + (long)(b + u) * S * H + e) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  *(float4*)(dpos + e) = acc;
+}
+
 // Embedding backward: dx0 (f32 grad of the embedding output) -> LN backward -> scatter-add into the
 // word / position tables (float atomics, 256 contiguous bytes per wave instruction), per-block partials
 // for LN gamma/beta and the (<= 2 row) token-type table: partials[blk][2 + type_vocab][H].
+// row_out != null (dense BERT rows, position id = row % S): the post-LN gradient rows are written there instead of
+// being added atomically to dpos (64 samples hitting the same 128 position rows serialise in L2);
+// pos_reduce_kernel then sums them over the batch in fixed order.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float* __restrict__ dx0,
                                                         const float* __restrict__ stats, float* __restrict__ dword,
-                                                        float* __restrict__ dpos, float* __restrict__ partials) {
+                                                        float* __restrict__ dpos, float* __restrict__ partials,
+                                                        float* __restrict__ row_out) {
   __shared__ float lds[4 * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const Row G = load_row(a.gamma, lane);
@@ -279,8 +298,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
       const int c = (i * 64 + lane) * 4;
       atomicAdd(wrow + c, DY.v[i].x); atomicAdd(wrow + c + 1, DY.v[i].y);
       atomicAdd(wrow + c + 2, DY.v[i].z); atomicAdd(wrow + c + 3, DY.v[i].w);
-      atomicAdd(prow + c, DY.v[i].x); atomicAdd(prow + c + 1, DY.v[i].y);
-      atomicAdd(prow + c + 2, DY.v[i].z); atomicAdd(prow + c + 3, DY.v[i].w);
+      if (row_out) {
+        *(float4*)(row_out + orow * H + c) = DY.v[i];
+      } else {
+        atomicAdd(prow + c, DY.v[i].x); atomicAdd(prow + c + 1, DY.v[i].y);
+        atomicAdd(prow + c + 2, DY.v[i].z); atomicAdd(prow + c + 3, DY.v[i].w);
+      }
     }
     Row& T = tid_ == 0 ? accT0 : accT1;
 #pragma unroll
@@ -464,9 +487,11 @@ extern "C" int carel_embed_ln_fwd(const carel_embed_args* a, void* stream_) {
 
 extern "C" int carel_embed_ln_bwd_blocks(int64_t rows) { return (int)((rows + LNB_ROWS - 1) / LNB_ROWS); }
 
-extern "C" int carel_embed_ln_bwd(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_,
-                                  void* dgamma, void* dbeta, void* partials, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace carel {
+// row_scratch: optional f32 [rows, hidden] buffer; with it, dense BERT batches get their position-table gradient from
+// a fixed-order reduction instead of float atomics (see embed_bwd_kernel)
+int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,
+                    void* partials, void* row_scratch, hipStream_t stream) {
   int rc = embed_check(a, "carel_embed_ln_bwd");
   if (rc) return rc;
   if (!dx0 || !dword || !dpos || !dtype_ || !dgamma || !dbeta || !partials || !a->stats)
@@ -474,15 +499,27 @@ extern "C" int carel_embed_ln_bwd(const carel_embed_args* a, const void* dx0, vo
   EmbedArgs e = make_embed(a);
   const int nblk = carel_embed_ln_bwd_blocks(e.rows);
   const int slots = 2 + e.type_vocab;
+  const bool by_reduction = row_scratch && !e.roberta && !e.tok_row && e.rows == (long)a->batch * a->seq_len;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblk), dim3(256), 0, stream, e, (const float*)dx0, (const float*)a->stats,
-                     (float*)dword, (float*)dpos, (float*)partials);
+                     (float*)dword, (float*)dpos, (float*)partials, by_reduction ? (float*)row_scratch : (float*)nullptr);
   rc = check_launch("embed_bwd_kernel");
   if (rc) return rc;
+  if (by_reduction) {
+    hipLaunchKernelGGL(pos_reduce_kernel, dim3((unsigned)(((long)a->seq_len * H / 4 + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)row_scratch, a->batch, a->seq_len, (float*)dpos);
+    if ((rc = check_launch("pos_reduce_kernel"))) return rc;
+  }
   SegOuts so; so.p[0] = (float*)dgamma; so.p[1] = (float*)dbeta; so.p[2] = (float*)dtype_;
   so.p[3] = e.type_vocab > 1 ? (float*)dtype_ + H : nullptr;
   hipLaunchKernelGGL(partial_reduce_seg_kernel, dim3((slots * H + PR_COLS - 1) / PR_COLS), dim3(256), 0, stream, (const float*)partials,
                      so, H, slots * H, nblk);
   return check_launch("partial_reduce_seg_kernel");
+}
+}  // namespace carel
+
+extern "C" int carel_embed_ln_bwd(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_,
+                                  void* dgamma, void* dbeta, void* partials, void* stream_) {
+  return embed_ln_bwd_ex(a, dx0, dword, dpos, dtype_, dgamma, dbeta, partials, nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int carel_layernorm_fwd(const void* h, const void* gamma, const void* beta, float eps, int64_t rows, int32_t hidden,
