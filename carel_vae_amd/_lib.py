@@ -162,6 +162,7 @@ SIGNATURES = {
     "carel_tail_backward": (C.c_int, [C.POINTER(TailArgs), C.c_void_p, C.c_void_p]),
     "carel_tail_profile": (C.c_int, [C.c_void_p]),
     "carel_side_stream": (C.c_void_p, [C.c_int32]),
+    "carel_encoder_backward_join": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),
     "carel_tail_backward_dz": (C.c_int, [C.POINTER(TailArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "carel_vi_aprx": (C.c_int, [C.POINTER(ViArgs), C.c_void_p]),
     "carel_vi_upper": (C.c_int, [C.POINTER(ViArgs), C.c_void_p]),

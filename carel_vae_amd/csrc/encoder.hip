@@ -127,7 +127,7 @@ int enc_check(const carel_encoder_args* a, const char* who) {
 }
 
 // One low-priority stream + a few events per device, created on first use and kept for the life of the process.
-struct SideStream { static constexpr int NEV = 6; hipStream_t stream; hipStream_t aux; hipStream_t peer; hipEvent_t ev[NEV]; bool ok; };
+struct SideStream { static constexpr int NEV = 10; hipStream_t stream; hipStream_t aux; hipStream_t peer; hipEvent_t ev[NEV]; bool ok; };
 SideStream* side_stream() {
   static SideStream per_dev[16];
   static bool made[16];
@@ -308,9 +308,13 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
   const ScratchLayout sl = scratch_layout(B, S);
   const size_t ws_bytes = sl.ws_bytes;
-  // Weight gradients on a second stream (a->overlap_wgrad): each dW GEMM + slab reduction is forked behind the kernel
-  // that produced its dY operand and runs beside the data-gradient chain, LayerNorm and attention backward kernels;
-  // everything is joined before this call returns (so the caller may all-reduce this layer's gradients right away).
+  // Weight gradients on a second stream (a->overlap_wgrad): each dW GEMM + slab reduction is forked (events ev[0..3])
+  // behind the kernel that produced its dY operand and runs beside the data-gradient chain, LayerNorm and attention
+  // backward kernels.  There is no join at the end of the layer: the side stream records ev[4..7] after each of its four
+  // groups, and the main stream waits for group i of the PREVIOUS call only just before it overwrites the scratch
+  // buffers that group read (dyb/part, du/part2, dyb2/part3, dqkv).  Consequently, in stream order after this call
+  // returns, the gradients of layer+1 are complete (the main stream waited for its last group before this layer's
+  // attention backward), those of `layer` after the next call or carel_encoder_backward_join.
   SideStream* sd = nullptr;
   if (a->overlap_wgrad) {
     sd = side_stream();
@@ -325,12 +329,21 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
       return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event fork failed");
     return CAREL_OK;
   };
+  auto group_done = [&](int i) -> int {       // side stream: group i of this layer is enqueued
+    if (!sd) return CAREL_OK;
+    return hipEventRecord(sd->ev[4 + i], sd->stream) == hipSuccess ? CAREL_OK : set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event record failed");
+  };
+  auto wait_group = [&](int i) -> int {       // main stream: group i of the previous call has finished with its buffers
+    if (!sd) return CAREL_OK;                 // (an event that was never recorded counts as complete)
+    return hipStreamWaitEvent((hipStream_t)stream, sd->ev[4 + i], 0) == hipSuccess ? CAREL_OK : set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event wait failed");
+  };
   // Row-wise half of the layer.  Last layer with dead-row elimination: only the n_cls [CLS] rows exist (compact).
   const bool cls_only = a->n_cls > 0 && layer + 1 == a->n_layers;
   const long R = cls_only ? (long)a->n_cls : T;
   const void* rmap = cls_only ? a->cls_orig_rows : a->tok_row;
   const void* ctx_rows = cls_only ? (const void*)((char*)a->act + l.o_cctx) : (const void*)la.ctx;
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
+  if ((rc = wait_group(0))) return rc;
   if ((rc = layernorm_bwd_rows(a->dx, la.h2, la.st2, w.ln2_g, R, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb,
                                s.part, (hipStream_t)stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
@@ -338,15 +351,18 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = fork())) return rc;
   if ((rc = layernorm_bwd_reduce(s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b, (hipStream_t)wstream))) return rc;
   if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream))) return rc;
+  if ((rc = group_done(0)) || (rc = wait_group(1))) return rc;
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_DGELU_BF16, 1, s.du, nullptr, nullptr, nullptr,
                       nullptr, la.u, 0, 0, 0, 0.f, stream, s.part2))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
   if ((rc = fork())) return rc;
   if ((rc = carel_partial_reduce_f32(s.part2, g.ffn1_b, EI, (int)(R / 128), 0, wstream))) return rc;
   if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream))) return rc;
+  if ((rc = group_done(1))) return rc;
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
                       nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
   // LN1 backward (its bf16 output goes to a second buffer: the FFN2 weight gradient may still be reading dyb)
+  if ((rc = wait_group(2))) return rc;
   if ((rc = layernorm_bwd_rows(a->dx, la.h1, la.st1, w.ln1_g, R, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb2,
                                s.part3, (hipStream_t)stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
@@ -354,6 +370,8 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = fork())) return rc;
   if ((rc = layernorm_bwd_reduce(s.part3, R, g.ln1_g, g.ln1_b, g.out_b, (hipStream_t)wstream))) return rc;
   if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream))) return rc;
+  if ((rc = group_done(2))) return rc;
+  if (cls_only && (rc = wait_group(3))) return rc;             // the compact result parks in dqkv
   if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
                       nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
   if (cls_only) {
@@ -378,17 +396,26 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
     hipError_t he = hipMemsetAsync(s.dqkv + (size_t)(T - 128) * 3 * EH * 2, 0, (size_t)128 * 3 * EH * 2, (hipStream_t)stream);
     if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
   }
+  if ((rc = wait_group(3))) return rc;
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
   if ((rc = fork())) return rc;
   if ((rc = wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, wstream, g.qkv_b))) return rc;
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
                       dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
-  if (sd) {        // join
-    hipEvent_t ev = sd->ev[SideStream::NEV - 1];
-    if (hipEventRecord(ev, sd->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess)
-      return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event join failed");
-  }
+  return group_done(3);
+}
+
+// `stream` waits for every weight-gradient kernel enqueued so far (no-op without overlap_wgrad).  Call it after the last
+// carel_encoder_backward_layer before using layer 0's gradients; carel_encoder_backward_embeddings calls it itself.
+extern "C" int carel_encoder_backward_join(const carel_encoder_args* a, void* stream) {
+  if (!a) return set_error(CAREL_ERR_ARG, "carel_encoder_backward_join: null args");
+  if (!a->overlap_wgrad) return CAREL_OK;
+  SideStream* sd = side_stream();
+  if (!sd) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_join: no side stream");
+  hipEvent_t ev = sd->ev[SideStream::NEV - 1];
+  if (hipEventRecord(ev, sd->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, ev, 0) != hipSuccess)
+    return set_error(CAREL_ERR_HIP, "carel_encoder_backward_join: event join failed");
   return CAREL_OK;
 }
 
@@ -397,6 +424,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
 extern "C" int carel_encoder_backward_embeddings(const carel_encoder_args* a, void* stream) {
   int rc = enc_check(a, "carel_encoder_backward_embeddings");
   if (rc) return rc;
+  if ((rc = carel_encoder_backward_join(a, stream))) return rc;
   if (a->inference || !a->scratch || !a->dx || !a->d_word_emb || !a->d_pos_emb || !a->d_type_emb || !a->d_emb_ln_g || !a->d_emb_ln_b)
     return set_error(CAREL_ERR_ARG, "carel_encoder_backward_embeddings: null buffer or inference-mode forward");
   const long B = a->batch, S = a->seq_len;

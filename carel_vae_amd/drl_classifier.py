@@ -703,11 +703,19 @@ class DrlClassifier(nn.Module):
         ops.scale_(self._flat_grad[lo:self._pair_hi], go)
         if self._dp is not None:
             self._dp.tail_done()
-        for l in range(self.cfg.layers - 1, -1, -1):
-            L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
+        def layer_ready(l):             # layer l's parameter gradients are complete in the order of the main stream
             work = self._dp.layer_done(l) if self._dp is not None else None
             if self._adam_hook is not None and not accumulate and (self._dp is None or work is not None):
                 self._adam_hook._layer_ready(l, after=work)
+
+        lag = 1 if self.overlap_wgrad else 0     # with the side stream a layer completes one call late (include/carel_hip.h)
+        for l in range(self.cfg.layers - 1, -1, -1):
+            L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
+            if l + lag < self.cfg.layers:
+                layer_ready(l + lag)
+        if lag:
+            L.check(lib.carel_encoder_backward_join(C.byref(ea), st), "carel_encoder_backward_join")
+            layer_ready(0)
         L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
         if self._dp is not None:
             self._dp.backward_done()

@@ -232,10 +232,13 @@ typedef struct carel_encoder_args {
    * index), -1 for filler.  The final hidden states (carel_encoder_x_last) are then the n_cls compact rows, and dx is
    * read as n_cls compact rows by the backward of the last layer.  n_cls = 0 disables. */
   int32_t n_cls; const void* cls_rows; const void* cls_orig_rows;
-  /* 1: carel_encoder_backward_layer enqueues the weight-gradient GEMMs (and their slab reductions) on a library-owned
-   * low-priority second stream, forked by events behind the kernel that produced each dY and joined before the call
-   * returns, so that they run beside the data-gradient chain and the memory-bound LayerNorm / attention backward
-   * kernels.  Results are identical (same kernels, same summation order).  0: everything on `stream`. */
+  /* 1: carel_encoder_backward_layer enqueues the weight-gradient GEMMs (and their slab / bias-gradient reductions) on a
+   * library-owned low-priority second stream, forked by events behind the kernel that produced each dY, so that they
+   * run beside the data-gradient chain and the memory-bound LayerNorm / attention backward kernels; the forward pass
+   * runs the two halves of a dense batch as two chains.  Results are identical (same kernels, same summation order).
+   * COMPLETION: in the order of `stream`, after carel_encoder_backward_layer(l) returns the parameter gradients of
+   * layer l+1 are complete; those of layer l after the next call, carel_encoder_backward_join or
+   * carel_encoder_backward_embeddings.  0: everything on `stream`, every layer complete when its call returns. */
   int32_t overlap_wgrad;
   const carel_layer_grads* layer_grads;     /* HOST array [n_layers] */
   void* d_word_emb; void* d_pos_emb; void* d_type_emb; void* d_emb_ln_g; void* d_emb_ln_b;
@@ -246,6 +249,7 @@ typedef struct carel_encoder_args {
  * 0 = the weight-gradient stream used by overlap_wgrad, 1 = an auxiliary stream the host side uses for work that may
  * trail the backward pass (the per-layer Adam updates of FusedAdam(fuse_into_backward=True)).  NULL on failure. */
 void* carel_side_stream(int32_t which);
+int carel_encoder_backward_join(const carel_encoder_args* args, void* stream);
 int64_t carel_encoder_act_bytes(int32_t batch, int32_t seq_len, int32_t n_layers, int32_t inference);
 int64_t carel_encoder_scratch_bytes(int32_t batch, int32_t seq_len);
 /* device pointer (inside act) of the final hidden states, f32 [B*S, 768] */
