@@ -216,6 +216,26 @@ def main():
         batches, lengths = keep
         log("ECPE-shaped leg: %.3f ms/step" % (1e3 * dtb / nb))
 
+    # ---- evaluation twin: get_pair_preds on a test-set-sized batch of ECPE-shaped pairs (:265-282, :958) ----
+    infer = None
+    if not a.no_ecpe and rank == 0:
+        tb = O.synthetic_batch(2048, 128, ocfg, opt.pair_bow_dim, seed=777, shape="B")
+        ti, ta_, tt_ = (tb[k].to(dev) for k in ("input_ids", "attention_masks", "token_type_ids"))
+        model.eval()
+        with torch.no_grad():
+            model.pair_probabilities(ti, ta_, tt_)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                prob = model.pair_probabilities(ti, ta_, tt_)
+            torch.cuda.synchronize()
+            dti = (time.perf_counter() - t2) / 3
+        model.train()
+        infer = {"value": 2048 / dti, "unit": "clause-pairs/s", "ms_per_2048_pairs": 1e3 * dti,
+                 "note": "pair_probabilities (the kernel path of get_pair_preds): eval-mode encoder + fresh noise, 2048 ECPE-shaped pairs, "
+                         "chunks of 256, padding skipped; one GPU"}
+        log("inference leg: %.1f ms per 2048 pairs" % (1e3 * dti))
+
     # ---- roofline of the dominant kernel family ----
     roof = None
     ms_t, fl_t, n_t = ev_timed
@@ -247,7 +267,7 @@ def main():
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
                       "wgrad_side_stream": bool(model.overlap_wgrad),
                       "adam_in_backward": bool(getattr(optim, "_aux", None) is not None)},
-           "roofline": roof, "ecpe_shaped": ecpe, "final_loss": final_loss}
+           "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):
             m2 = M.DrlClassifier(M.make_opt(**vars(oopt)), M.encoder_config("zh", hidden_dropout=0.0, attn_dropout=0.0), seed=0)
