@@ -526,13 +526,14 @@ def vi_upper_loss(P, z_e, z_c, perm):
 
 
 def vi_train_step(P, batch, iteration, epoch, cfg, opt, eps_e, eps_c, perm, st_vae: "AdamState", st_aprx: "AdamState",
-                  quant: Quant = None, train=False, seed=None):
+                  quant: Quant = None, train=False, seed=None, emotion_head: str = "bce"):
     """The two-phase step of ec_vi :754-774: Adam(aprx_lr) on the approximation net with the aprx loss, then
     vae loss + beta * CLUB bound (with the UPDATED net) -> Adam(vae_lr) on get_params()[1].
-    Returns (P, dict(aprx=, vae=, upper=, total=))."""
+    emotion_head: "bce" = drl_classifier_ec_vi.py (one-logit head), "ce" = drl_classifier_ec_vi_final.py (:465-477,
+    six-way cross entropy, the head of the main script).  Returns (P, dict(aprx=, vae=, upper=, total=))."""
     leaf = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     out = forward_terms(leaf, batch, iteration, cfg, opt, eps_e, eps_c, train=train, seed=seed, quant=quant,
-                        disentangle="none", emotion_head="bce")
+                        disentangle="none", emotion_head=emotion_head)
     aprx = vi_aprx_loss(leaf, out["z_e"], out["z_c"])
     g_aprx = torch.autograd.grad(aprx, [leaf[k] for k in VI_KEYS], retain_graph=True)
     P = dict(P)

@@ -165,3 +165,43 @@ def test_extra_loss_on_sampled_embeddings_reaches_encoder(golden_dir):
     d1, d2 = got[1] - got[0], got[2] - got[1]
     assert float(d1.norm()) > 1e-3 * float(got[0].norm())
     assert float((d1 - d2).norm()) <= 2e-2 * float(d1.norm())
+
+
+def test_vi_final_variant_six_way_emotion_head(golden_dir):
+    """drl_classifier_ec_vi_final.py = the VI step with the main script's six-way CE emotion head (:465-477):
+    opt.disentangle = "vi", opt.emotion_head = "ce".  Against the bf16-emulating oracle (its CE head is pinned by the main
+    goldens, its VI part by vi_small)."""
+    cfg, opt = O.EncoderConfig(layers=2, vocab_size=900), O.Opt(pair_bow_dim=211, dropout=0.0, e_num_class=6)
+    z = np.load(os.path.join(golden_dir, "vi_small.npz"), allow_pickle=False)
+    wseed, bseed = int(z["meta"][5]), int(z["meta"][6])
+    batch = O.synthetic_batch(16, 128, cfg, opt.pair_bow_dim, seed=bseed, shape="B")       # six-class emotion labels
+    mopt = M.make_opt(**vars(opt), disentangle="vi", emotion_head="ce")
+    model = M.DrlClassifier(mopt, M.encoder_config("zh", vocab_size=cfg.vocab_size, layers=cfg.layers, hidden_dropout=0.0, attn_dropout=0.0))
+    P = {**O.init_params(cfg, opt, seed=wseed), **O.init_vi_params(opt, seed=wseed + 1)}
+    model.load_state_dict(P)
+    model.to("cuda").train()
+    ec_aprx_params, other_params = model.get_params()
+    ec_aprx_opt = torch.optim.Adam(ec_aprx_params, lr=opt.aprx_lr)
+    vae_and_cls_opt = M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=True)
+    b = {k: v.cuda() for k, v in batch.items()}
+    st_vae, st_aprx, Pq = O.AdamState(), O.AdamState(), dict(P)
+    for s, epoch in enumerate((3, 8)):
+        eps_e, eps_c = torch.from_numpy(z[f"eps_e_{s}"]), torch.from_numpy(z[f"eps_c_{s}"])
+        perm = torch.from_numpy(z[f"perm_{s}"])
+        model.set_noise(eps_e, eps_c)
+        e_embedding, c_embedding, ec_aprx_loss, vae_and_cls_loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"],
+                                                                         b["emo_labels"], b["cau_labels"], b["labels"], b["bow_reps"], 5 + s)
+        ec_aprx_opt.zero_grad()
+        ec_aprx_loss.backward(retain_graph=True)
+        ec_aprx_opt.step()
+        Rj_loss = model.get_ec_upper_loss(e_embedding, c_embedding, random_index=perm)
+        vae_only = float(vae_and_cls_loss.detach())
+        vae_and_cls_loss += min(1.0, (epoch - 1) * 0.1) * Rj_loss
+        vae_and_cls_opt.zero_grad()
+        vae_and_cls_loss.backward()
+        vae_and_cls_opt.step()
+        Pq, out = O.vi_train_step(Pq, batch, 5 + s, epoch, cfg, opt, eps_e, eps_c, perm, st_vae, st_aprx, quant=O.bf16_round, emotion_head="ce")
+        assert abs(float(ec_aprx_loss.detach()) - float(out["aprx"])) <= 3e-3 * abs(float(out["aprx"])), s
+        assert abs(vae_only - float(out["vae"])) <= 3e-3 * abs(float(out["vae"])), s
+        assert abs(float(Rj_loss.detach()) - float(out["upper"])) <= 3e-3 * max(abs(float(out["upper"])), 1.0), s
+        assert abs(float(vae_and_cls_loss.detach()) - float(out["total"])) <= 3e-3 * abs(float(out["total"])), s
