@@ -70,6 +70,7 @@ class TailArgs(C.Structure):
                 ("mmd_alpha", C.c_float), ("mmd_eps", C.c_float), ("dis_mode", C.c_int32), ("emo_bce", C.c_int32),
                 ("global_label_sum", C.c_void_p), ("global_n", C.c_int32), ("global_row_offset", C.c_int32),
                 ("z_global", C.c_void_p), ("mmd_grad_scale", C.c_float), ("global_rank_stride", C.c_int32),
+                ("global_label_ranks", C.c_int32),
                 ("pooled", C.c_void_p), ("lat", C.c_void_p), ("z", C.c_void_p), ("terms", C.c_void_p),
                 ("work", C.c_void_p),
                 ("d_emo_w", C.c_void_p), ("d_emo_b", C.c_void_p), ("d_cau_w", C.c_void_p), ("d_cau_b", C.c_void_p),

@@ -172,6 +172,7 @@ struct TailCore {
   Dropout d_emo, d_cau, d_pair;                // element index b*D + k (pair: b*2D + k)
   float alpha, mmd_eps;
   const float* label_sum_override; float n_override;   // global-batch pos_weight (DP); null/0 = local
+  int label_sum_ranks;          // > 1: the global label sum is the sum of this many floats, rank_stride apart
   const float* z_global; int n_global, row_offset; float mmd_grad_scale;  // global-batch MMD (DP)
   int rank_stride;              // floats between consecutive ranks' blocks of B rows in z_global (B*2D when dense)
   // outputs
@@ -299,7 +300,11 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   if (t < B) ysum = a.pair_labels[t];
   ysum = block_sum(t < B ? ysum : 0.f, red);        // (its barriers also publish lg)
   const float ntot = a.label_sum_override ? a.n_override : (float)B;
-  const float ytot = a.label_sum_override ? a.label_sum_override[0] : ysum;
+  float ytot = ysum;
+  if (a.label_sum_override) {
+    ytot = a.label_sum_override[0];
+    for (int r = 1; r < a.label_sum_ranks; ++r) ytot += a.label_sum_override[(long)r * a.rank_stride];
+  }
   const float pw = (ntot - ytot) / ytot;        // inf when there is no positive in the batch
   float xp = 0.f, tp = 0.f;
   for (int b = t; b < B; b += blockDim.x) {
@@ -771,6 +776,9 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   c.d_pair = make_dropout(a->drop_seed, 102u, a->drop_p, a->drop_row_offset * (uint32_t)(2 * D));
   c.alpha = a->mmd_alpha; c.mmd_eps = a->mmd_eps;
   c.label_sum_override = (const float*)a->global_label_sum; c.n_override = (float)a->global_n;
+  c.label_sum_ranks = a->global_label_ranks > 1 ? a->global_label_ranks : 1;
+  if (c.label_sum_ranks > 1 && a->global_rank_stride <= 0)
+    return set_error(CAREL_ERR_ARG, "carel_tail_losses: global_label_ranks > 1 needs global_rank_stride");
   c.z_global = (const float*)a->z_global; c.n_global = a->global_n; c.row_offset = a->global_row_offset;
   c.rank_stride = a->global_rank_stride > 0 ? a->global_rank_stride : B * 2 * D;
   if (c.z_global && a->global_rank_stride > 0 && (a->global_rank_stride < B * 2 * D || c.n_global % B))

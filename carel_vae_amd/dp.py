@@ -94,25 +94,27 @@ class DataParallel:
             self._noise_gen.manual_seed(self._noise_seed)
         return (torch.randn(n, device=device, generator=self._noise_gen), torch.randn(n, device=device, generator=self._noise_gen))
 
+    def prepare(self, call):
+        """Called when the batch is known (before the encoder runs): park this rank's label sum behind the z buffer, so
+        that nothing but the all-gather itself sits between the latents and the loss kernel."""
+        if self.global_batch_terms:
+            n = call.buf.z.numel()
+            call.buf.zpack[n:] = call.labels["pair"].sum()
+
     def fill_global(self, ta, call):
-        """ONE all-gather carries the sampled latents and each rank's label sum; point the tail at the result."""
+        """ONE all-gather carries the sampled latents and each rank's label sum; the loss kernel reads both straight
+        out of the gathered buffer (per-rank stride)."""
         if not self.global_batch_terms:
             return
-        z = call.buf.z
-        n = z.numel()
-        stride = n + 16                                  # 16 spare floats per rank; [n] = the rank's label sum
-        mine = torch.empty(stride, device=z.device, dtype=z.dtype)
-        mine[:n] = z.reshape(-1)
-        mine[n:] = call.labels["pair"].sum()
+        z, mine = call.buf.z, call.buf.zpack
+        n, stride = z.numel(), call.buf.zpack.numel()
         flat = torch.empty(self.world * stride, device=z.device, dtype=z.dtype)
         dist.all_gather_into_tensor(flat, mine, group=self.group)
-        gathered = flat.view(self.world, stride)
-        ysum = gathered[:, n].sum().reshape(1)
-        ta.z_global, ta.global_n, ta.global_rank_stride = gathered.data_ptr(), self.world * z.shape[0], stride
+        ta.z_global, ta.global_n, ta.global_rank_stride = flat.data_ptr(), self.world * z.shape[0], stride
         ta.global_row_offset = self.rank * z.shape[0]
-        ta.global_label_sum = ysum.data_ptr()
+        ta.global_label_sum, ta.global_label_ranks = flat.data_ptr() + 4 * n, self.world
         ta.mmd_grad_scale = float(self.world)       # gradients are averaged over ranks afterwards
-        call.dp_keep = (gathered, ysum)
+        call.dp_keep = (flat.view(self.world, stride),)
 
     def tail_done(self):
         self.reducer.reduce("tail")

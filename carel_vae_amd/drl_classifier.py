@@ -646,6 +646,8 @@ class DrlClassifier(nn.Module):
             buf = ops.TailBuffers(B, S, self.opt.ec_dim, self.opt.e_num_class, self.opt.pair_bow_dim, dev, rows=Bp * S)
             self._ws[key] = buf
         c.buf = buf
+        if self._dp is not None:
+            self._dp.prepare(c)
         return c
 
     def _tail_weights(self):

@@ -93,14 +93,17 @@ class TailBuffers:
         self.rows = rows if rows is not None else B * S        # rows of the encoder's last hidden state / its gradient
         self.pooled = torch.empty((B, H), **f)
         self.lat = torch.empty((B, 4 * D), **f)
-        self.z = torch.empty((B, 2 * D), **f)
+        # z sits at the head of a buffer with 16 spare floats: a data-parallel caller all-gathers the whole thing (z + its
+        # label sum in [n]) in ONE collective without packing anything (carel_vae_amd.dp.DataParallel.fill_global)
+        self.zpack = torch.zeros(B * 2 * D + 16, **f)
+        self.z = self.zpack[:B * 2 * D].view(B, 2 * D)
         self.terms = torch.zeros(16, **f)
         self.work = torch.empty(L.load().carel_tail_workspace_floats(B, D, V), **f)
         self.dx_last = torch.empty((self.rows, H), **f)
 
 
 def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight, *, grads=None, drop=(0.0, 0, 0),
-              global_label_sum=None, global_n=0, global_row_offset=0, z_global=None, mmd_grad_scale=1.0, global_rank_stride=0, cls_rows=None,
+              global_label_sum=None, global_n=0, global_row_offset=0, z_global=None, mmd_grad_scale=1.0, global_rank_stride=0, global_label_ranks=0, cls_rows=None,
               n_rows=0):
     """W / grads: dicts keyed by the reference's state_dict names (tail part)."""
     a = L.TailArgs()
@@ -137,6 +140,7 @@ def tail_args(buf: TailBuffers, x_last, W, labels, eps_e, eps_c, opt, kl_weight,
     a.z_global = None if z_global is None else z_global.data_ptr()
     a.mmd_grad_scale = mmd_grad_scale
     a.global_rank_stride = global_rank_stride
+    a.global_label_ranks = global_label_ranks
     a.pooled, a.lat, a.z, a.terms, a.work = (buf.pooled.data_ptr(), buf.lat.data_ptr(), buf.z.data_ptr(),
                                              buf.terms.data_ptr(), buf.work.data_ptr())
     a.dx_last_f32 = buf.dx_last.data_ptr()

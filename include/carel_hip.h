@@ -304,6 +304,9 @@ typedef struct carel_tail_args {
   float mmd_grad_scale;
   int32_t global_rank_stride;        /* 0: z_global is dense; else floats between the blocks of `batch` rows contributed by
                                         consecutive ranks (lets one all-gather carry z plus a few extra floats per rank) */
+  int32_t global_label_ranks;        /* > 1: the global label sum is the sum of this many floats starting at
+                                        global_label_sum, global_rank_stride apart (each rank's own sum, straight out of
+                                        the same all-gather); 0 / 1: global_label_sum[0] is already the total */
   /* outputs */
   void* pooled;                      /* f32 [B, 768] */
   void* lat;                         /* f32 [B, 4*ec_dim] */

@@ -56,13 +56,17 @@ def _worker(rank, world, port, q):
         dist.all_gather(both, torch.cat((e1, c1, e2, c2)))
         ok_noise = ok_noise and all(torch.equal(b, both[0]) for b in both) and not torch.equal(e1, e2) and not torch.equal(e1, c1)
         B = 4
-        call = SimpleNamespace(buf=SimpleNamespace(z=torch.full((B, 48), float(rank))), labels={"pair": torch.ones(B) * (rank == 0)})
+        zpack = torch.zeros(B * 48 + 16)
+        zpack[:B * 48] = float(rank)
+        call = SimpleNamespace(buf=SimpleNamespace(z=zpack[:B * 48].view(B, 48), zpack=zpack), labels={"pair": torch.ones(B) * (rank == 0)})
         ta = L.TailArgs()
+        dp.prepare(call)
         dp.fill_global(ta, call)
-        gathered, ysum = call.dp_keep            # [world, B*48 + 16]: rank r's z, then its label sum
+        gathered, = call.dp_keep                 # [world, B*48 + 16]: rank r's z, then its label sum
         ok_global = (ta.global_n == world * B and ta.global_row_offset == rank * B and ta.mmd_grad_scale == float(world)
                      and ta.global_rank_stride == B * 48 + 16 and gathered.shape == (world, B * 48 + 16)
-                     and float(ysum) == B and bool((gathered[0, :B * 48] == 0).all()) and bool((gathered[1, :B * 48] == 1).all())
+                     and ta.global_label_ranks == world and ta.global_label_sum == gathered.data_ptr() + 4 * B * 48
+                     and bool((gathered[0, :B * 48] == 0).all()) and bool((gathered[1, :B * 48] == 1).all())
                      and float(gathered[0, B * 48]) == B and float(gathered[1, B * 48]) == 0.0
                      and ta.z_global == gathered.data_ptr())
         dp.tail_done(); dp.layer_done(1); dp.layer_done(0); dp.backward_done()

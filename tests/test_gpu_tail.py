@@ -110,13 +110,17 @@ def test_tail_global_batch_hooks(strided):
         packed = torch.full((R, stride), float("nan"), device="cuda")
         for r in range(R):
             packed[r, :Bl * 48] = zs[r].reshape(-1)
+            packed[r, Bl * 48] = float(shards[r][0]["labels"].sum())      # each rank's own label sum rides behind its z
         zg = packed
     ysum = batch["labels"].sum().reshape(1).cuda()
+    label_ranks = 0
+    if strided:
+        ysum, label_ranks = packed.view(-1)[Bl * 48:], R
     tot = {k: torch.zeros_like(v) for k, v in P.items()}
     loss = 0.0
     for r, (sb, xl) in enumerate(shards):
         buf, G = hip_tail(P, xl, sb, eps_e, eps_c, opt, Bl, S, V, it, (opt.dropout, seed, r * Bl), global_label_sum=ysum,
-                          global_n=B, global_row_offset=r * Bl, z_global=zg, mmd_grad_scale=float(R), global_rank_stride=stride)
+                          global_n=B, global_row_offset=r * Bl, z_global=zg, mmd_grad_scale=float(R), global_rank_stride=stride, global_label_ranks=label_ranks)
         for k in tot:
             tot[k] += G[k].cpu() / R          # gradient averaging over ranks
         t = buf.terms.cpu().numpy()
