@@ -101,15 +101,20 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
         model.train()
         log("\n############ Epoch {}: Training Start ############\n".format(epoch))
         for iteration, batch in enumerate(train_loader):
-            ids = batch["input_ids"].to(device, dtype=torch.long)
-            att = batch["attention_masks"].to(device, dtype=torch.long)
-            tt = batch["token_type_ids"].to(device, dtype=torch.long)
-            labels = batch["labels"].to(device, dtype=torch.float)
-            emo = batch["emo_labels"].to(device, dtype=torch.long)
-            cau = batch["cau_labels"].to(device, dtype=torch.float)
-            bow = batch["bow_reps"].to(device, dtype=torch.float)
+            # attended lengths from the HOST copy of the mask: lets the model skip padding without reading the mask back
+            # from the device (a sync that would stop the host from running ahead of the GPU)
+            kw = {}
+            if getattr(model, "varlen", False) and not batch["attention_masks"].is_cuda:
+                kw["seq_lengths"] = batch["attention_masks"].sum(1).tolist()
+            ids = batch["input_ids"].to(device, dtype=torch.long, non_blocking=True)
+            att = batch["attention_masks"].to(device, dtype=torch.long, non_blocking=True)
+            tt = batch["token_type_ids"].to(device, dtype=torch.long, non_blocking=True)
+            labels = batch["labels"].to(device, dtype=torch.float, non_blocking=True)
+            emo = batch["emo_labels"].to(device, dtype=torch.long, non_blocking=True)
+            cau = batch["cau_labels"].to(device, dtype=torch.float, non_blocking=True)
+            bow = batch["bow_reps"].to(device, dtype=torch.float, non_blocking=True)
             if vi:                  # two-phase step, drl_classifier_ec_vi.py:754-774
-                e_embedding, c_embedding, ec_aprx_loss, loss = model(ids, att, tt, emo, cau, labels, bow, iteration)
+                e_embedding, c_embedding, ec_aprx_loss, loss = model(ids, att, tt, emo, cau, labels, bow, iteration, **kw)
                 ec_aprx_opt.zero_grad()
                 ec_aprx_loss.backward(retain_graph=True)
                 ec_aprx_opt.step()
@@ -117,14 +122,17 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
                 beta = min(1, (epoch - 1) * 0.1)
                 loss += beta * Rj_loss
             else:
-                loss = model(ids, att, tt, emo, cau, labels, bow, iteration)
+                loss = model(ids, att, tt, emo, cau, labels, bow, iteration, **kw)
             vae_and_cls_opt.zero_grad()
             loss.backward()
             vae_and_cls_opt.step()
-            running_loss += loss.item() + (ec_aprx_loss.item() if vi else 0.0)
+            # same numbers as the reference's `running_loss += loss.item()` (:845-851), but accumulated on the device and
+            # read back only when they are printed: a per-step .item() would stop the host from running ahead of the GPU
+            step_loss = loss.detach() + ec_aprx_loss.detach() if vi else loss.detach()
+            running_loss = step_loss if isinstance(running_loss, int) else running_loss + step_loss
             if iteration % 10 == 9:
-                log("[%d, %5d] training loss: %.4f" % (epoch, iteration + 1, running_loss / 10))
-                running_loss = 0.0
+                log("[%d, %5d] training loss: %.4f" % (epoch, iteration + 1, float(running_loss) / 10))
+                running_loss = 0
         model.eval()
         with torch.no_grad():
             for batch in test_loader:
