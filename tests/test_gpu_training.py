@@ -1,0 +1,67 @@
+"""The reference's driver end to end on the GPU: read_ECPE_data -> ECPEDataset -> DataLoader -> train() (step body of
+drl_classifier_ec_mmd_final_mul.py :823-845 / the two-phase VI step) -> evaluation with get_pair_preds -> checkpoint ->
+generate_self_train_data, on the committed ECPE sample with a 2-layer encoder and a character tokenizer stand-in."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from carel_vae_amd import data as D
+from carel_vae_amd import drl_classifier as M
+from carel_vae_amd import training as T
+from tests.test_host_data import FakeTokenizer, char_segmenter
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ECPE = os.path.join(HERE, "golden", "ecpe")
+
+
+def _loaders(bs):
+    import random
+    random.seed(42)
+    train_df, _, _ = D.read_ECPE_data(os.path.join(ECPE, "sample_zh_train.txt"), test=False, language="zh")
+    test_df, sizes, unpred = D.read_ECPE_data(os.path.join(ECPE, "sample_zh_test.txt"), test=True, language="zh")
+    bow = D.get_bow_zh(os.path.join(ECPE, "sample_zh_train.txt"), segmenter=char_segmenter)
+    tok = FakeTokenizer()
+    tr = D.ECPEDataset(train_df, tokenizer=tok, bow=bow, max_len=128, segmenter=char_segmenter)
+    te = D.ECPEDataset(test_df, tokenizer=tok, bow=bow, max_len=128, segmenter=char_segmenter)
+    return (torch.utils.data.DataLoader(tr, batch_size=bs, shuffle=True, num_workers=0, drop_last=True),
+            torch.utils.data.DataLoader(te, batch_size=len(te), shuffle=False, num_workers=0), test_df, sizes, unpred, len(bow))
+
+
+@pytest.mark.parametrize("mode", ["mmd", "vi"])
+def test_train_driver_end_to_end(tmp_path, mode):
+    torch.manual_seed(0)
+    train_loader, test_loader, test_df, sizes, unpred, V = _loaders(bs=4)
+    assert len(train_loader) >= 2
+    kw = dict(disentangle="vi", emotion_head="ce") if mode == "vi" else {}
+    opt = M.make_opt(epochs=2, pair_bow_dim=V, best_model_path=str(tmp_path / "ckpt"), model_id="e2e", vae_lr=1e-4, **kw)
+    model = M.DrlClassifier(opt, M.encoder_config("zh", vocab_size=1300, layers=2), seed=1).to("cuda")
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    if mode == "vi":
+        aprx, other = model.get_params()
+        optimizers = [torch.optim.Adam(aprx, lr=opt.aprx_lr), M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=True)]
+    else:
+        optimizers = [M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=True)]
+    logs = []
+    best = T.train(train_loader, test_loader, model, optimizers, "cuda", num_unpred_pairs=unpred, opt=opt, log=logs.append)
+    torch.cuda.synchronize()
+    assert best is model
+    after = model.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    assert any(k.startswith("encoder.encoder.layer.0.") for k in moved) and "decoder.weight" in moved
+    assert all(torch.isfinite(v).all() for v in after.values())
+    assert sum("f1 socre" in str(l) for l in logs) == 2                    # one evaluation per epoch
+    # checkpoint written when F1 improved, and it loads back into a fresh model with the reference's key names
+    ck = tmp_path / "ckpt" / "e2e.pt"
+    if ck.exists():
+        sd = torch.load(str(ck), map_location="cpu", weights_only=True)
+        assert set(sd) == set(after)
+        fresh = M.DrlClassifier(opt, M.encoder_config("zh", vocab_size=1300, layers=2), seed=2)
+        T.load_ckp(str(ck), fresh)
+    # pseudo-labelling pass over the test documents (:734-799)
+    df = T.generate_self_train_data(sizes, test_df, test_loader, model, "random")
+    assert list(df.columns) == ["pair", "label", "emotion"] and set(df["label"]) <= {0, 1}
+    preds = model.get_pair_preds(*(next(iter(test_loader))[k].cuda() for k in ("input_ids", "attention_masks", "token_type_ids")))
+    assert len(preds) == len(test_df) and all(p[0] in (0.0, 1.0) for p in preds)
