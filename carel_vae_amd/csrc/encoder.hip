@@ -169,6 +169,11 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
   g.splitk_ws = nullptr; g.splitk_ws_bytes = 0;
   float* cs = db ? (float*)slabs + (size_t)splits * M * N : nullptr;
   g.colsum_a = cs;
+  if (splits == 1) {                 // one slab IS the result: write it (and the bias sums) in place, nothing to reduce
+    g.out_f32 = dW;
+    if (db) g.colsum_a = db;
+    return carel_gemm_bf16(&g, stream);
+  }
   int rc = carel_gemm_bf16(&g, stream);
   if (rc) return rc;
   if ((rc = carel_slab_reduce_f32(slabs, dW, (int64_t)M * N, splits, 0, stream))) return rc;
