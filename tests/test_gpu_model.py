@@ -375,3 +375,32 @@ def test_adam_fused_into_backward_equals_plain_step(golden_dir, name):
     for k in res[False][1][1]:
         assert relnorm(res[True][1][1][k], res[False][1][1][k]) <= 1e-6, k
     assert relnorm(res[True][2], res[False][2]) < 1e-4 and relnorm(res[True][3], res[False][3]) < 1e-4
+
+
+@pytest.mark.parametrize("nb,varlen", [(2, False), (3, True), (5, False)])
+def test_gradients_small_batches(golden_dir, nb, varlen):
+    """Two to five pairs: the weight gradients run as ONE K slice written in place (no slabs), the batch is padded to a
+    multiple of 128 rows, the forward stays a single chain (odd batch) -- against the oracle's autograd."""
+    cfg, opt = CASES["zh_ragged"]
+    z, batch = load(golden_dir, "zh_ragged")
+    batch = {k: v[:nb].clone() for k, v in batch.items()}
+    batch["labels"][0], batch["cau_labels"][0] = 1.0, 1.0          # at least one positive pair
+    B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
+    model, P = build(cfg, opt, wseed)
+    model.train()
+    model.varlen = varlen
+    eps_e, eps_c = torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"])
+    model.set_noise(eps_e, eps_c)
+    loss = model(*call(model, batch, it0))
+    loss.backward()
+    torch.cuda.synchronize()
+    out, grads = O.loss_and_grads(P, batch, it0, cfg, opt, eps_e, eps_c)
+    terms = {k: float(v) for k, v in model.last_terms().items()}
+    for k in TERMS:
+        r = float(out[k])
+        assert abs(terms[k] - r) <= TOL_TERM_BF16 * max(abs(r), 1e-3), (k, terms[k], r)
+    named = dict(model.named_parameters())
+    worst = {k: relnorm(named[k].grad, g) for k, g in grads.items() if g is not None and float(g.norm()) > 1e-7}
+    bad = {k: v for k, v in worst.items() if v > 6e-2}
+    assert not bad, bad
+    assert np.median(list(worst.values())) < 2e-2
