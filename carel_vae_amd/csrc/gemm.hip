@@ -182,19 +182,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  // XCD-aware tile map: blocks that share an XCD (bid % 8; round-robin dispatch) get a compact 2-D patch of tiles
-  // (tiles_m / xm) x (tiles_n / xn), walked N-fastest, so that the patch's B columns stay in that XCD's L2 and each
-  // A row panel is read once per patch.  Falls back to bijective row-major chunks when the counts do not divide.
+  // XCD-aware tile map (blocks that share an XCD: bid % 8, round-robin dispatch).  Default (xcd_n = 1): each XCD gets a
+  // contiguous chunk of the row-major tile order, walked N-fastest; the weight gradients use 1 x 8 patches (xcd_n = 8: a
+  // compact (tiles_m / xm) x (tiles_n / xn) patch).  Option xcd_n = 0 (carel_gemm_set_variant(24)): each XCD owns
+  // tiles_m/8 whole tile rows and walks them M-fastest, which keeps its A panels in L2 and streams B once.  Measured
+  // (tools/exp_walk_pmc.py, tools/exp_walk_step.py): fabric-side fetch per launch falls -- QKV forward 97 -> 55 MB, FFN1
+  // forward 170 -> 75 MB, FFN2 dgrad 180 -> 126 MB -- but the GEMMs get 3-4 % SLOWER (530 -> 512 TFLOP/s in the step,
+  // 10.86 -> 11.16 ms serial, 9.34 -> 9.40 ms overlapped): the misses it removes were not on the critical path, and
+  // the M-fastest order spreads each moment's output rows over 8x more distinct 128-row panels.  Hence not the default.
   const int bid = blockIdx.x;
   int tm, tn;
   {
-    const int xn = p.xcd_n, xm = 8 / xn;
+    const int xn = p.xcd_n, xm = xn > 0 ? 8 / xn : 8;
     if (xn > 1 && p.tiles_m % xm == 0 && p.tiles_n % xn == 0) {
       const int xcd = bid & 7, local = bid >> 3;
       const int pm = p.tiles_m / xm, pn = p.tiles_n / xn;
       (void)pm;
       tm = (xcd / xn) * pm + local / pn;
       tn = (xcd % xn) * pn + local % pn;
+    } else if (xn == 0 && (p.tiles_m & 7) == 0) {
+      // each XCD owns tiles_m/8 whole tile rows and walks them M-FASTEST: the ~64 tiles in flight on an XCD then span
+      // all of its rows x a few columns, so its A panels stay in L2 for the whole launch and B streams through once
+      const int xcd = bid & 7, local = bid >> 3, rows = p.tiles_m >> 3;
+      tm = xcd * rows + local % rows;
+      tn = local / rows;
     } else {
       const int nwg = p.tiles_m * p.tiles_n;
       const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
@@ -537,7 +548,7 @@ static int launch_big(GemmParams p, int splits, hipStream_t s) {
 }
 
 static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x96 kernel
-static int g_xcd_n = 1;          // tuning hook: XCD patch layout (see gemm_kernel)
+static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-major chunks (default), 0 = row bands walked M-fastest, 2/4/8 = patches
 
 // Small-M GEMMs (packed ECPE batches: ~1.8 k tokens) launch only 84-170 workgroups of 12-48 K steps each on 256 CUs.
 // With a workspace they are run split-K into fp32 slabs + one fused-epilogue pass instead.
@@ -705,6 +716,7 @@ static int gemm_shape_ok(int M, int N, int K, int splits) {
 
 extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
+  if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
   if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }         // automatic use of the 256x192 tile off / on
   g_gemm_variant = v;
   return CAREL_OK;
@@ -727,7 +739,7 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   p.bias = (const float*)a->bias; p.resid = (const float*)a->resid_f32; p.aux = (const bf16_t*)a->aux_bf16;
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
-  p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n == 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
+  p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n <= 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
   p.splitk_ws = (float*)a->splitk_ws; p.splitk_ws_bytes = a->splitk_ws ? (size_t)a->splitk_ws_bytes : 0;
   if (a->ldc != a->N) p.splitk_ws = nullptr;                    // the slab epilogue assumes a dense C
   if (a->colsum_part) p.splitk_ws = nullptr;                    // fused column sums live in the single-pass epilogue
