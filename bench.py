@@ -243,10 +243,10 @@ def main():
         ach = fl_t / (ms_t * 1e-3) / 1e12
         traffic = None
         try:        # HBM traffic per GEMM launch from the committed PMC summary (rocprofv3 --pmc passes)
-            for line in open(os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.csv")):
+            for line in open(os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.csv")):
                 if line.startswith('"ALL carel::gemm_kernel'):
                     f = line.rsplit(",", 3)
-                    traffic = {"bytes_per_launch": (float(f[2]) + float(f[3])) * 1e6, "source": "profiles/r01_d_pmc_hbm_traffic.csv (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the serial dense run)"}
+                    traffic = {"bytes_per_launch": (float(f[2]) + float(f[3])) * 1e6, "source": "profiles/r01_e_pmc_hbm_traffic.csv (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the serial dense run)"}
         except OSError:
             pass
         roof = {"bound": "mfma", "kernel": "carel::gemm_kernel (all instantiations: fwd NT, dgrad NN, wgrad TN)",
