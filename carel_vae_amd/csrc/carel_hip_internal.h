@@ -20,6 +20,8 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        hipStream_t stream);
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);
 
+// split-K heuristics of carel_gemm_bf16: treat the grid as `f` times larger (f equal GEMMs run side by side); gemm.hip
+void gemm_split_tile_factor(int f);
 int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,
                     void* partials, void* row_scratch, hipStream_t stream);
 

@@ -288,8 +288,11 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   if (hipEventRecord(sd->ev[0], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->peer, sd->ev[0], 0) != hipSuccess)
     return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event fork failed");
   char* ws2 = (char*)a->scratch + sl.o_slabs;                    // the weight-gradient slabs are idle during the forward pass
-  if ((rc = forward_layers(a, 0, lsplit, hb, hb, (void*)sd->peer, ws2, sl.ws_bytes))) return rc;
-  if ((rc = forward_layers(a, 0, lsplit, 0, hb, stream, ws, ws_bytes))) return rc;
+  gemm_split_tile_factor(2);                                     // same split-K choices (same bits) as the one-chain forward
+  rc = forward_layers(a, 0, lsplit, hb, hb, (void*)sd->peer, ws2, sl.ws_bytes);
+  if (!rc) rc = forward_layers(a, 0, lsplit, 0, hb, stream, ws, ws_bytes);
+  gemm_split_tile_factor(1);
+  if (rc) return rc;
   if (hipEventRecord(sd->ev[1], sd->peer) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, sd->ev[1], 0) != hipSuccess)
     return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event join failed");
   if (lsplit < a->n_layers) return forward_layers(a, lsplit, a->n_layers, 0, B, stream, ws, ws_bytes);

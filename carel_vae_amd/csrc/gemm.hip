@@ -552,9 +552,13 @@ static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-m
 
 // Small-M GEMMs (packed ECPE batches: ~1.8 k tokens) launch only 84-170 workgroups of 12-48 K steps each on 256 CUs.
 // With a workspace they are run split-K into fp32 slabs + one fused-epilogue pass instead.
+// g_split_tile_factor (carel::gemm_split_tile_factor, internal): the caller runs this many equal GEMMs side by side (the
+// forward's half-batch chains), so the split factor is chosen as for ONE GEMM over all of their rows -- the same K
+// partition, hence the same bits, as the single-chain forward.
+static int g_split_tile_factor = 1;
 static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   if (g_gemm_variant != 0) return 1;
-  const int tiles = p.tiles_m * p.tiles_n;
+  const int tiles = p.tiles_m * p.tiles_n * g_split_tile_factor;
   int s = 1;
   while (tiles * s < 256 && p.K >= 1536 && (p.K / (s * 2)) >= 384 && p.K % (128 * s) == 0 &&
          (size_t)(s * 2) * p.M * p.N * 4 <= ws_bytes) s *= 2;
@@ -623,6 +627,8 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     *(float4*)(out + i) = a;
   }
 }
+
+void gemm_split_tile_factor(int f) { g_split_tile_factor = f > 0 ? f : 1; }
 
 }  // namespace carel
 
