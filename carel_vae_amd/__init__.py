@@ -6,11 +6,11 @@ The Python host code mirrors the module surface of the reference's drl_classifie
 C ABI of include/carel_hip.h.  There is no CPU / eager fallback.
 """
 from . import _lib  # noqa: F401
-from .data import ECPEDataset, get_bow_en, get_bow_zh, read_ECPE_data  # noqa: F401
+from .data import BatchLoader, ECPEDataset, get_bow_en, get_bow_zh, read_ECPE_data  # noqa: F401
 from .drl_classifier import (HSIC, DrlClassifier, FusedAdam, MMDStatistic, encoder_config, make_opt, pdist,  # noqa: F401
                              permutation_test_mat)
 from .training import generate_self_train_data, load_ckp, save_ckp, train  # noqa: F401
 
-__all__ = ["ECPEDataset", "DrlClassifier", "MMDStatistic", "pdist", "HSIC", "permutation_test_mat", "read_ECPE_data", "train",
+__all__ = ["ECPEDataset", "BatchLoader", "DrlClassifier", "MMDStatistic", "pdist", "HSIC", "permutation_test_mat", "read_ECPE_data", "train",
            "generate_self_train_data", "save_ckp", "load_ckp", "get_bow_zh", "get_bow_en", "FusedAdam", "make_opt",
            "encoder_config"]

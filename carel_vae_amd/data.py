@@ -226,3 +226,73 @@ class ECPEDataset(torch.utils.data.Dataset):
             "cau_labels": torch.FloatTensor([self.cau_labels[index]]),
             "bow_reps": torch.from_numpy(self.bow_representations[index]).clone(),
         }
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchLoader: drop-in for `DataLoader(dataset, batch_size, shuffle, num_workers=0)` (ref :952-961)
+# ----------------------------------------------------------------------------------------------
+class BatchLoader:
+    """Yields the same dict-of-tensors batches as `torch.utils.data.DataLoader(ECPEDataset, batch_size, shuffle,
+    num_workers=0)` -- same keys, dtypes, shapes and, under the same `torch.manual_seed`, the same sample order (the index
+    stream of torch's RandomSampler is reproduced) -- but each batch is ONE row gather per field from tensors stacked at
+    construction instead of `batch_size` `__getitem__` calls and a collate (64 x 95 KB bag-of-words rows cloned and
+    re-stacked per batch at V = 23 771).  pin_memory=True allocates each batch in page-locked memory (as the stock
+    loader's flag does); that allocation is slow, so it only pays when the copies are overlapped with compute.  Adds `seq_lengths` (host list of attended lengths) so the model can skip padding without reading
+    the mask back from the device.  Needs a dataset built with a tokenizer (pretokenize=True)."""
+
+    def __init__(self, dataset, batch_size=64, shuffle=False, drop_last=False, pin_memory=False, generator=None):
+        if dataset._cache is None and len(dataset):
+            raise ValueError("BatchLoader needs ECPEDataset(..., tokenizer=..., pretokenize=True)")
+        self.dataset, self.batch_size, self.shuffle, self.drop_last, self.generator = dataset, int(batch_size), shuffle, drop_last, generator
+        n = len(dataset)
+        ids, att, tt = dataset._cache if n else (torch.zeros((0, dataset.max_len), dtype=torch.long),) * 3
+        V = len(dataset.bow_features)
+        bow = torch.from_numpy(np.stack(dataset.bow_representations)) if n else torch.zeros((0, V))
+        self.fields = {
+            "input_ids": ids, "attention_masks": att, "token_type_ids": tt,
+            "labels": torch.as_tensor(np.asarray(dataset.labels, dtype=np.float32)).view(-1, 1),
+            "emo_labels": torch.as_tensor(np.asarray(dataset.emo_labels, dtype=np.int64)).view(-1, 1),
+            "cau_labels": torch.as_tensor(np.asarray(dataset.cau_labels, dtype=np.float32)).view(-1, 1),
+            "bow_reps": bow.to(torch.float32),
+        }
+        self.lengths = att.sum(1).tolist()
+        self.pin = bool(pin_memory) and torch.cuda.is_available()
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _order(self):
+        n = len(self.dataset)
+        if not self.shuffle:
+            return torch.arange(n)
+        g = self.generator
+        if g is None:
+            # what DataLoader + RandomSampler draw from the global stream (torch 2.x): the iterator's base seed first
+            # (unused with num_workers=0), then the sampler's seed for a private generator
+            torch.empty((), dtype=torch.int64).random_()
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator()
+            g.manual_seed(seed)
+        return torch.randperm(n, generator=g)
+
+    def __iter__(self):
+        order = self._order()
+        n = len(order)
+        for s in range(0, n, self.batch_size):
+            idx = order[s:s + self.batch_size]
+            if len(idx) < self.batch_size and self.drop_last:
+                return
+            batch = {}
+            # single-threaded on purpose: a parallel gather leaves the OpenMP pool spin-waiting on every core, which starves
+            # the HIP runtime's threads -- measured: a whole training epoch 5x slower (tools/bench_train_epoch.py)
+            nt = torch.get_num_threads()
+            torch.set_num_threads(1)
+            try:
+                for k, t in self.fields.items():
+                    out = t.index_select(0, idx)      # (the out= form of index_select is ~60x slower on CPU)
+                    batch[k] = out.pin_memory() if self.pin else out
+            finally:
+                torch.set_num_threads(nt)
+            batch["seq_lengths"] = [self.lengths[i] for i in idx.tolist()]
+            yield batch

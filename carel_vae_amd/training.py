@@ -104,8 +104,11 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
             # attended lengths from the HOST copy of the mask: lets the model skip padding without reading the mask back
             # from the device (a sync that would stop the host from running ahead of the GPU)
             kw = {}
-            if getattr(model, "varlen", False) and not batch["attention_masks"].is_cuda:
-                kw["seq_lengths"] = batch["attention_masks"].sum(1).tolist()
+            if getattr(model, "varlen", False):
+                if "seq_lengths" in batch:                               # carel_vae_amd.data.BatchLoader provides them
+                    kw["seq_lengths"] = batch["seq_lengths"]
+                elif not batch["attention_masks"].is_cuda:
+                    kw["seq_lengths"] = batch["attention_masks"].sum(1).tolist()
             ids = batch["input_ids"].to(device, dtype=torch.long, non_blocking=True)
             att = batch["attention_masks"].to(device, dtype=torch.long, non_blocking=True)
             tt = batch["token_type_ids"].to(device, dtype=torch.long, non_blocking=True)

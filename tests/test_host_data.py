@@ -104,3 +104,24 @@ def test_bow_vocabularies():
     assert len(ven) == 7            # spaces are removed first (bow_util.py:70): one "word" per clause
     vopt = D.get_bow_en(os.path.join(HERE, "golden", "ecpe", "sample_en_train.txt"), bow_optimize=True)
     assert "sep" in vopt and "storm" in vopt and "villagers" in vopt
+
+
+def test_batch_loader_equals_stock_dataloader():
+    """BatchLoader yields what DataLoader(dataset, batch_size, shuffle, num_workers=0) yields: same keys, dtypes, shapes,
+    values and (same torch seed) sample order; plus the host-side attended lengths."""
+    random.seed(42)
+    df, _, _ = D.read_ECPE_data(os.path.join(HERE, "golden", "ecpe", "sample_zh_train.txt"), test=False, language="zh")
+    bow = D.get_bow_zh(os.path.join(HERE, "golden", "ecpe", "sample_zh_train.txt"), segmenter=char_segmenter)
+    ds = D.ECPEDataset(df, tokenizer=FakeTokenizer(), bow=bow, max_len=64, segmenter=char_segmenter)
+    for shuffle, drop_last, bs in ((False, False, 4), (True, False, 4), (True, True, 5)):
+        torch.manual_seed(123)
+        ref = list(torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=shuffle, num_workers=0, drop_last=drop_last))
+        torch.manual_seed(123)
+        fast = D.BatchLoader(ds, batch_size=bs, shuffle=shuffle, drop_last=drop_last, pin_memory=False)
+        got = list(fast)
+        assert len(got) == len(ref) == len(fast)
+        for a, b in zip(ref, got):
+            assert set(b) == set(a) | {"seq_lengths"}
+            for k in a:
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (k, shuffle)
+            assert b["seq_lengths"] == a["attention_masks"].sum(1).tolist()
