@@ -136,6 +136,27 @@ __device__ __forceinline__ void stage_row_image(const bf16_t* __restrict__ g, lo
     __builtin_amdgcn_global_load_lds(src, (CAREL_LDS void*)(lds_tile + q * 1024), 16, 0, 0);
   }
 }
+// The same two stagings with the address split into a per-lane 32-bit byte offset that is computed ONCE per kernel
+// (row_lane_off / col_lane_off, one per DMA instruction of the wave) and a wave-uniform byte pointer that the caller
+// advances per K step: the loads then take the SGPR-base + VGPR-offset form and the loop body carries no 64-bit
+// multiply-adds (the plain forms above cost ~60 VALU instructions per K step for eight loads).
+__device__ __forceinline__ uint32_t row_lane_off(long ld, int i) {            // 128-row ROW image, DMA i of this wave (0..3)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = wave * 4 + i, r = q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+  return (uint32_t)((r * ld + c * 8) * 2);
+}
+__device__ __forceinline__ uint32_t col_lane_off(long ld, int i) {            // COL image, DMA i of this wave (0..3)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = wave * 4 + i, r = q * 4 + (lane >> 4), c = (lane & 15) ^ swz_col(r);
+  return (uint32_t)((r * ld + c * 8) * 2);
+}
+// base: wave-uniform byte pointer to element (row0, k0) [ROW] / (krow0, x0) [COL] of the global matrix
+__device__ __forceinline__ void stage_image_fast(const char* base, const uint32_t (&off)[4], char* lds_tile) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    __builtin_amdgcn_global_load_lds((const void*)(base + off[i]), (CAREL_LDS void*)(lds_tile + (wave * 4 + i) * 1024), 16, 0, 0);
+}
 // COL image: 64 k-rows x 128 columns, global matrix is [k][x] row-major.
 __device__ __forceinline__ void stage_col_image(const bf16_t* __restrict__ g, long ld, long krow0, long x0,
                                                 char* lds_tile) {

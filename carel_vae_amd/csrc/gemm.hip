@@ -230,13 +230,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
+  // per-lane byte offsets of this wave's four DMA pieces of each operand (constant over K) and the wave-uniform bases
+  uint32_t aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aoff[i] = AT ? col_lane_off(p.lda, i) : row_lane_off(p.lda, i);
+    boff[i] = BT ? col_lane_off(p.ldb, i) : row_lane_off(p.ldb, i);
+  }
+  const char* abase = (const char*)(AT ? p.A + kbase * p.lda + m0 : p.A + m0 * p.lda + kbase);
+  const char* bbase = (const char*)(BT ? p.B + kbase * p.ldb + n0 : p.B + n0 * p.ldb + kbase);
+  const long astep = AT ? 64 * p.lda * 2 : 128, bstep = BT ? 64 * p.ldb * 2 : 128;     // bytes per K step
   auto stage = [&](int kt, int buf) {
     char* ta = smem + buf * 32768;
     char* tb = ta + 16384;
-    const long k0 = (DBG == 9) ? 0 : kbase + (long)kt * 64;             // DBG 9: every block re-reads one L2-hot tile
-    const long ms = (DBG == 9) ? 0 : m0, ns = (DBG == 9) ? 0 : n0;
-    if (AT) stage_col_image(p.A, p.lda, k0, ms, ta); else stage_row_image<128>(p.A, p.lda, ms, k0, ta);
-    if (BT) stage_col_image(p.B, p.ldb, k0, ns, tb); else stage_row_image<128>(p.B, p.ldb, ns, k0, tb);
+    const long kk = (DBG == 9) ? 0 : kt;                                 // DBG 9: every block re-reads one L2-hot tile
+    stage_image_fast(((DBG == 9) ? (const char*)p.A : abase) + kk * astep, aoff, ta);
+    stage_image_fast(((DBG == 9) ? (const char*)p.B : bbase) + kk * bstep, boff, tb);
   };
 
   const int nk = p.K >> 6;
