@@ -243,7 +243,7 @@ def main():
         ach = fl_t / (ms_t * 1e-3) / 1e12
         traffic = None
         try:        # HBM traffic per GEMM launch from the committed PMC summary (rocprofv3 --pmc passes)
-            for line in open(os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.csv")):
+            for line in open(os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.csv")):
                 if line.startswith('"ALL carel::gemm_kernel'):
                     f = line.rsplit(",", 3)
                     traffic = (float(f[2]) + float(f[3])) * 1e6        # bytes per GEMM launch (fetch x2-corrected + write)
@@ -251,7 +251,7 @@ def main():
             pass
         roof = {"bound": "mfma", "kernel": "carel::gemm_kernel (all instantiations: fwd NT, dgrad NN, wgrad TN)",
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                "traffic_unit": "bytes per launch, HBM/fabric side", "traffic_source": "profiles/r01_e_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE x2 and --pmc WRITE_SIZE, separate passes of the serial dense run; algorithmic operand+output bytes average ~40e6)",
+                "traffic_unit": "bytes per launch, HBM/fabric side", "traffic_source": "profiles/r01_f_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE x2 and --pmc WRITE_SIZE, separate passes of the serial dense run; algorithmic operand+output bytes average ~40e6)",
                 "launches_per_step": n_t / nprof, "avg_launch_us": 1e3 * ms_t / n_t, "alg_gflop_per_launch": fl_t / n_t / 1e9,
                 "gemm_ms_per_step": ms_t / nprof,
                 "note": "per-kernel durations from a serial replay of the step (wgrad_side_stream off); the timed region overlaps them",
