@@ -569,7 +569,7 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   if (g_gemm_variant != 0) return 1;
   const int tiles = p.tiles_m * p.tiles_n * g_split_tile_factor;
   int s = 1;
-  while (tiles * s < 256 && p.K >= 1536 && (p.K / (s * 2)) >= 384 && p.K % (128 * s) == 0 &&
+  while (tiles * s < 256 && p.K >= 768 && (p.K / (s * 2)) >= 384 && p.K % (128 * s) == 0 &&
          (size_t)(s * 2) * p.M * p.N * 4 <= ws_bytes) s *= 2;
   return s;
 }
