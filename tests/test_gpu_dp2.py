@@ -1,0 +1,110 @@
+"""Two real data-parallel ranks on the one GPU (gloo for the collectives, both processes on cuda:0): DataParallel over two
+shards of a batch must reproduce the single-process step on the whole batch -- loss, averaged gradients and updated
+weights -- with dropout ON (the masks hash the global row index) and the global-batch MMD / pos_weight / shared noise
+(SURVEY 8(e)).  RCCL itself refuses two ranks on one device; its single-rank path is covered by tests/test_gpu_dp.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+KEYS = ["encoder.encoder.layer.0.attention.self.query.weight", "encoder.encoder.layer.1.output.dense.weight",
+        "encoder.encoder.layer.1.output.LayerNorm.weight", "encoder.embeddings.position_embeddings.weight",
+        "encoder.pooler.dense.weight", "decoder.weight", "pair_classifier.weight", "emotion_classifier.bias"]
+
+
+def _build():
+    from carel_vae_amd import drl_classifier as M
+    from oracle import carel_oracle as O
+    cfg, opt = O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=513, dropout=0.3)
+    z = np.load(os.path.join(HERE, "golden", "zh_ragged.npz"), allow_pickle=False)
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    mcfg = M.encoder_config("zh", vocab_size=cfg.vocab_size, layers=cfg.layers)          # encoder dropout 0.1 on
+    model = M.DrlClassifier(M.make_opt(**vars(opt)), mcfg)
+    model.load_state_dict(O.init_params(cfg, opt, seed=int(z["meta"][5])))
+    model.to("cuda").train()
+    eps = (torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"]))
+    return M, model, batch, eps, opt
+
+
+def _step(M, model, batch, eps, opt, lo, hi):
+    b = {k: v[lo:hi].cuda() for k, v in batch.items()}
+    optim = M.FusedAdam(model, lr=1e-3)
+    model.set_noise(*eps)
+    loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"], b["bow_reps"], 3)
+    optim.zero_grad()
+    loss.backward()
+    named = dict(model.named_parameters())
+    grads = {k: named[k].grad.detach().float().cpu().clone() for k in KEYS}
+    optim.step()
+    torch.cuda.synchronize()
+    weights = {k: named[k].detach().float().cpu().clone() for k in KEYS}
+    terms = {k: float(v) for k, v in model.last_terms().items()}
+    return float(loss.detach()), terms, grads, weights
+
+
+def _worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from carel_vae_amd.dp import DataParallel
+        M, model, batch, eps, opt = _build()
+        DataParallel(model)
+        B = batch["input_ids"].shape[0]
+        n = B // world
+        loss, terms, grads, weights = _step(M, model, batch, eps, opt, rank * n, (rank + 1) * n)
+        # plain numpy through the queue (torch tensors would travel as shared-memory handles that die with this process)
+        q.put((rank, (loss, terms, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in weights.items()})))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:           # surface the failure instead of hanging the parent
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc()))
+
+
+def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in res.values():
+        assert not isinstance(r, str), r
+    M, model, batch, eps, opt = _build()
+    loss, terms, grads, weights = _step(M, model, batch, eps, opt, 0, batch["input_ids"].shape[0])
+    # the MMD statistic and the pair term's pos_weight are those of the WHOLE batch on every rank
+    for r in range(world):
+        assert abs(res[r][1]["mmd"] - terms["mmd"]) <= 1e-5 * max(abs(terms["mmd"]), 1e-3), (r, res[r][1]["mmd"], terms["mmd"])
+    # batch-mean terms: the average over the shards is the whole-batch value
+    for k in ("emo", "cau", "pair", "kl_e", "kl_c", "rec"):
+        avg = sum(res[r][1][k] for r in range(world)) / world
+        assert abs(avg - terms[k]) <= 2e-4 * max(abs(terms[k]), 1e-3), (k, avg, terms[k])
+    # averaged gradients and updated weights are identical on both ranks and equal to the single-process ones
+    for k in KEYS:
+        g0, g1, g = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k]), grads[k]
+        assert torch.equal(g0, g1), k
+        den = float(g.norm()) + 1e-12
+        assert float((g0 - g).norm()) / den < 2e-3, (k, float((g0 - g).norm()) / den)
+        w0, w1 = torch.from_numpy(res[0][3][k]), torch.from_numpy(res[1][3][k])
+        assert torch.equal(w0, w1), k
+        assert float((w0 - weights[k]).abs().max()) <= 2.2e-3, k      # Adam: |update| <= lr, sign flips at ~0 gradients
