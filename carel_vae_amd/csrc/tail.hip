@@ -175,6 +175,7 @@ struct TailCore {
   int label_sum_ranks;          // > 1: the global label sum is the sum of this many floats, rank_stride apart
   const float* z_global; int n_global, row_offset; float mmd_grad_scale;  // global-batch MMD (DP)
   int rank_stride;              // floats between consecutive ranks' blocks of B rows in z_global (B*2D when dense)
+  const float* mmd_part; int mmd_nblk; const float* dz_mmd;   // global-batch MMD computed by mmd_global_kernel (else null)
   // outputs
   float* z;                     // [B, 2D]
   float* terms;                 // [16]: 0 partial loss (everything but rec), 1 mmd, 2 emo, 3 cau, 4 pair, 5 kl_e, 6 kl_c
@@ -185,6 +186,93 @@ struct TailCore {
   long long* prof;              // diagnostics (carel_tail_profile): phase time stamps, or null
 };
 #define TAIL_STAMP(i) do { if (a.prof && threadIdx.x == 0) a.prof[i] = (long long)wall_clock64(); } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Global-batch RBF-MMD for data parallel runs (z_global = every rank's sampled latents): the statistic needs all
+// (2n)^2 pairs -- 1 M at 8 x 64 samples -- which one workgroup would chew on for ~0.4 ms.  Here each workgroup takes 32
+// rows (8 lanes per row split the partners, streamed through LDS in chunks of 256 rows) and writes its partial sums of
+// the three blocks; rows of THIS rank's samples also get d(gscale * mmd)/dz.  tail_core_kernel adds the partials in
+// block order.  Feature width padded to CD with zeros (CD = 24: the reference's ec_dim; 32: anything else <= 32).
+// ------------------------------------------------------------------------------------------
+struct MmdGlobalArgs {
+  const float* zg; int n, B, D, rank_stride, row_offset;     // n samples per side in total, B per rank
+  float alpha, eps, gscale;
+  float* part;      // [gridDim.x][4]: s11, s22, s12
+  float* dz;        // [B][2D] (local rows)
+};
+template <int CD>
+__global__ __launch_bounds__(256) void mmd_global_kernel(MmdGlobalArgs a) {
+  constexpr int CH = 256, ZS = CD + 1;
+  __shared__ float zc[CH * ZS];
+  __shared__ float nc[CH];
+  __shared__ float red[64];
+  const int t = threadIdx.x, grp = t & 7;
+  const int n = a.n, n2 = 2 * n, D = a.D, D2 = 2 * D;
+  auto zrow = [&](int r) -> const float* {               // row r of Z = [all emotion samples ; all cause samples]
+    const int side = r >= n, s = r - side * n;
+    return a.zg + (long)(s / a.B) * a.rank_stride + (long)(s % a.B) * D2 + side * D;
+  };
+  const int i = blockIdx.x * 32 + (t >> 3);
+  const bool live = i < n2;
+  float zi[CD], g[CD];
+  float ni = 0.f;
+  {
+    const float* zp = zrow(live ? i : 0);
+#pragma unroll
+    for (int k = 0; k < CD; ++k) { zi[k] = (k < D) ? zp[k] : 0.f; g[k] = 0.f; ni = fmaf(zi[k], zi[k], ni); }
+  }
+  const bool i1 = i < n;
+  const int si = i - (i1 ? 0 : n);
+  const bool local = live && si >= a.row_offset && si < a.row_offset + a.B;
+  const float a00 = (float)(1.0 / ((double)n * (n - 1))), a01 = (float)(-1.0 / ((double)n * n));
+  float s11 = 0.f, s22 = 0.f, s12 = 0.f;
+  for (int c0 = 0; c0 < n2; c0 += CH) {
+    const int cn = min(CH, n2 - c0);
+    __syncthreads();
+    for (int e = t; e < cn * CD; e += 256) {
+      const int r = e / CD, k = e - r * CD;
+      zc[r * ZS + k] = (k < D) ? zrow(c0 + r)[k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = t; r < cn; r += 256) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < CD; ++k) s = fmaf(zc[r * ZS + k], zc[r * ZS + k], s);
+      nc[r] = s;
+    }
+    __syncthreads();
+    if (live) {
+      for (int jj = grp; jj < cn; jj += 8) {
+        const int j = c0 + jj;
+        if (j == i) continue;
+        float zj[CD], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CD; ++k) { zj[k] = zc[jj * ZS + k]; dot = fmaf(zi[k], zj[k], dot); }
+        const float d2 = ni + nc[jj] - 2.0f * dot;
+        const float e = expf(-a.alpha * (a.eps + fabsf(d2)));
+        const bool j1 = j < n;
+        if (i1 && j1) s11 += e; else if (!i1 && !j1) s22 += e; else if (i1 && !j1) s12 += e;
+        if (local) {
+          const float dcs = (d2 > 0.f) ? a.alpha * e : ((d2 < 0.f) ? -a.alpha * e : 0.f);
+          const float coef = -4.0f * ((i1 == j1) ? a00 : a01) * dcs * a.gscale;
+#pragma unroll
+          for (int k = 0; k < CD; ++k) g[k] = fmaf(coef, zi[k] - zj[k], g[k]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CD; ++k) {
+    float v = g[k];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    if (local && grp == 0 && k < D) a.dz[(long)(si - a.row_offset) * D2 + (i1 ? 0 : D) + k] = v;
+  }
+  __syncthreads();
+  s11 = block_sum(s11, red);
+  s22 = block_sum(s22, red + 16);
+  s12 = block_sum(s12, red + 32);
+  if (t == 0) { a.part[blockIdx.x * 4] = s11; a.part[blockIdx.x * 4 + 1] = s22; a.part[blockIdx.x * 4 + 2] = s12; }
+}
 
 static long long* g_tail_prof = nullptr;
 
@@ -223,8 +311,8 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     hw[e] = e < o_eb ? a.emo_w[e] : e < o_cw ? a.emo_b[e - o_eb] : e < o_cb ? a.cau_w[e - o_cw] : e < o_pw ? a.cau_b[0]
           : e < o_pb ? a.pair_w[e - o_pw] : a.pair_b[0];
   __syncthreads();
-  // ---- MMD samples: rows [0,nm) emotion, [nm,2nm) cause
-  for (int e = t; e < 2 * nm * D; e += blockDim.x) {
+  // ---- MMD samples: rows [0,nm) emotion, [nm,2nm) cause   (not needed when mmd_global_kernel did the statistic)
+  for (int e = t; e < (a.mmd_part ? 0 : 2 * nm * D); e += blockDim.x) {
     const int i = e / D, k = e - i * D;
     const int s = i < nm ? i : i - nm, off = i < nm ? 0 : D;
     Z[i * zs + k] = a.z_global ? a.z_global[(long)(s / B) * a.rank_stride + (long)(s % B) * D2 + off + k] : zl[s * D2 + off + k];
@@ -233,7 +321,20 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   TAIL_STAMP(1);
   float mmd = 0.f;                     // value of the disentanglement statistic (terms[1])
   float dis_term = 0.f;                // its contribution to the loss
-  if (a.dis_mode == 0) {
+  if (a.dis_mode == 0 && a.mmd_part) {
+    // partial block sums in fixed order (double accumulation as in mmd_forward_block), gradient rows already computed
+    if (t == 0) {
+      double s11 = 0.0, s22 = 0.0, s12 = 0.0;
+      for (int q = 0; q < a.mmd_nblk; ++q) { s11 += a.mmd_part[q * 4]; s22 += a.mmd_part[q * 4 + 1]; s12 += a.mmd_part[q * 4 + 2]; }
+      const double b00 = 1.0 / ((double)nm * (nm - 1)), b01 = -1.0 / ((double)nm * nm);
+      sc[0] = (float)(2.0 * b01 * s12 + b00 * s11 + b00 * s22);
+    }
+    __syncthreads();
+    mmd = sc[0];
+    dis_term = -a.w_mmd * mmd;
+    for (int e = t; e < B * D2; e += blockDim.x) dzl[e] += a.dz_mmd[e];
+    TAIL_STAMP(2);
+  } else if (a.dis_mode == 0) {
     MmdCfg mc; mc.n1 = nm; mc.n2 = nm; mc.d = D; mc.zs = zs; mc.n_alphas = 1; mc.alphas[0] = a.alpha; mc.eps = a.mmd_eps;
     if (!a.z_global && D == 24) {      // the configuration of every reference script: one fused forward + backward sweep
       mmd = mmd_forward_backward_block<24>(mc, Z, nrm, red, -a.w_mmd * a.mmd_grad_scale, dzl, D2);
@@ -681,10 +782,11 @@ __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restric
 using namespace carel;
 
 static size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
+constexpr int MMD_MAX_BLOCKS = 1024;          // mmd_global_kernel: 32 rows per block -> up to 16 384 samples per side
 
 struct TailWork {     // carve-up of the caller's f32 workspace
   float* dz_core; float* dlat_direct; float* dlat; float* dpooled; float* dpre; float* part; float* rowstat; float* dz_part;
-  float* dcls; float* dgpart; float* pair_dead;
+  float* dcls; float* dgpart; float* pair_dead; float* mmd_part; float* dz_mmd;
   size_t total;
 };
 static TailWork carve(float* base, int B, int D, int V) {
@@ -696,6 +798,7 @@ static TailWork carve(float* base, int B, int D, int V) {
   w.rowstat = take((size_t)B * 4); w.dz_part = take((size_t)chunks * B * 2 * D); w.dcls = take((size_t)B * TH);
   w.dgpart = take((size_t)((TH + DG_CHUNK - 1) / DG_CHUNK) * B * TH);
   w.pair_dead = take(16);
+  w.mmd_part = take(4 * MMD_MAX_BLOCKS); w.dz_mmd = take((size_t)B * 2 * D);
   w.total = o;
   return w;
 }
@@ -789,7 +892,7 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   c.z = (float*)a->z; c.terms = (float*)a->terms; c.dz = w.dz_core; c.dlat_direct = w.dlat_direct;
   c.d_emo_w = (float*)a->d_emo_w; c.d_emo_b = (float*)a->d_emo_b; c.d_cau_w = (float*)a->d_cau_w; c.d_cau_b = (float*)a->d_cau_b;
   c.d_pair_w = (float*)a->d_pair_w; c.d_pair_b = (float*)a->d_pair_b; c.pair_dead = w.pair_dead;
-  const int nm = c.z_global ? c.n_global : B;
+  const int nm = (c.z_global && c.dis_mode != 0) ? c.n_global : B;        // the global-batch MMD runs in its own kernel
   const int n_hw = a->e_classes * D + a->e_classes + D + 1 + 2 * D + 1;
   const size_t lds = sizeof(float) * (64 + 64 + (size_t)2 * B * 2 * D + (size_t)B * 8 + (size_t)B * 2 + (size_t)B * 4 * D + (size_t)B * 16 +
                                       ((n_hw + 3) & ~3) + ((2 * nm + 3) & ~3) + (size_t)2 * nm * (D | 1) + 2 * (size_t)B);
@@ -797,6 +900,18 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)tail_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  c.mmd_part = nullptr; c.mmd_nblk = 0; c.dz_mmd = nullptr;
+  if (c.z_global && c.dis_mode == 0) {
+    MmdGlobalArgs g;
+    g.zg = c.z_global; g.n = c.n_global; g.B = B; g.D = D; g.rank_stride = c.rank_stride; g.row_offset = c.row_offset;
+    g.alpha = c.alpha; g.eps = c.mmd_eps; g.gscale = -c.w_mmd * c.mmd_grad_scale; g.part = w.mmd_part; g.dz = w.dz_mmd;
+    const int nblk = (2 * c.n_global + 31) / 32;
+    if (nblk > MMD_MAX_BLOCKS) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: global batch too large for the MMD partial buffer");
+    if (D == 24) hipLaunchKernelGGL(mmd_global_kernel<24>, dim3(nblk), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(mmd_global_kernel<32>, dim3(nblk), dim3(256), 0, stream, g);
+    if ((rc = check_launch("mmd_global_kernel"))) return rc;
+    c.mmd_part = w.mmd_part; c.mmd_nblk = nblk; c.dz_mmd = w.dz_mmd;
   }
   c.prof = g_tail_prof;
   hipLaunchKernelGGL(tail_core_kernel, dim3(1), dim3(1024), lds, stream, c);

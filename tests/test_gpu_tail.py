@@ -134,6 +134,34 @@ def test_tail_global_batch_hooks(strided):
         close(tot[k], grads[k], 3e-4, 3e-5 * scale, k)
 
 
+def test_tail_global_batch_eight_ranks_of_64():
+    """The 8-GPU configuration of BASELINE.json: 8 shards x 64 samples, global-batch MMD over 512 samples per side (1 M
+    pairs, its own multi-workgroup kernel).  Two of the shards are run and compared with the oracle on the whole batch."""
+    B, S, V, it, seed, R = 512, 1, 200, 3, 9, 8
+    cfg, opt, P, x_last, batch, eps_e, eps_c = setup(B, S, V, seed=6)
+    out, pooled, grads, dx = oracle_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, it, True, seed)
+    Bl = B // R
+    zs = []
+    for r in range(R):
+        sb = {k: v[r * Bl:(r + 1) * Bl] for k, v in batch.items()}
+        buf, _ = hip_tail(P, x_last[r * Bl * S:(r + 1) * Bl * S], sb, eps_e, eps_c, opt, Bl, S, V, it, (opt.dropout, seed, r * Bl))
+        zs.append(buf.z.clone())
+    stride = Bl * 48 + 16
+    packed = torch.full((R, stride), float("nan"), device="cuda")
+    for r in range(R):
+        packed[r, :Bl * 48] = zs[r].reshape(-1)
+        packed[r, Bl * 48] = float(batch["labels"][r * Bl:(r + 1) * Bl].sum())
+    for r in (0, 5):
+        sb = {k: v[r * Bl:(r + 1) * Bl] for k, v in batch.items()}
+        buf, G = hip_tail(P, x_last[r * Bl * S:(r + 1) * Bl * S], sb, eps_e, eps_c, opt, Bl, S, V, it, (opt.dropout, seed, r * Bl),
+                          global_label_sum=packed.view(-1)[Bl * 48:], global_n=B, global_row_offset=r * Bl, z_global=packed,
+                          mmd_grad_scale=float(R), global_rank_stride=stride, global_label_ranks=R)
+        t = buf.terms.cpu().numpy()
+        np.testing.assert_allclose(t[1], float(out["mmd"]), rtol=5e-5, atol=2e-6)
+        scale = float(dx.abs().max())
+        close(buf.dx_last / R, dx[r * Bl * S:(r + 1) * Bl * S], 5e-4, 5e-5 * scale, "dx shard %d" % r)
+
+
 def test_pair_probs_matches_oracle():
     B, S, V = 50, 2, 64
     cfg, opt, P, x_last, batch, eps_e, eps_c = setup(B, S, V, seed=77)
