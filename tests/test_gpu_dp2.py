@@ -78,8 +78,9 @@ def _worker(rank, world, port, q):
         q.put((rank, "ERROR: " + traceback.format_exc()))
 
 
-def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -103,6 +104,8 @@ def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch():
     for k in KEYS:
         g0, g1, g = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k]), grads[k]
         assert torch.equal(g0, g1), k
+        for r in range(2, world):
+            assert torch.equal(g0, torch.from_numpy(res[r][2][k])), (k, r)
         den = float(g.norm()) + 1e-12
         assert float((g0 - g).norm()) / den < 2e-3, (k, float((g0 - g).norm()) / den)
         w0, w1 = torch.from_numpy(res[0][3][k]), torch.from_numpy(res[1][3][k])
