@@ -94,11 +94,18 @@ def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
 
 def main():
     a = parse()
+    # Libraries chat on stdout (RCCL prints a five-line version banner at the first collective, gloo its peer counts): the
+    # contract is ONE JSON line on stdout, so file descriptor 1 points at stderr until that line is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if os.environ.get("CAREL_REHEARSE_ONE_GPU") == "1":      # rehearsal of the N > 1 code path on a one-GPU box: every rank on
+        local_rank = 0                                       # cuda:0, gloo carrying the collectives (RCCL refuses that)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from carel_vae_amd import _lib as L
@@ -110,7 +117,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("CAREL_REHEARSE_ONE_GPU") == "1":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from oracle import carel_oracle as O          # synthetic batch generator only (test infrastructure helper)
     opt = M.make_opt()
@@ -285,7 +295,9 @@ def main():
         out["elbo_parity"] = parity
         out["speedup_vs_cpu_baseline"] = pairs_per_s / base["value"]
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()
 
