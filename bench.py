@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
     ap.add_argument("--no-adam-in-backward", action="store_true",
                     help="run the whole fused Adam in optim.step() instead of layer by layer beside the backward pass")
+    ap.add_argument("--no-forward-chains", action="store_true", help="forward pass as one chain (keeps the weight-gradient side stream)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="weight-gradient GEMMs on the main stream (serial kernels: the run to put under rocprofv3 --kernel-trace)")
     return ap.parse_args()
@@ -142,6 +143,7 @@ def main():
         batches.append({k: v.to(dev) for k, v in b.items()})
     model.varlen = not a.no_varlen
     model.overlap_wgrad = not a.no_overlap
+    model.forward_chains = (not a.no_forward_chains) and dp is None        # DataParallel switches the second chain off (dp.py)
 
     def step(i):
         b = batches[i % len(batches)]
@@ -276,7 +278,7 @@ def main():
                       "attended_tokens_per_pair": sum(sum(l) for l in lengths) / (len(lengths) * a.batch),
                       "padding_skipped": bool(model.varlen and a.shape == "B"),
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
-                      "wgrad_side_stream": bool(model.overlap_wgrad),
+                      "wgrad_side_stream": bool(model.overlap_wgrad), "forward_chains": bool(model.overlap_wgrad and model.forward_chains),
                       "adam_in_backward": bool(getattr(optim, "_aux", None) is not None)},
            "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

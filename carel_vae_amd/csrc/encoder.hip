@@ -283,7 +283,7 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   const long hb = B / 2;
   const int lsplit = a->n_cls > 0 ? a->n_layers - 1 : a->n_layers;
   SideStream* sd = nullptr;
-  if (a->overlap_wgrad && !a->tok_row && (B & 1) == 0 && (hb * S) % 128 == 0 && lsplit >= 1 && a->scratch) sd = side_stream();
+  if ((a->overlap_wgrad & 2) && !a->tok_row && (B & 1) == 0 && (hb * S) % 128 == 0 && lsplit >= 1 && a->scratch) sd = side_stream();
   if (!sd) return forward_layers(a, 0, a->n_layers, 0, B, stream, ws, ws_bytes);
   if (hipEventRecord(sd->ev[0], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->peer, sd->ev[0], 0) != hipSuccess)
     return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event fork failed");
@@ -324,7 +324,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   // returns, the gradients of layer+1 are complete (the main stream waited for its last group before this layer's
   // attention backward), those of `layer` after the next call or carel_encoder_backward_join.
   SideStream* sd = nullptr;
-  if (a->overlap_wgrad) {
+  if (a->overlap_wgrad & 1) {
     sd = side_stream();
     if (!sd) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: could not create the side stream / events");
   }
@@ -418,7 +418,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
 // carel_encoder_backward_layer before using layer 0's gradients; carel_encoder_backward_embeddings calls it itself.
 extern "C" int carel_encoder_backward_join(const carel_encoder_args* a, void* stream) {
   if (!a) return set_error(CAREL_ERR_ARG, "carel_encoder_backward_join: null args");
-  if (!a->overlap_wgrad) return CAREL_OK;
+  if (!(a->overlap_wgrad & 1)) return CAREL_OK;
   SideStream* sd = side_stream();
   if (!sd) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_join: no side stream");
   hipEvent_t ev = sd->ev[SideStream::NEV - 1];

@@ -329,6 +329,7 @@ class DrlClassifier(nn.Module):
         self.varlen = True                   # skip padded positions (results identical; see _pack_info)
         self.cls_only_last = True            # last layer's row-wise half on the [CLS] rows only (results identical)
         self.overlap_wgrad = True            # weight-gradient GEMMs on a second stream beside the dgrad chain (results identical)
+        self.forward_chains = True           # dense batches: the two halves of the batch as two forward chains (results identical)
         self._fwd_count = 0
         self._noise = None
         self._ws = {}
@@ -527,7 +528,7 @@ class DrlClassifier(nn.Module):
             a.n_tokens, a.tok_row, a.cu_seqlens = pack.n_tokens, pack.tok_row.data_ptr(), pack.cu.data_ptr()
         if cls is not None:
             a.n_cls, a.cls_rows, a.cls_orig_rows = cls.n_cls, cls.rows.data_ptr(), cls.orig.data_ptr()
-        a.overlap_wgrad = int(self.overlap_wgrad)
+        a.overlap_wgrad = (1 if self.overlap_wgrad else 0) | (2 if (self.overlap_wgrad and self.forward_chains) else 0)
         c = self.cfg
         a.batch, a.seq_len, a.n_layers, a.hidden, a.heads, a.intermediate = B, S, c.layers, H, NH, I_FF
         a.vocab_size, a.max_pos, a.type_vocab, a.roberta, a.pad_id, a.inference = (c.vocab_size, c.max_pos, c.type_vocab,

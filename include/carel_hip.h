@@ -232,10 +232,11 @@ typedef struct carel_encoder_args {
    * index), -1 for filler.  The final hidden states (carel_encoder_x_last) are then the n_cls compact rows, and dx is
    * read as n_cls compact rows by the backward of the last layer.  n_cls = 0 disables. */
   int32_t n_cls; const void* cls_rows; const void* cls_orig_rows;
-  /* 1: carel_encoder_backward_layer enqueues the weight-gradient GEMMs (and their slab / bias-gradient reductions) on a
+  /* bit 0 (1): carel_encoder_backward_layer enqueues the weight-gradient GEMMs (and their slab / bias-gradient reductions) on a
    * library-owned low-priority second stream, forked by events behind the kernel that produced each dY, so that they
-   * run beside the data-gradient chain and the memory-bound LayerNorm / attention backward kernels; the forward pass
-   * runs the two halves of a dense batch as two chains.  Results are identical (same kernels, same summation order).
+   * run beside the data-gradient chain and the memory-bound LayerNorm / attention backward kernels; bit 1 (2): the
+   * forward pass runs the two halves of a dense batch as two chains (second chain on a peer stream).  3 = both.
+   * Results are identical (same kernels, same summation order).
    * COMPLETION: in the order of `stream`, after carel_encoder_backward_layer(l) returns the parameter gradients of
    * layer l+1 are complete; those of layer l after the next call, carel_encoder_backward_join or
    * carel_encoder_backward_embeddings.  0: everything on `stream`, every layer complete when its call returns. */
