@@ -157,3 +157,35 @@ def test_vi_club_two_phase_steps(golden_dir):
             pk = k[2:]
             got = P[pk].numpy() if pk in O.VI_KEYS else gslice(P[pk])
             np.testing.assert_allclose(got, z[k], atol=(0.6 * lr_a if pk in O.VI_KEYS else 0.6 * lr_v), rtol=0, err_msg=pk)
+
+
+def test_en_adversarial_three_space_steps(golden_dir):
+    """Config 4 (drl_classifier_en.py): three latent spaces, five discriminators, six optimisers -- the seven losses,
+    the gradients every optimiser sees and the weights after three steps, against the reference class run by
+    tests/golden/gen_golden_en_adv.py."""
+    from oracle import carel_oracle_en as OE
+    cfg = O.EncoderConfig(layers=2, vocab_size=900, max_pos=514, type_vocab=1, ln_eps=1e-5, variant="roberta", pad_id=1)
+    opt = OE.OptEn(pair_bow_dim=211, dropout=0.0)
+    z, batch = load(golden_dir, "en_adv_small")
+    B, S, L, vocab, V, wseed, bseed, steps = (int(v) for v in z["meta"])
+    P = OE.init_params(cfg, opt, seed=wseed)
+    states = [O.AdamState() for _ in range(6)]
+    for s in range(steps):
+        eps = dict(con=torch.from_numpy(z[f"eps_con_{s}"]), e=torch.from_numpy(z[f"eps_e_{s}"]), c=torch.from_numpy(z[f"eps_c_{s}"]))
+        P, out, grads = OE.train_step(P, batch, 7 + s, cfg, opt, states, eps)
+        got = np.array([float(out[n]) for n in OE.LOSS_NAMES])
+        np.testing.assert_allclose(got, z[f"losses_{s}"], rtol=3e-5, atol=2e-6, err_msg=f"losses step {s}")
+        if s == 1:
+            for k in z.files:
+                if k.startswith("g_"):
+                    ref = z[k]
+                    np.testing.assert_allclose(gslice(grads[k[2:]]), ref, rtol=2e-3, atol=2e-6 + 2e-4 * float(np.abs(ref).max()), err_msg=k)
+                    np.testing.assert_allclose(float(grads[k[2:]].norm()), float(z["gn_" + k[2:]]), rtol=1e-3, atol=1e-7, err_msg=k)  # key bias: exactly 0 in theory
+    disc = tuple(g + "." for g in OE.DISC_GROUPS)
+    for k in z.files:
+        if k.startswith("w_"):
+            lr = opt.adv_lr if k[2:].startswith(disc) else opt.vae_lr
+            np.testing.assert_allclose(gslice(P[k[2:]]), z[k], atol=0.6 * lr, rtol=0, err_msg=k)
+    got = OE.pair_logits(P, batch["input_ids"], batch["attention_masks"], batch["token_type_ids"], cfg, opt,
+                         torch.from_numpy(z["pp_eps_e"]), torch.from_numpy(z["pp_eps_c"]))
+    np.testing.assert_allclose(got.numpy(), z["pp_logits"], rtol=1e-4, atol=1e-5)
