@@ -126,6 +126,33 @@ class ViArgs(C.Structure):
                 ("loss_out", C.c_void_p), ("d_net", C.c_void_p * 8), ("dz", C.c_void_p)]
 
 
+class EnTailArgs(C.Structure):
+    """carel_en_tail_args (include/carel_hip.h)."""
+    _fields_ = [("batch", C.c_int32), ("seq_len", C.c_int32), ("hidden", C.c_int32), ("ec_dim", C.c_int32), ("con_dim", C.c_int32),
+                ("bow_dim", C.c_int32),
+                ("x_last_f32", C.c_void_p), ("cls_rows", C.c_void_p), ("n_rows", C.c_int32),
+                ("pooler_w", C.c_void_p), ("pooler_b", C.c_void_p),
+                ("head_w", C.c_void_p * 6), ("head_b", C.c_void_p * 6),
+                ("cdisc_w", C.c_void_p), ("cdisc_b", C.c_void_p),
+                ("sdisc_w", C.c_void_p * 4), ("sdisc_b", C.c_void_p * 4),
+                ("ccls_w", C.c_void_p), ("ccls_b", C.c_void_p),
+                ("emo_w", C.c_void_p), ("emo_b", C.c_void_p), ("cau_w", C.c_void_p), ("cau_b", C.c_void_p),
+                ("pair_w", C.c_void_p), ("pair_b", C.c_void_p), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p),
+                ("emo_labels", C.c_void_p), ("cau_labels", C.c_void_p), ("pair_labels", C.c_void_p),
+                ("bow", C.c_void_p), ("eps", C.c_void_p),
+                ("w_con_adv", C.c_float), ("w_ec_adv", C.c_float), ("w_ecce_adv", C.c_float), ("w_ec_mul", C.c_float),
+                ("w_con_mul", C.c_float), ("w_pair", C.c_float), ("kl_w_ec", C.c_float), ("kl_w_con", C.c_float),
+                ("label_smoothing", C.c_float), ("epsilon", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("pooled", C.c_void_p), ("lat", C.c_void_p), ("z", C.c_void_p), ("terms", C.c_void_p), ("work", C.c_void_p),
+                ("g_cdisc_w", C.c_void_p * 3), ("g_cdisc_b", C.c_void_p * 3),
+                ("g_sdisc_w", C.c_void_p * 4), ("g_sdisc_b", C.c_void_p * 4),
+                ("g_sdisc_ent_w", C.c_void_p * 4), ("g_sdisc_ent_b", C.c_void_p * 4),
+                ("d_ccls_w", C.c_void_p), ("d_ccls_b", C.c_void_p), ("d_emo_w", C.c_void_p), ("d_emo_b", C.c_void_p),
+                ("d_cau_w", C.c_void_p), ("d_cau_b", C.c_void_p), ("d_pair_w", C.c_void_p), ("d_pair_b", C.c_void_p),
+                ("d_dec_w", C.c_void_p), ("d_dec_b", C.c_void_p), ("d_pooler_w", C.c_void_p), ("d_pooler_b", C.c_void_p),
+                ("dx_last_f32", C.c_void_p)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
 
@@ -178,6 +205,14 @@ SIGNATURES = {
     "carel_encoder_forward": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),
     "carel_encoder_backward_layer": (C.c_int, [C.POINTER(EncoderArgs), C.c_int32, C.c_void_p]),
     "carel_encoder_backward_embeddings": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),
+    "carel_en_tail_workspace_floats": (C.c_int64, [C.c_int32] * 4),
+    "carel_en_tail_latents": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p]),
+    "carel_en_tail_losses": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p]),
+    "carel_en_tail_backward": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p, C.c_void_p]),
+    "carel_en_pair_logits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "carel_axpy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "carel_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "carel_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "carel_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
 }

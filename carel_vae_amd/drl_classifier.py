@@ -306,21 +306,9 @@ class DrlClassifier(nn.Module):
         if opt.bert_dim != H:
             raise L.CarelError("bert_dim must be 768 (BERT-base kernels)")
         self.encoder = CarelEncoder(self.cfg)
-        self.emotion_mu = _Holder((opt.ec_dim, H))
-        self.emotion_log_var = _Holder((opt.ec_dim, H))
-        self.cause_mu = _Holder((opt.ec_dim, H))
-        self.cause_log_var = _Holder((opt.ec_dim, H))
-        self.emotion_classifier = _Holder((opt.e_num_class, opt.ec_dim))
-        self.cause_classifier = _Holder((opt.c_num_class, opt.ec_dim))
-        self.pair_classifier = _Holder((opt.pair_num_class, opt.ec_dim * 2))
-        self.decoder = _Holder((opt.pair_bow_dim, opt.ec_dim * 2))
-        self.dropout = nn.Dropout(opt.dropout)       # probability holder; the mask is drawn in-kernel
         self._aprx_names = []
-        if getattr(opt, "disentangle", "mmd") == "vi":      # approximation network p(e|c), drl_classifier_ec_vi.py:156-163
-            D = opt.ec_dim
-            self.ec_mu = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D))
-            self.ec_log_var = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D), nn.Tanh())
-            self._aprx_names = [f"{n}.{i}.{t}" for n in ("ec_mu", "ec_log_var") for i in (0, 2) for t in ("weight", "bias")]
+        self._has_pair_skip = True          # the pair head is frozen for a step whose pair loss was replaced by 0 (ref :510-511)
+        self._build_heads(opt)
         gen = None
         if seed is not None:
             gen = torch.Generator().manual_seed(seed)
@@ -338,10 +326,40 @@ class DrlClassifier(nn.Module):
         self._flat = None
         self._flatten()
 
+    def _build_heads(self, opt):
+        self.emotion_mu = _Holder((opt.ec_dim, H))
+        self.emotion_log_var = _Holder((opt.ec_dim, H))
+        self.cause_mu = _Holder((opt.ec_dim, H))
+        self.cause_log_var = _Holder((opt.ec_dim, H))
+        self.emotion_classifier = _Holder((opt.e_num_class, opt.ec_dim))
+        self.cause_classifier = _Holder((opt.c_num_class, opt.ec_dim))
+        self.pair_classifier = _Holder((opt.pair_num_class, opt.ec_dim * 2))
+        self.decoder = _Holder((opt.pair_bow_dim, opt.ec_dim * 2))
+        self.dropout = nn.Dropout(opt.dropout)       # probability holder; the mask is drawn in-kernel
+        if getattr(opt, "disentangle", "mmd") == "vi":      # approximation network p(e|c), drl_classifier_ec_vi.py:156-163
+            D = opt.ec_dim
+            self.ec_mu = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D))
+            self.ec_log_var = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, D), nn.Tanh())
+            self._aprx_names = [f"{n}.{i}.{t}" for n in ("ec_mu", "ec_log_var") for i in (0, 2) for t in ("weight", "bias")]
+
     # ------------------------------------------------------------------ flat parameter storage
     def _param_order(self):
         """Flat layout: optimised tensors first (so fused Adam is one contiguous range), the four latent
         heads (never optimised, ref :292-295) last; q/k/v weights and biases adjacent (fused QKV GEMM)."""
+        order, _, named = self._param_order_encoder()
+        order += ["encoder.pooler.dense.weight", "encoder.pooler.dense.bias", "decoder.weight", "decoder.bias",
+                  "emotion_classifier.weight", "emotion_classifier.bias", "cause_classifier.weight", "cause_classifier.bias"]
+        self._pair_range_names = ["pair_classifier.weight", "pair_classifier.bias"]
+        order += self._pair_range_names
+        n_opt_names = len(order)
+        order += ["emotion_mu.weight", "emotion_mu.bias", "emotion_log_var.weight", "emotion_log_var.bias",
+                  "cause_mu.weight", "cause_mu.bias", "cause_log_var.weight", "cause_log_var.bias"]
+        order += self._aprx_names            # own optimiser (ref ec_vi :873), fp32 only
+        assert set(order) == set(named), "parameter inventory mismatch"
+        return order, n_opt_names, named
+
+    def _param_order_encoder(self):
+        """Embeddings and encoder layers (q/k/v weights and biases adjacent: fused QKV GEMM); (order, None, named)."""
         named = dict(self.named_parameters())
         order = []
         e = "encoder.embeddings."
@@ -355,16 +373,7 @@ class DrlClassifier(nn.Module):
                       p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
                       p + "intermediate.dense.weight", p + "intermediate.dense.bias",
                       p + "output.dense.weight", p + "output.dense.bias", p + "output.LayerNorm.weight", p + "output.LayerNorm.bias"]
-        order += ["encoder.pooler.dense.weight", "encoder.pooler.dense.bias", "decoder.weight", "decoder.bias",
-                  "emotion_classifier.weight", "emotion_classifier.bias", "cause_classifier.weight", "cause_classifier.bias"]
-        self._pair_range_names = ["pair_classifier.weight", "pair_classifier.bias"]
-        order += self._pair_range_names
-        n_opt_names = len(order)
-        order += ["emotion_mu.weight", "emotion_mu.bias", "emotion_log_var.weight", "emotion_log_var.bias",
-                  "cause_mu.weight", "cause_mu.bias", "cause_log_var.weight", "cause_log_var.bias"]
-        order += self._aprx_names            # own optimiser (ref ec_vi :873), fp32 only
-        assert set(order) == set(named), "parameter inventory mismatch"
-        return order, n_opt_names, named
+        return order, None, named
 
     def _flatten(self):
         order, n_opt_names, named = self._param_order()
@@ -706,6 +715,18 @@ class DrlClassifier(nn.Module):
         ops.scale_(self._flat_grad[lo:self._pair_hi], go)
         if self._dp is not None:
             self._dp.tail_done()
+        self._backward_encoder(ea, accumulate)
+        if self._dp is not None:
+            self._dp.backward_done()
+        if accumulate:
+            self._flat_grad.add_(prev)
+        self._bind_grads()
+
+    def _backward_encoder(self, ea, accumulate):
+        """Encoder layers 11..0 and the embeddings, given ea.dx = d loss / d (last hidden states)."""
+        lib = L.load()
+        st = L.current_stream()
+
         def layer_ready(l):             # layer l's parameter gradients are complete in the order of the main stream
             work = self._dp.layer_done(l) if self._dp is not None else None
             if self._adam_hook is not None and not accumulate and (self._dp is None or work is not None):
@@ -720,11 +741,6 @@ class DrlClassifier(nn.Module):
             L.check(lib.carel_encoder_backward_join(C.byref(ea), st), "carel_encoder_backward_join")
             layer_ready(0)
         L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
-        if self._dp is not None:
-            self._dp.backward_done()
-        if accumulate:
-            self._flat_grad.add_(prev)
-        self._bind_grads()
 
     def _bind_grads(self):
         if self._grad_views is None:
@@ -842,15 +858,20 @@ class FusedAdam:
     zero_grad() -> backward() -> step() (no gradient accumulation, no use of the gradients to decide whether to step).
     Under DataParallel (RCCL) each layer's update additionally waits for that layer's gradient all-reduce."""
 
-    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fuse_into_backward=False):
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fuse_into_backward=False, param_range=None, params=None):
+        """param_range / params (both or neither): a contiguous [lo, hi) slice of the flat buffer and the Parameters in
+        it, for models whose get_params() returns several optimiser groups (drl_classifier_en.py:357-376)."""
         model._require_cuda()
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.step_count = 0
-        n = model._n_opt
-        self.exp_avg = torch.zeros(n, device=model._flat.device, dtype=torch.float32)
+        self._lo, self._hi = (0, model._n_opt) if param_range is None else param_range
+        if params is None:
+            params = model.get_params() if not model._aprx_names else model.get_params()[1]
+        self._params = list(params)
+        self.exp_avg = torch.zeros(self._hi - self._lo, device=model._flat.device, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.grad_scale = 1.0
-        self.param_groups = [dict(params=model.get_params() if not model._aprx_names else model.get_params()[1], lr=lr, betas=betas, eps=eps)]
+        self.param_groups = [dict(params=self._params, lr=lr, betas=betas, eps=eps)]
         self._done = []                  # [lo, hi) ranges already updated for the coming step()
         self._aux = None
         if fuse_into_backward:
@@ -866,21 +887,22 @@ class FusedAdam:
             model._adam_hook = self
 
     def zero_grad(self, set_to_none=True):
-        for p in self.model._named.values():
+        for p in (self.model._named.values() if self._lo == 0 and self._hi == self.model._n_opt and not hasattr(self.model, "_group_ranges")
+                  else self._params):
             p.grad = None
 
     def _launch(self, lo, hi, stream, with_skip):
         m = self.model
         a = L.AdamArgs()
         a.param, a.grad = m._flat.data_ptr() + 4 * lo, m._flat_grad.data_ptr() + 4 * lo
-        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr() + 4 * (lo - self._lo), self.exp_avg_sq.data_ptr() + 4 * (lo - self._lo)
         a.shadow_bf16 = m._shadow.data_ptr() + 2 * lo
         a.n, a.step = hi - lo, self.step_count + 1
         a.lr, a.beta1, a.beta2, a.eps = self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps
         a.grad_scale = self.grad_scale
         a.skip_lo, a.skip_hi, a.skip_flag = 0, 0, None
         call = getattr(m, "_last_call", None)
-        if with_skip and call is not None and lo <= m._pair_lo and m._pair_hi <= hi:
+        if with_skip and m._has_pair_skip and call is not None and lo <= m._pair_lo and m._pair_hi <= hi:
             # the pair head keeps its weights/moments when its loss term was replaced by 0
             a.skip_lo, a.skip_hi = m._pair_lo - lo, m._pair_hi - lo
             off = L.load().carel_tail_pair_dead_offset(call.B, m.opt.ec_dim, m.opt.pair_bow_dim)
@@ -906,13 +928,13 @@ class FusedAdam:
 
     def step(self):
         m = self.model
-        lo = 0
+        lo = self._lo
         for dlo, dhi in sorted(self._done):             # whatever backward() has not updated yet
             if dlo > lo:
                 self._launch(lo, dlo, L.current_stream(), with_skip=True)
             lo = max(lo, dhi)
-        if lo < m._n_opt:
-            self._launch(lo, m._n_opt, L.current_stream(), with_skip=True)
+        if lo < self._hi:
+            self._launch(lo, self._hi, L.current_stream(), with_skip=True)
         self._join()
         self._done = []
         self.step_count += 1

@@ -423,6 +423,84 @@ int carel_vi_aprx(const carel_vi_args* args, void* stream);
 int carel_vi_upper(const carel_vi_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Tail of the three-space adversarial model of drl_classifier_en.py (config 4): replaces everything after
+ * `pooler_output` in DrlClassifier.forward (drl_classifier_en.py:220-334) and the gradient side of the six
+ * backward calls of its training step (:919-939).  fp32 throughout.
+ *
+ * Latent layout  lat [B, 2*con_dim + 4*ec_dim] = content_mu | content_log_var | emotion_mu | emotion_log_var |
+ *                                                cause_mu | cause_log_var               (:227-232, :378-415)
+ * Sample layout  z   [B, 2*ec_dim + con_dim]   = emotion | cause | content  == generative_emb (:243);
+ *                eps  [2*ec_dim + con_dim] in the same layout (the reference draws content, emotion, cause in that
+ *                order, :238-240 -- the caller fills eps accordingly).
+ * terms [32]: 0..6 = content_disc_loss_emo, content_disc_loss_cau, emotion_disc_loss, ec_disc_loss,
+ *             cause_disc_loss, ce_disc_loss, vae_and_classifier_loss (the tuple forward returns, :334);
+ *             7,8 content entropies (emo, cau); 9 emotion_disc entropy; 10 cause_disc entropy; 11 ec_disc entropy;
+ *             12 ce_disc entropy; 13 emo_mul; 14 cau_mul; 15 content_mul; 16 pair_mul; 17 kl_e; 18 kl_c;
+ *             19 kl_content (the three already multiplied by their annealed weights); 20 reconstruction.
+ *
+ * Every discriminator reads a DETACHED embedding (:425-515), so its loss and its entropy term reach only its own
+ * parameters.  carel_en_tail_losses writes, for unit upstream gradients:
+ *   g_cdisc_*[0], [1] : d content_disc_loss_emo / d content_disc, d content_disc_loss_cau / d content_disc
+ *   g_cdisc_*[2]      : d vae_loss / d content_disc   (= con_adv_weight * both entropies)
+ *   g_sdisc_*[i]      : d (own discriminator loss) / d {emotion_disc, cause_disc, ec_disc, ce_disc}[i]
+ *   g_sdisc_ent_*[i]  : d vae_loss / d the same (weighted entropy)
+ *   d_*               : d vae_loss / d {content_classifier, emotion/cause/pair classifier, decoder}
+ * and keeps d vae_loss / d lat in `work`; carel_en_tail_backward turns that into d_pooler_* and dx_last, all
+ * scaled by *grad_out_dev.  The six latent heads are not in any optimiser group (:357-376): no gradient is
+ * produced for them.  Dropout masks: counter-based, sites 110..119 in the order of the ten nn.Dropout calls.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_en_tail_args {
+  int32_t batch, seq_len, hidden, ec_dim, con_dim, bow_dim;
+  const void* x_last_f32;            /* f32 [rows, 768] last encoder LayerNorm output */
+  const void* cls_rows;              /* int32 [B] or NULL (= b*seq_len) */
+  int32_t n_rows;                    /* rows of dx_last to clear (0 = B*seq_len) */
+  const void* pooler_w; const void* pooler_b;
+  const void* head_w[6]; const void* head_b[6];     /* content_mu, content_log_var, emotion_mu, emotion_log_var, cause_mu, cause_log_var */
+  const void* cdisc_w; const void* cdisc_b;         /* content_disc [V, ec_dim] */
+  const void* sdisc_w[4]; const void* sdisc_b[4];   /* emotion_disc [1,con_dim], cause_disc [1,con_dim], ec_disc [1,ec_dim], ce_disc [1,ec_dim] */
+  const void* ccls_w; const void* ccls_b;           /* content_classifier [V, con_dim] */
+  const void* emo_w; const void* emo_b; const void* cau_w; const void* cau_b;   /* [1, ec_dim] */
+  const void* pair_w; const void* pair_b;           /* [1, 2*ec_dim] */
+  const void* dec_w; const void* dec_b;             /* [V, 2*ec_dim + con_dim] */
+  const void* emo_labels; const void* cau_labels; const void* pair_labels;     /* f32 [B] */
+  const void* bow;                                  /* f32 [B, V] */
+  const void* eps;                                  /* f32 [2*ec_dim + con_dim] */
+  float w_con_adv, w_ec_adv, w_ecce_adv, w_ec_mul, w_con_mul, w_pair;           /* :325-330 */
+  float kl_w_ec, kl_w_con;                          /* annealed KL weights (1 once iteration >= kl_ann_iterations) */
+  float label_smoothing, epsilon;
+  float drop_p; uint32_t drop_seed;
+  /* outputs */
+  void* pooled;                      /* f32 [B, 768] */
+  void* lat;                         /* f32 [B, 2*con_dim + 4*ec_dim] */
+  void* z;                           /* f32 [B, 2*ec_dim + con_dim] */
+  void* terms;                       /* f32 [32] */
+  void* work;                        /* f32 [carel_en_tail_workspace_floats(...)] */
+  void* g_cdisc_w[3]; void* g_cdisc_b[3];
+  void* g_sdisc_w[4]; void* g_sdisc_b[4];
+  void* g_sdisc_ent_w[4]; void* g_sdisc_ent_b[4];
+  void* d_ccls_w; void* d_ccls_b; void* d_emo_w; void* d_emo_b; void* d_cau_w; void* d_cau_b;
+  void* d_pair_w; void* d_pair_b; void* d_dec_w; void* d_dec_b;
+  void* d_pooler_w; void* d_pooler_b;
+  void* dx_last_f32;                 /* f32 [n_rows, 768] */
+} carel_en_tail_args;
+int64_t carel_en_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t con_dim, int32_t bow_dim);
+int carel_en_tail_latents(const carel_en_tail_args* args, void* stream);     /* pooled, lat (also the front of get_pair_preds, :336-349) */
+int carel_en_tail_losses(const carel_en_tail_args* args, void* stream);      /* z, terms and every gradient listed above */
+int carel_en_tail_backward(const carel_en_tail_args* args, const void* grad_out_dev_f32, void* stream);
+/* get_pair_preds (:336-353): raw pair logits from lat with fresh emotion / cause noise (f32 [ec_dim] each) */
+int carel_en_pair_logits(const void* lat, int32_t lat_stride, int32_t emo_off, int32_t cau_off, const void* eps_e, const void* eps_c,
+                         const void* pair_w, const void* pair_b, int32_t batch, int32_t ec_dim, void* logits, void* stream);
+/* dst = (accumulate ? dst : 0) + *scale_dev * src   (scale_dev NULL = 1): how a discriminator's .grad takes one
+ * backward call's share without a host sync */
+int carel_axpy_f32(void* dst_f32, const void* src_f32, int64_t n, const void* scale_dev_f32, int32_t accumulate, void* stream);
+/* fp32 GEMM used by the vocabulary-wide heads (exposed for the parity tests): C[M,N] (+)= op(A) op(B)
+ * ta = 0: A is [M,K] row-major (lda); 1: A is [K,M].  tb = 0: B is [N,K] row-major (ldb); 1: B is [K,N].
+ * bias [N] or NULL.  splits > 1: C receives `splits` partial results c_split_stride floats apart (no bias). */
+int carel_sgemm_f32(const void* A, int64_t lda, int32_t ta, const void* B, int64_t ldb, int32_t tb, void* C, int64_t ldc,
+                    int32_t M, int32_t N, int32_t K, const void* bias, int32_t accumulate, int32_t splits, int64_t c_split_stride,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Hardware-layout self test (MFMA fragment maps, transposed LDS reads, LDS-DMA staging) used by
  * tests/test_gpu_layouts.py: raw dumps of what the helpers produce on exact integer data (layout of
  * the two buffers is documented in csrc/selftest.hip); the test compares them with numpy.
