@@ -93,6 +93,58 @@ def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
             "sample": "oracle train_step (fwd+bwd+Adam, set_detect_anomaly as ref :837), B=8 S=128 12 layers fp32, %d timed steps" % len(timed)}, parity
 
 
+def english_leg(dev, batch_size, steps):
+    """Config 4 (BASELINE.json configs[3]): one training step of the three-space adversarial model of drl_classifier_en.py --
+    RoBERTa-base encoder (vocab 50 265), content / emotion / cause latents, five discriminators, the six backward calls and
+    six Adam steps of its loop (:919-947).  V = 22 463 (data/ecpe_and_reccon_all_data_pair_en.txt)."""
+    from carel_vae_amd import drl_classifier_en as ME
+    from oracle import carel_oracle as O
+    from oracle import carel_oracle_en as OE          # synthetic batch generator only
+    V = 22463
+    opt = ME.make_opt(pair_bow_dim=V)
+    model = ME.DrlClassifier(opt, seed=0).to(dev)
+    model.train()
+    opts = model.make_fused_optimizers(fuse_into_backward=True)
+    ocfg = O.EncoderConfig.roberta_base()
+    out = {}
+    for shape in ("A", "B"):
+        bb, ll = [], []
+        for i in range(4):
+            b = OE.synthetic_batch(batch_size, 128, ocfg, V, seed=301 + i, shape=shape)
+            ll.append(b["attention_masks"].sum(1).tolist())
+            bb.append({k: v.to(dev) for k, v in b.items()})
+
+        def step(i):
+            b = bb[i % 4]
+            cd_e, cd_c, ed, ecd, cad, ced, vae = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"],
+                                                       b["cau_labels"], b["labels"], b["bow_reps"], i % 41, seq_lengths=ll[i % 4])
+            opts[0].zero_grad(); (cd_e + cd_c).backward(retain_graph=True)        # noqa: E702   the reference's sequence (:919-939)
+            opts[1].zero_grad(); ed.backward(retain_graph=True)                  # noqa: E702
+            opts[3].zero_grad(); ecd.backward(retain_graph=True)                 # noqa: E702
+            opts[2].zero_grad(); cad.backward(retain_graph=True)                 # noqa: E702
+            opts[4].zero_grad(); ced.backward(retain_graph=True)                 # noqa: E702
+            opts[5].zero_grad(); vae.backward()                                  # noqa: E702
+            for o in opts:
+                o.step()
+            return vae
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            vae = step(3 + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["dense" if shape == "A" else "ecpe_shaped"] = {"value": batch_size * steps / dt, "unit": "clause-pairs/s", "ms_per_step": 1e3 * dt / steps,
+                                                           "steps": steps, "final_vae_loss": float(vae.detach())}
+        log("english adversarial leg, shape %s: %.3f ms/step" % (shape, 1e3 * dt / steps))
+    out["note"] = ("drl_classifier_en.py step: RoBERTa-base (vocab 50265), con_dim 384, bow V=22463, B=%d, dropout on, fused HIP Adam x6; "
+                   "one GPU" % batch_size)
+    del model, opts
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     # Libraries chat on stdout (RCCL prints a five-line version banner at the first collective, gloo its peer counts): the
@@ -248,6 +300,11 @@ def main():
                          "chunks of 256, padding skipped; one GPU"}
         log("inference leg: %.1f ms per 2048 pairs" % (1e3 * dti))
 
+    # ---- config 4: the English three-space adversarial model (drl_classifier_en.py), one GPU ----
+    english = None
+    if not a.no_ecpe and rank == 0 and world == 1:
+        english = english_leg(dev, a.batch, max(5, a.steps // 2))
+
     # ---- roofline of the dominant kernel family ----
     roof = None
     ms_t, fl_t, n_t = ev_timed
@@ -280,7 +337,7 @@ def main():
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
                       "wgrad_side_stream": bool(model.overlap_wgrad), "forward_chains": bool(model.overlap_wgrad and model.forward_chains),
                       "adam_in_backward": bool(getattr(optim, "_aux", None) is not None)},
-           "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "final_loss": final_loss}
+           "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "english_adversarial": english, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):
             m2 = M.DrlClassifier(M.make_opt(**vars(oopt)), M.encoder_config("zh", hidden_dropout=0.0, attn_dropout=0.0), seed=0)

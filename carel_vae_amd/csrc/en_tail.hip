@@ -15,67 +15,72 @@
 namespace carel {
 
 // ------------------------------------------------------------------------------------------
-// fp32 GEMM, 64 x 64 tile, 16-deep steps, 256 threads, 4 x 4 outputs per thread.
+// fp32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain per output).
+// 64 x 64 tile per workgroup, four waves of one 32 x 32 accumulator each, 32-deep steps staged through LDS
+// (k-major images, so lane l reads A[k = 2s + (l >> 5)][m = l & 31] as one conflict-free b32), the next step's
+// global loads in flight while the current step's 16 MFMAs run.  All edges are guarded (any M, N, K).
 //   TA = false: A is [M, K] row-major;  true: A is [K, M].   TB = false: B is [N, K];  true: B is [K, N].
 // blockIdx.z splits the reduction into chunks of `kchunk`; split z writes to C + z * c_split_stride.
 // ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SG_BK = 32, SG_LD = 65;
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ A, long lda, const float* __restrict__ Bm, long ldb,
                                                       float* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
                                                       int accumulate, int kchunk, long c_split_stride) {
-  __shared__ __attribute__((aligned(16))) float As[16][68];
-  __shared__ __attribute__((aligned(16))) float Bs[16][68];
-  const int t = threadIdx.x, tm = t >> 4, tn = t & 15;
+  __shared__ float As[SG_BK][SG_LD];
+  __shared__ float Bs[SG_BK][SG_LD];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
-  float acc[4][4];
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float ra[8], rb[8];
+  auto gload = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int k0 = kb; k0 < ke; k0 += 16) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int e = t + i * 256;
       int m, k;
-      if (TA) { k = e >> 6; m = e & 63; } else { m = e >> 4; k = e & 15; }
+      if (TA) { k = e >> 6; m = e & 63; } else { m = e >> 5; k = e & 31; }
       const int gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < M && gk < ke) v = TA ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk];
-      As[k][m] = v;
+      ra[i] = (gm < M && gk < ke) ? (TA ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk]) : 0.f;
       int n, k2;
-      if (TB) { k2 = e >> 6; n = e & 63; } else { n = e >> 4; k2 = e & 15; }
+      if (TB) { k2 = e >> 6; n = e & 63; } else { n = e >> 5; k2 = e & 31; }
       const int gn = n0 + n, gk2 = k0 + k2;
-      float u = 0.f;
-      if (gn < N && gk2 < ke) u = TB ? Bm[(long)gk2 * ldb + gn] : Bm[(long)gn * ldb + gk2];
-      Bs[k2][n] = u;
+      rb[i] = (gn < N && gk2 < ke) ? (TB ? Bm[(long)gk2 * ldb + gn] : Bm[(long)gn * ldb + gk2]) : 0.f;
+    }
+  };
+  gload(kb);
+  for (int k0 = kb; k0 < ke; k0 += SG_BK) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + i * 256;
+      if (TA) As[e >> 6][e & 63] = ra[i]; else As[e & 31][e >> 5] = ra[i];
+      if (TB) Bs[e >> 6][e & 63] = rb[i]; else Bs[e & 31][e >> 5] = rb[i];
     }
     __syncthreads();
+    if (k0 + SG_BK < ke) gload(k0 + SG_BK);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const float4 a = *(const float4*)&As[kk][tm * 4];
-      const float4 b = *(const float4*)&Bs[kk][tn * 4];
-      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    for (int s = 0; s < SG_BK / 2; ++s) {
+      const float a = As[2 * s + (l >> 5)][wm * 32 + (l & 31)];
+      const float b = Bs[2 * s + (l >> 5)][wn * 32 + (l & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
   }
   float* Cz = C + (long)blockIdx.z * c_split_stride;
+  const int gn = n0 + wn * 32 + (l & 31);
+  if (gn >= N) return;
+  const float bv = bias ? bias[gn] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gm = m0 + tm * 4 + i;
+  for (int r = 0; r < 16; ++r) {
+    const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
     if (gm >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gn = n0 + tn * 4 + j;
-      if (gn >= N) continue;
-      float v = acc[i][j] + (bias ? bias[gn] : 0.f);
-      if (accumulate) v += Cz[(long)gm * ldc + gn];
-      Cz[(long)gm * ldc + gn] = v;
-    }
+    float v = acc[r] + bv;
+    if (accumulate) v += Cz[(long)gm * ldc + gn];
+    Cz[(long)gm * ldc + gn] = v;
   }
 }
 
@@ -87,36 +92,81 @@ __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ 
 struct BowRowArgs {
   float* L; float* L2; const float* bow; int B, V; float ls, eps, s_bce, s_ent; float* rowstat;
 };
-template <int ENT>
-__global__ __launch_bounds__(1024) void bow_row_kernel(BowRowArgs a) {
+// Three passes over a row, each spread over BR_CHUNK-wide chunks (grid = chunks x B) so that all CUs take part (the work
+// is transcendental-bound: exp / log / log1p per element):
+//   PASS 1: chunk maximum and sum of exp                                      -> part[b][c][0..1]
+//   PASS 2: log-sum-exp from part; chunk sums of BCE, p*dBCE/dp (+ entropy, p*dEnt/dp) -> part2[b][c][0..3]
+//   PASS 3: row sums from part2; writes the gradients; chunk 0 writes rowstat
+// hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp) for the per-element work of the row passes; log(1 - p)
+// by its series for small p (most entries have p ~ 1/V), where 1 - p would round away the information
+__device__ __forceinline__ float br_log1m(float p) {
+  if (p < 0.0625f) return -p * (1.f + p * (0.5f + p * (0.33333334f + p * (0.25f + p * (0.2f + p * (0.16666667f + p * 0.14285715f))))));
+  return __logf(1.f - p);
+}
+constexpr int BR_CHUNK = 2048, BR_THREADS = 256, BR_NPT = BR_CHUNK / BR_THREADS;
+template <int ENT, int PASS>
+__global__ __launch_bounds__(BR_THREADS) void bow_row_kernel(BowRowArgs a, float* __restrict__ part, float* __restrict__ part2, int chunks) {
   __shared__ float red[16];
-  const int b = blockIdx.x, t = threadIdx.x, V = a.V;
+  const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x, V = a.V;
   float* L = a.L + (long)b * V;
   const float* bw = a.bow + (long)b * V;
-  float m = -INFINITY;
-  for (int j = t; j < V; j += 1024) m = fmaxf(m, L[j]);
-  m = block_max(m, red);
+  const int j0 = c * BR_CHUNK;
+  float x[BR_NPT];
+#pragma unroll
+  for (int i = 0; i < BR_NPT; ++i) { const int j = j0 + t + i * BR_THREADS; x[i] = j < V ? L[j] : -INFINITY; }
+  if (PASS == 1) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < BR_NPT; ++i) m = fmaxf(m, x[i]);
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < BR_NPT; ++i) s += expf(x[i] - m);
+    s = block_sum(s, red);
+    if (t == 0) { part[((long)b * chunks + c) * 2] = m; part[((long)b * chunks + c) * 2 + 1] = s; }
+    return;
+  }
+  float m = -INFINITY;            // every thread combines the (few) chunk partials itself, in fixed order
+  for (int q = 0; q < chunks; ++q) m = fmaxf(m, part[((long)b * chunks + q) * 2]);
   float s = 0.f;
-  for (int j = t; j < V; j += 1024) s += expf(L[j] - m);
-  s = block_sum(s, red);
+  for (int q = 0; q < chunks; ++q) s += part[((long)b * chunks + q) * 2 + 1] * expf(part[((long)b * chunks + q) * 2] - m);
   const float lse = m + logf(s);
   const float t0 = a.ls / (float)V, t1 = 1.f - a.ls;
+  float tg[BR_NPT];
+#pragma unroll
+  for (int i = 0; i < BR_NPT; ++i) { const int j = j0 + t + i * BR_THREADS; tg[i] = j < V ? bw[j] * t1 + t0 : 0.f; }
+  if (PASS == 2) {
+    float le = 0.f, db = 0.f, en = 0.f, de = 0.f;
+#pragma unroll
+    for (int i = 0; i < BR_NPT; ++i) {
+      if (j0 + t + i * BR_THREADS < V) {
+        const float lp = x[i] - lse, p = __expf(lp);
+        le += -(tg[i] * fmaxf(lp, -100.f) + (1.f - tg[i]) * fmaxf(br_log1m(p), -100.f));
+        db += p * ((p - tg[i]) * __frcp_rn(fmaxf((1.f - p) * p, 1e-12f)));
+        if (ENT) { const float lg = __logf(p + a.eps); en += p * lg; de += p * (lg + p * __frcp_rn(p + a.eps)); }
+      }
+    }
+    le = block_sum(le, red); db = block_sum(db, red);
+    if (ENT) { en = block_sum(en, red); de = block_sum(de, red); }
+    if (t == 0) { float* o = part2 + ((long)b * chunks + c) * 4; o[0] = le; o[1] = db; o[2] = en; o[3] = de; }
+    return;
+  }
   float le = 0.f, db = 0.f, en = 0.f, de = 0.f;
-  for (int j = t; j < V; j += 1024) {
-    const float lp = L[j] - lse, p = expf(lp), tg = bw[j] * t1 + t0;
-    le += -(tg * fmaxf(lp, -100.f) + (1.f - tg) * fmaxf(log1pf(-p), -100.f));
-    db += p * ((p - tg) / fmaxf((1.f - p) * p, 1e-12f));
-    if (ENT) { const float lg = logf(p + a.eps); en += p * lg; de += p * (lg + p / (p + a.eps)); }
+  for (int q = 0; q < chunks; ++q) {
+    const float* o = part2 + ((long)b * chunks + q) * 4;
+    le += o[0]; db += o[1]; en += o[2]; de += o[3];
   }
-  le = block_sum(le, red); db = block_sum(db, red);
-  if (ENT) { en = block_sum(en, red); de = block_sum(de, red); }
-  for (int j = t; j < V; j += 1024) {
-    const float lp = L[j] - lse, p = expf(lp), tg = bw[j] * t1 + t0;
-    const float gp = (p - tg) / fmaxf((1.f - p) * p, 1e-12f);
-    if (ENT) { const float lg = logf(p + a.eps); a.L2[(long)b * V + j] = p * ((lg + p / (p + a.eps)) - de) * a.s_ent; }
-    L[j] = p * (gp - db) * a.s_bce;
+#pragma unroll
+  for (int i = 0; i < BR_NPT; ++i) {
+    const int j = j0 + t + i * BR_THREADS;
+    if (j < V) {
+      const float p = __expf(x[i] - lse);
+      const float gp = (p - tg[i]) * __frcp_rn(fmaxf((1.f - p) * p, 1e-12f));
+      if (ENT) { const float lg = __logf(p + a.eps); a.L2[(long)b * V + j] = p * ((lg + p * __frcp_rn(p + a.eps)) - de) * a.s_ent; }
+      L[j] = p * (gp - db) * a.s_bce;
+    }
   }
-  if (t == 0) { a.rowstat[b * 2] = le; a.rowstat[b * 2 + 1] = en; }
+  if (c == 0 && t == 0) { a.rowstat[b * 2] = le; a.rowstat[b * 2 + 1] = en; }
 }
 
 // out[j] (+)= sum_b X[b][j]
@@ -124,7 +174,15 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= V) return;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += X[(long)b * V + j];
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {        // eight independent loads in flight; summation order stays b = 0, 1, 2, ...
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = X[(long)(b + u) * V + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < B; ++b) s += X[(long)b * V + j];
   out[j] = accumulate ? out[j] + s : s;
 }
 
@@ -140,20 +198,41 @@ __device__ __forceinline__ void en_lat_index(int k, int D, int Cd, int& mu, int&
   else { mu = k - 2 * D; lv = Cd + (k - 2 * D); }
 }
 
-__global__ __launch_bounds__(256) void en_sample_kernel(const float* __restrict__ lat, const float* __restrict__ eps, int B, int D, int Cd,
-                                                        float* __restrict__ z, float* __restrict__ xd, EnSegs sg) {
+// One workgroup per sample: z, the dropped-out copies, the sample's three KL sums (klrow[b][3], unweighted) and the seven
+// one-logit heads' pre-activations lg[h][b] (head h reads segment hseg[h]).
+struct EnHeadIn { int hseg[7]; const float* w[7]; const float* b[7]; };
+__global__ __launch_bounds__(512) void en_sample_kernel(const float* __restrict__ lat, const float* __restrict__ eps, int B, int D, int Cd,
+                                                        float* __restrict__ z, float* __restrict__ xd, EnSegs sg, EnHeadIn hi,
+                                                        float* __restrict__ lg, float* __restrict__ klrow) {
+  extern __shared__ float zrow[];           // [2D + Cd] + 16
   const int ZW = 2 * D + Cd, LW = 2 * Cd + 4 * D;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= B * ZW) return;
-  const int b = e / ZW, k = e - b * ZW;
-  int mu, lv;
-  en_lat_index(k, D, Cd, mu, lv);
-  const float zv = lat[(long)b * LW + mu] + eps[k] * expf(lat[(long)b * LW + lv]);
-  z[e] = zv;
+  float* red = zrow + ZW;
+  const int b = blockIdx.x, t = threadIdx.x, nthr = blockDim.x;
+  float kl[3] = {0.f, 0.f, 0.f};
+  for (int k = t; k < ZW; k += nthr) {
+    int mu, lv;
+    en_lat_index(k, D, Cd, mu, lv);
+    const float m = lat[(long)b * LW + mu], l = lat[(long)b * LW + lv], ex = expf(l);
+    const float zv = m + eps[k] * ex;
+    z[(long)b * ZW + k] = zv;
+    zrow[k] = zv;
+    const float v = -0.5f * (1.f + l - ex - m * m);          // :615-624
+    if (k < D) kl[0] += v; else if (k < 2 * D) kl[1] += v; else kl[2] += v;
 #pragma unroll
-  for (int s = 0; s < EN_NSEG; ++s) {
-    const int kk = k - sg.src[s];
-    if (kk >= 0 && kk < sg.K[s]) xd[sg.dst[s] + (long)b * sg.K[s] + kk] = zv * dropout_mult(sg.d[s], (uint32_t)(b * sg.K[s] + kk));
+    for (int s = 0; s < EN_NSEG; ++s) {
+      const int kk = k - sg.src[s];
+      if (kk >= 0 && kk < sg.K[s]) xd[sg.dst[s] + (long)b * sg.K[s] + kk] = zv * dropout_mult(sg.d[s], (uint32_t)(b * sg.K[s] + kk));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { kl[i] = block_sum(kl[i], red); if (t == 0) klrow[b * 3 + i] = kl[i]; }      // also publishes zrow
+#pragma unroll
+  for (int h = 0; h < 7; ++h) {
+    const int sgi = hi.hseg[h], K = sg.K[sgi], src = sg.src[sgi];
+    float acc = 0.f;
+    for (int kk = t; kk < K; kk += nthr) acc = fmaf(zrow[src + kk] * dropout_mult(sg.d[sgi], (uint32_t)(b * K + kk)), hi.w[h][kk], acc);
+    acc = block_sum(acc, red);
+    if (t == 0) lg[h * B + b] = acc + hi.b[h][0];
   }
 }
 
@@ -167,7 +246,8 @@ struct EnHeads {
   const float* xd; long xoff[7]; int K[7];
   const float* w[7]; const float* b[7];
   const float* emo; const float* cau; const float* pair;
-  const float* lat;
+  const float* lg_in;                // [7][B] pre-activations (en_sample_kernel)
+  const float* klrow;                // [B][3]
   float w_con_adv, w_ec_adv, w_ecce_adv, w_ec_mul, w_con_mul, w_pair, kl_w_ec, kl_w_con, ls, eps;
   Dropout d_emul, d_caumul, d_pair;
   const float* rowstat;              // [4][B][2]: content_disc(emotion), content_disc(cause), content_classifier, decoder
@@ -179,20 +259,13 @@ struct EnHeads {
 
 __global__ __launch_bounds__(1024) void en_heads_kernel(EnHeads a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int B = a.B, D = a.D, Cd = a.Cd;
+  const int B = a.B, D = a.D;
   float* red = sm;                   // 16
   float* lg = sm + 16;               // [7][B]
   float* dl = lg + 7 * B;            // [7][B]
   float* de = dl + 7 * B;            // [4][B]
-  const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wv = t >> 6, nw = nthr >> 6;
-  for (int pr = wv; pr < 7 * B; pr += nw) {
-    const int h = pr / B, b = pr - h * B;
-    const float* x = a.xd + a.xoff[h] + (long)b * a.K[h];
-    float s = 0.f;
-    for (int k = lane; k < a.K[h]; k += 64) s = fmaf(x[k], a.w[h][k], s);
-    s = wave_sum(s);
-    if (lane == 0) lg[pr] = s + a.b[h][0];
-  }
+  const int t = threadIdx.x, nthr = blockDim.x;
+  for (int e = t; e < 7 * B; e += nthr) lg[e] = a.lg_in[e];
   float ys = 0.f;
   for (int b = t; b < B; b += nthr) ys += a.pair[b];
   ys = block_sum(ys, red);           // also publishes lg
@@ -231,17 +304,8 @@ __global__ __launch_bounds__(1024) void en_heads_kernel(EnHeads a) {
   for (int h = 0; h < 7; ++h) loss[h] = block_sum(loss[h], red) * invB;
 #pragma unroll
   for (int h = 0; h < 4; ++h) ent[h] = block_sum(ent[h], red) * invB;
-  // KL (:615-624): mean_b(-0.5 sum_d(1 + lv - exp(lv) - mu^2))
-  const int LW = 2 * Cd + 4 * D;
-  float kl[3] = {0.f, 0.f, 0.f};
-  for (int e = t; e < B * (2 * D + Cd); e += nthr) {
-    const int b = e / (2 * D + Cd), k = e - b * (2 * D + Cd);
-    int mu, lv;
-    en_lat_index(k, D, Cd, mu, lv);
-    const float m = a.lat[(long)b * LW + mu], l = a.lat[(long)b * LW + lv];
-    const float v = -0.5f * (1.f + l - expf(l) - m * m);
-    if (k < D) kl[0] += v; else if (k < 2 * D) kl[1] += v; else kl[2] += v;
-  }
+  float kl[3] = {0.f, 0.f, 0.f};          // per-sample sums from en_sample_kernel (:615-624)
+  for (int b = t; b < B; b += nthr) { kl[0] += a.klrow[b * 3]; kl[1] += a.klrow[b * 3 + 1]; kl[2] += a.klrow[b * 3 + 2]; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) kl[i] = block_sum(kl[i], red) * invB;
   float rs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // cd_e loss, cd_e ent, cd_c loss, cd_c ent, cmul loss, dec loss
@@ -276,10 +340,19 @@ __global__ __launch_bounds__(1024) void en_heads_kernel(EnHeads a) {
       const float* x = a.xd + a.xoff[h] + k;
       const int Kh = a.K[h];
       float s = 0.f, se = 0.f;
-      for (int b = 0; b < B; ++b) {
+      const float* deh = de + (h < 4 ? h : 0) * B;
+      int b = 0;
+      for (; b + 8 <= B; b += 8) {          // eight loads in flight; accumulation order stays b = 0, 1, 2, ...
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = x[(long)(b + u) * Kh];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s = fmaf(dl[h * B + b + u], xv[u], s); se = fmaf(deh[b + u], xv[u], se); }
+      }
+      for (; b < B; ++b) {
         const float xv = x[(long)b * Kh];
         s = fmaf(dl[h * B + b], xv, s);
-        if (h < 4) se = fmaf(de[h * B + b], xv, se);
+        se = fmaf(deh[b], xv, se);
       }
       a.gw[h][k] = s;
       if (h < 4) a.gew[h][k] = se;
@@ -352,7 +425,7 @@ constexpr int EN_MAX_SPLITS = 64;
 
 struct EnWork {
   float* xd; long xoff[EN_NSEG]; float* L1; float* L2; float* rowstat; float* dxd_cmul; float* dz_dec; float* dz_heads; float* parts;
-  float* dlat; float* dpooled; float* dpre; float* dcls; float* dgpart;
+  float* dlat; float* dpooled; float* dpre; float* dcls; float* dgpart; float* rowpart; float* rowpart2; float* lg; float* klrow;
   size_t total;
 };
 // inputs of the heads, in the order of the ten nn.Dropout calls (sites 110..119)
@@ -380,6 +453,8 @@ static EnWork en_carve(float* base, int B, int D, int Cd, int V) {
   w.dlat = take((size_t)B * LW); w.dpooled = take((size_t)B * TH); w.dpre = take((size_t)B * TH); w.dcls = take((size_t)B * TH);
   const int hc = (2 * Cd + DG_CHUNK - 1) / DG_CHUNK + (4 * D + DG_CHUNK - 1) / DG_CHUNK, pc = (TH + DG_CHUNK - 1) / DG_CHUNK;
   w.dgpart = take((size_t)(hc > pc ? hc : pc) * B * TH);
+  const size_t chunks = (size_t)(V + BR_CHUNK - 1) / BR_CHUNK;
+  w.rowpart = take((size_t)B * chunks * 2); w.rowpart2 = take((size_t)B * chunks * 4); w.lg = take((size_t)7 * B); w.klrow = take((size_t)3 * B);
   w.total = o;
   return w;
 }
@@ -403,7 +478,7 @@ static int sgemm(const float* A, long lda, bool ta, const float* Bm, long ldb, b
                  const float* bias, int accumulate, int splits, long c_split_stride, hipStream_t stream) {
   if (M < 1 || N < 1 || K < 1 || splits < 1) return set_error(CAREL_ERR_SHAPE, "carel_sgemm_f32: bad shape");
   int kchunk = (K + splits - 1) / splits;
-  kchunk = (kchunk + 15) & ~15;
+  kchunk = (kchunk + SG_BK - 1) & ~(SG_BK - 1);
   const int nz = (K + kchunk - 1) / kchunk;
   if (nz != splits && splits > 1) {       // fewer non-empty chunks than requested: the caller sums `splits` slabs, so clear the tail
     (void)hipMemsetAsync(C + (long)nz * c_split_stride, 0, sizeof(float) * (size_t)(splits - nz) * (size_t)c_split_stride, stream);
@@ -476,8 +551,15 @@ static int bow_head(const carel_en_tail_args* a, const EnWork& w, const BowHead&
   if (rc) return rc;
   BowRowArgs r; r.L = w.L1; r.L2 = w.L2; r.bow = (const float*)a->bow; r.B = B; r.V = V; r.ls = a->label_smoothing; r.eps = a->epsilon;
   r.s_bce = h.s_bce; r.s_ent = h.s_ent; r.rowstat = h.rowstat;
-  if (h.ent) hipLaunchKernelGGL(bow_row_kernel<1>, dim3(B), dim3(1024), 0, stream, r);
-  else hipLaunchKernelGGL(bow_row_kernel<0>, dim3(B), dim3(1024), 0, stream, r);
+  const int chunks = (V + BR_CHUNK - 1) / BR_CHUNK;
+  const dim3 rg(chunks, B);
+#define BOW_ROW(PASS)                                                                                                         \
+  do {                                                                                                                        \
+    if (h.ent) hipLaunchKernelGGL((bow_row_kernel<1, PASS>), rg, dim3(BR_THREADS), 0, stream, r, w.rowpart, w.rowpart2, chunks);  \
+    else hipLaunchKernelGGL((bow_row_kernel<0, PASS>), rg, dim3(BR_THREADS), 0, stream, r, w.rowpart, w.rowpart2, chunks);        \
+  } while (0)
+  BOW_ROW(1); BOW_ROW(2); BOW_ROW(3);
+#undef BOW_ROW
   if ((rc = check_launch("bow_row_kernel"))) return rc;
   // dW[j][k] = sum_b dL[b][j] x[b][k]
   if ((rc = sgemm(w.L1, V, true, h.x, h.K, true, h.gw, h.K, V, h.K, B, nullptr, h.acc_g, 1, 0, stream))) return rc;
@@ -520,8 +602,13 @@ extern "C" int carel_en_tail_losses(const carel_en_tail_args* a, void* stream_) 
     sg.dst[s] = w.xoff[s];
     sg.d[s] = make_dropout(a->drop_seed, 110u + (uint32_t)s, a->drop_p, 0u);
   }
-  hipLaunchKernelGGL(en_sample_kernel, dim3((B * ZW + 255) / 256), dim3(256), 0, stream, (const float*)a->lat, (const float*)a->eps, B, D, Cd,
-                     (float*)a->z, w.xd, sg);
+  const int seg_of_head[7] = {3, 6, 4, 7, 5, 8, 9};
+  const void* hw[7] = {a->sdisc_w[0], a->sdisc_w[1], a->sdisc_w[2], a->sdisc_w[3], a->emo_w, a->cau_w, a->pair_w};
+  const void* hb[7] = {a->sdisc_b[0], a->sdisc_b[1], a->sdisc_b[2], a->sdisc_b[3], a->emo_b, a->cau_b, a->pair_b};
+  EnHeadIn hin;
+  for (int i = 0; i < 7; ++i) { hin.hseg[i] = seg_of_head[i]; hin.w[i] = (const float*)hw[i]; hin.b[i] = (const float*)hb[i]; }
+  hipLaunchKernelGGL(en_sample_kernel, dim3(B), dim3(512), sizeof(float) * (size_t)(ZW + 16), stream, (const float*)a->lat, (const float*)a->eps,
+                     B, D, Cd, (float*)a->z, w.xd, sg, hin, w.lg, w.klrow);
   if ((rc = check_launch("en_sample_kernel"))) return rc;
   const float inv_b = 1.0f / (float)B, inv_bv = inv_b / (float)V;
   BowHead h;
@@ -546,9 +633,6 @@ extern "C" int carel_en_tail_losses(const carel_en_tail_args* a, void* stream_) 
 
   EnHeads e;
   e.B = B; e.D = D; e.Cd = Cd; e.V = V; e.xd = w.xd;
-  const int seg_of_head[7] = {3, 6, 4, 7, 5, 8, 9};
-  const void* hw[7] = {a->sdisc_w[0], a->sdisc_w[1], a->sdisc_w[2], a->sdisc_w[3], a->emo_w, a->cau_w, a->pair_w};
-  const void* hb[7] = {a->sdisc_b[0], a->sdisc_b[1], a->sdisc_b[2], a->sdisc_b[3], a->emo_b, a->cau_b, a->pair_b};
   void* gw[7] = {a->g_sdisc_w[0], a->g_sdisc_w[1], a->g_sdisc_w[2], a->g_sdisc_w[3], a->d_emo_w, a->d_cau_w, a->d_pair_w};
   void* gb[7] = {a->g_sdisc_b[0], a->g_sdisc_b[1], a->g_sdisc_b[2], a->g_sdisc_b[3], a->d_emo_b, a->d_cau_b, a->d_pair_b};
   for (int i = 0; i < 7; ++i) {
@@ -556,7 +640,7 @@ extern "C" int carel_en_tail_losses(const carel_en_tail_args* a, void* stream_) 
     e.w[i] = (const float*)hw[i]; e.b[i] = (const float*)hb[i]; e.gw[i] = (float*)gw[i]; e.gb[i] = (float*)gb[i];
   }
   for (int i = 0; i < 4; ++i) { e.gew[i] = (float*)a->g_sdisc_ent_w[i]; e.geb[i] = (float*)a->g_sdisc_ent_b[i]; }
-  e.emo = (const float*)a->emo_labels; e.cau = (const float*)a->cau_labels; e.pair = (const float*)a->pair_labels; e.lat = (const float*)a->lat;
+  e.emo = (const float*)a->emo_labels; e.cau = (const float*)a->cau_labels; e.pair = (const float*)a->pair_labels; e.lg_in = w.lg; e.klrow = w.klrow;
   e.w_con_adv = a->w_con_adv; e.w_ec_adv = a->w_ec_adv; e.w_ecce_adv = a->w_ecce_adv; e.w_ec_mul = a->w_ec_mul; e.w_con_mul = a->w_con_mul;
   e.w_pair = a->w_pair; e.kl_w_ec = a->kl_w_ec; e.kl_w_con = a->kl_w_con; e.ls = a->label_smoothing; e.eps = a->epsilon;
   e.d_emul = sg.d[5]; e.d_caumul = sg.d[8]; e.d_pair = sg.d[9];
