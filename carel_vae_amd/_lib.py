@@ -199,6 +199,7 @@ SIGNATURES = {
     "carel_pair_probs": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_adam_step": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "carel_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "carel_rmsprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "carel_encoder_act_bytes": (C.c_int64, [C.c_int32] * 4),
     "carel_encoder_scratch_bytes": (C.c_int64, [C.c_int32] * 2),
     "carel_encoder_x_last": (C.c_void_p, [C.POINTER(EncoderArgs)]),

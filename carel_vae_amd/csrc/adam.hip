@@ -50,6 +50,20 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
+// torch.optim.RMSprop defaults (drl_classifier_en.py:1056-1060: the five discriminator optimisers): alpha 0.99, eps 1e-8,
+// no momentum, not centered, no weight decay:  v = alpha v + (1 - alpha) g^2 ;  p -= lr g / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v, long n,
+                                                      float lr, float alpha, float eps) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float gi = g[i];
+    const float vi = v[i] * alpha + (1.0f - alpha) * gi * gi;        // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
+    v[i] = vi;
+    p[i] = p[i] - lr * (gi / (sqrtf(vi) + eps));                     // param.addcdiv_(grad, sqrt(square_avg) + eps, value=-lr)
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
@@ -88,6 +102,15 @@ extern "C" int carel_adam_step(const carel_adam_args* a, void* stream_) {
   k.skip_lo = a->skip_lo; k.skip_hi = a->skip_hi; k.skip_flag = (const float*)a->skip_flag;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(k.n)), dim3(256), 0, stream, k);
   return check_launch("adam_kernel");
+}
+
+extern "C" int carel_rmsprop_step(void* param, const void* grad, void* square_avg, int64_t n, float lr, float alpha, float eps, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!param || !grad || !square_avg || n <= 0) return set_error(CAREL_ERR_ARG, "carel_rmsprop_step: bad arguments");
+  long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (float*)param, (const float*)grad, (float*)square_avg, (long)n,
+                     lr, alpha, eps);
+  return check_launch("rmsprop_kernel");
 }
 
 extern "C" int carel_cast_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream_) {

@@ -66,6 +66,37 @@ class _EnLosses(torch.autograd.Function):
         return None, None, None
 
 
+class FusedRMSprop:
+    """`torch.optim.RMSprop(params, lr)` (torch defaults) over one contiguous range of the model's flat buffer; used through
+    zero_grad() / step() like the reference's discriminator optimisers (:919-947, :1056-1060)."""
+
+    def __init__(self, model, lr, param_range, params, alpha=0.99, eps=1e-8):
+        model._require_cuda()
+        self.model, self.lr, self.alpha, self.eps = model, lr, alpha, eps
+        self._lo, self._hi = param_range
+        self._params = list(params)
+        self.square_avg = torch.zeros(self._hi - self._lo, device=model._flat.device, dtype=torch.float32)
+        self.param_groups = [dict(params=self._params, lr=lr, alpha=alpha, eps=eps)]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._params:
+            p.grad = None
+
+    def step(self):
+        m = self.model
+        if any(p.grad is None for p in self._params):
+            return                                   # torch skips parameters without a gradient
+        L.check(L.load().carel_rmsprop_step(m._flat.data_ptr() + 4 * self._lo, m._flat_grad.data_ptr() + 4 * self._lo, self.square_avg.data_ptr(),
+                                            self._hi - self._lo, self.param_groups[0]["lr"], self.alpha, self.eps, L.current_stream()),
+                "carel_rmsprop_step")
+
+    def state_dict(self):
+        return dict(square_avg=self.square_avg, lr=self.lr)
+
+    def load_state_dict(self, sd):
+        self.square_avg.copy_(sd["square_avg"])
+
+
 class DrlClassifier(_Base):
     """Reference `DrlClassifier` of drl_classifier_en.py (:140-624)."""
 
@@ -131,11 +162,12 @@ class DrlClassifier(_Base):
         return tuple(groups) + (other,)
 
     def make_fused_optimizers(self, adv_lr=None, vae_lr=None, fuse_into_backward=False):
-        """Six FusedAdam objects in get_params() order (the tuple the reference's train() unpacks, :884)."""
+        """The six optimisers of the script body (:1056-1062) as HIP kernels over the flat buffer, in get_params() order (the
+        list the reference's train() unpacks, :884): RMSprop(adv_lr) for the five discriminators, Adam(vae_lr) for the rest."""
         adv_lr = self.opt.adv_lr if adv_lr is None else adv_lr
         vae_lr = self.opt.vae_lr if vae_lr is None else vae_lr
         groups = self.get_params()
-        opts = [FusedAdam(self, lr=adv_lr, param_range=self._group_ranges[g], params=groups[i]) for i, g in enumerate(DISC_GROUPS)]
+        opts = [FusedRMSprop(self, lr=adv_lr, param_range=self._group_ranges[g], params=groups[i]) for i, g in enumerate(DISC_GROUPS)]
         opts.append(FusedAdam(self, lr=vae_lr, param_range=self._group_ranges["vae"], params=groups[5], fuse_into_backward=fuse_into_backward))
         return tuple(opts)
 

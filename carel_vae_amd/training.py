@@ -1,7 +1,8 @@
 """The reference's training driver around the hot path: `train`, `generate_self_train_data`, `save_ckp`,
 `load_ckp` (drl_classifier_ec_mmd_final_mul.py :603-628, :734-799, :802-922), same signatures and control
 flow; `opt` is an explicit keyword instead of a module global.  With two optimisers it runs the VI ablation's
-two-phase step (drl_classifier_ec_vi.py :723-790).  The step body (:823-845) is unchanged: the
+two-phase step (drl_classifier_ec_vi.py :723-790); with six, the adversarial step of drl_classifier_en.py (:904-947: five
+discriminator backward calls, the vae backward, six optimiser steps; evaluation on sigmoid(logits), :975-976).  The step body (:823-845) is unchanged: the
 model/optimiser objects it calls are carel_vae_amd.DrlClassifier and FusedAdam (or any torch optimiser).
 """
 import os
@@ -48,6 +49,8 @@ def generate_self_train_data(test_docs_pair_size, test_df, test_loader, model, s
             att = data["attention_masks"].to(device, dtype=torch.long)
             tt = data["token_type_ids"].to(device, dtype=torch.long)
             outs = model.get_pair_preds(ids, att, tt)
+            if torch.is_tensor(outs):        # drl_classifier_en.py:826-828: raw logits -> probabilities
+                outs = torch.sigmoid(outs).cpu().detach().numpy().tolist()
             predicted_df["label"] = [x[0] for x in outs]
     rows, curr = [], 0
     for doc_pair_size in test_docs_pair_size:
@@ -88,7 +91,8 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
     evaluation pass with `get_pair_preds`, checkpointing the best F1."""
     opt = opt if opt is not None else model.opt
     vi = len(optimizers) == 2       # VI ablation (drl_classifier_ec_vi.py:723-725): [ec_aprx_opt, vae_and_cls_opt]
-    ec_aprx_opt, vae_and_cls_opt = optimizers if vi else (None, optimizers[0])
+    en = len(optimizers) == 6       # drl_classifier_en.py:884: five discriminator optimisers + vae_and_cls_opt
+    ec_aprx_opt, vae_and_cls_opt = optimizers if vi else (None, optimizers[-1])
     max_p = max_r = max_f1 = 0.0
     self_p = self_r = self_f1 = 0.0
     if self_train:
@@ -113,9 +117,33 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
             att = batch["attention_masks"].to(device, dtype=torch.long, non_blocking=True)
             tt = batch["token_type_ids"].to(device, dtype=torch.long, non_blocking=True)
             labels = batch["labels"].to(device, dtype=torch.float, non_blocking=True)
-            emo = batch["emo_labels"].to(device, dtype=torch.long, non_blocking=True)
+            emo = batch["emo_labels"].to(device, dtype=torch.float if en else torch.long, non_blocking=True)
             cau = batch["cau_labels"].to(device, dtype=torch.float, non_blocking=True)
             bow = batch["bow_reps"].to(device, dtype=torch.float, non_blocking=True)
+            if en:                  # drl_classifier_en.py:913-947
+                content_disc_opt, emotion_disc_opt, cause_disc_opt, ec_disc_opt, ce_disc_opt, _ = optimizers
+                losses = model(ids, att, tt, emo, cau, labels, bow, iteration, **kw)
+                cd_emo, cd_cau, emotion_disc_loss, ec_disc_loss, cause_disc_loss, ce_disc_loss, loss = losses
+                content_disc_opt.zero_grad()
+                (cd_emo + cd_cau).backward(retain_graph=True)
+                emotion_disc_opt.zero_grad()
+                emotion_disc_loss.backward(retain_graph=True)
+                ec_disc_opt.zero_grad()
+                ec_disc_loss.backward(retain_graph=True)
+                cause_disc_opt.zero_grad()
+                cause_disc_loss.backward(retain_graph=True)
+                ce_disc_opt.zero_grad()
+                ce_disc_loss.backward(retain_graph=True)
+                vae_and_cls_opt.zero_grad()
+                loss.backward()
+                for o in optimizers:
+                    o.step()
+                step_loss = sum(l.detach() for l in losses)
+                running_loss = step_loss if isinstance(running_loss, int) else running_loss + step_loss
+                if iteration % 10 == 9:
+                    log("[%d, %5d] training loss: %.4f" % (epoch, iteration + 1, float(running_loss) / 10))
+                    running_loss = 0
+                continue
             if vi:                  # two-phase step, drl_classifier_ec_vi.py:754-774
                 e_embedding, c_embedding, ec_aprx_loss, loss = model(ids, att, tt, emo, cau, labels, bow, iteration, **kw)
                 ec_aprx_opt.zero_grad()
@@ -144,6 +172,8 @@ def train(train_loader, test_loader, model, optimizers, device, num_unpred_pairs
                 tt = batch["token_type_ids"].to(device, dtype=torch.long)
                 labels = batch["labels"].cpu().numpy().tolist()
                 preds = model.get_pair_preds(ids, att, tt)
+                if torch.is_tensor(preds):       # drl_classifier_en.py:975-976
+                    preds = torch.sigmoid(preds).cpu().detach().numpy().round().tolist()
                 labels += [[1]] * num_unpred_pairs            # unpredicted emotions count as misses (:864-865)
                 preds += [[0]] * num_unpred_pairs
                 p, r, f1 = _prf1(labels, preds)

@@ -360,6 +360,9 @@ typedef struct carel_adam_args {
 } carel_adam_args;
 int carel_adam_step(const carel_adam_args* args, void* stream);
 int carel_cast_f32_to_bf16(const void* src_f32, void* dst_bf16, int64_t n, void* stream);
+/* torch.optim.RMSprop(params, lr).step() with torch's defaults (alpha 0.99, eps 1e-8, no momentum, not centered): the
+ * optimiser of the five discriminators of drl_classifier_en.py (:1056-1060).  fp32 only (the discriminators have no bf16 copy). */
+int carel_rmsprop_step(void* param_f32, const void* grad_f32, void* square_avg_f32, int64_t n, float lr, float alpha, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RBF-MMD statistic.  Replaces MMDStatistic.__call__ (ref :547-569) + pdist (ref :580-589) and

@@ -220,12 +220,30 @@ def loss_and_grads(P, batch, iteration, cfg, opt: OptEn, eps, **kw):
     return {k: v.detach() for k, v in out.items()}, grads
 
 
+def rmsprop_step(P, grads, keys, st: "O.AdamState", lr, alpha=0.99, eps=1e-8):
+    """torch.optim.RMSprop defaults (no momentum, not centered, no weight decay): v = alpha v + (1 - alpha) g^2;
+    p -= lr g / (sqrt(v) + eps).  The running average lives in st.v."""
+    for k in keys:
+        g = grads.get(k)
+        if g is None:
+            continue
+        if k not in st.v:
+            st.v[k] = torch.zeros_like(g)
+        st.v[k].mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        P[k] = P[k] - lr * (g / (st.v[k].sqrt() + eps))
+    return P
+
+
 def train_step(P, batch, iteration, cfg, opt: OptEn, states, eps, **kw):
-    """One iteration of the training loop (:904-947).  states: six carel_oracle.AdamState, in get_params order."""
+    """One iteration of the training loop (:904-947) with the optimisers the script builds (:1056-1062): RMSprop(adv_lr)
+    for the five discriminators, Adam(vae_lr) for the rest.  states: six carel_oracle.AdamState, in get_params order."""
     out, grads = loss_and_grads(P, batch, iteration, cfg, opt, eps, **kw)
     P = dict(P)
     for i, keys in enumerate(group_keys(cfg, opt)):
-        P = O.adam_step(P, grads, keys, states[i], lr=opt.adv_lr if i < 5 else opt.vae_lr)
+        if i < 5:
+            P = rmsprop_step(P, grads, keys, states[i], lr=opt.adv_lr)
+        else:
+            P = O.adam_step(P, grads, keys, states[i], lr=opt.vae_lr)
     return P, out, grads
 
 

@@ -4,7 +4,8 @@ reference's own `DrlClassifier` class (AST-extracted at run time, nothing copied
 2-layer RobertaModel.
 
 The update sequence below -- five discriminator backward calls with retain_graph, the vae backward, then six Adam
-steps -- is the procedure of the reference's training loop (:919-947); every model call in it is reference code.
+steps -- is the procedure of the reference's training loop (:919-947) with the optimisers its script body builds (RMSprop for
+the five discriminators, Adam for the rest, :1056-1062); every model call in it is reference code.
 Weights come from oracle.carel_oracle_en.init_params (numpy RandomState), so the fixture holds inputs, noise and expected
 outputs only.
 
@@ -80,7 +81,7 @@ def main():
     got = [[ids[id(p)] for p in g] for g in groups]          # encoder keys: HF's own order, compared as a set
     assert [heads(g) for g in got] == [heads(g) for g in okeys] and [set(g) for g in got] == [set(g) for g in okeys], \
         "get_params grouping differs from oracle.group_keys"
-    opts = [torch.optim.Adam(g, lr=opt.adv_lr) for g in groups[:5]] + [torch.optim.Adam(groups[5], lr=opt.vae_lr)]
+    opts = [torch.optim.RMSprop(g, lr=opt.adv_lr) for g in groups[:5]] + [torch.optim.Adam(groups[5], lr=opt.vae_lr)]    # :1056-1062
     rec = dict(meta=np.array([B, S, cfg.layers, cfg.vocab_size, opt.pair_bow_dim, wseed, bseed, steps], dtype=np.int64),
                versions=np.array(f"torch={torch.__version__};transformers={__import__('transformers').__version__}"))
     for k, v in batch.items():

@@ -65,3 +65,31 @@ def test_train_driver_end_to_end(tmp_path, mode):
     assert list(df.columns) == ["pair", "label", "emotion"] and set(df["label"]) <= {0, 1}
     preds = model.get_pair_preds(*(next(iter(test_loader))[k].cuda() for k in ("input_ids", "attention_masks", "token_type_ids")))
     assert len(preds) == len(test_df) and all(p[0] in (0.0, 1.0) for p in preds)
+
+
+def test_train_driver_english_adversarial(tmp_path):
+    """drl_classifier_en.py's loop (six optimisers, :904-947) through the same driver: discriminators on fused RMSprop, the
+    rest on fused Adam inside backward; evaluation thresholds sigmoid(logits) (:975-976)."""
+    from carel_vae_amd import drl_classifier_en as ME
+    torch.manual_seed(0)
+    train_loader, test_loader, test_df, sizes, unpred, V = _loaders(bs=4)
+    ds = train_loader.dataset
+    ds.emo_labels = (np.asarray(ds.emo_labels) > 2).astype(np.int64)           # the English script's emotion label is binary (:132)
+    opt = ME.make_opt(epochs=2, pair_bow_dim=V, best_model_path=str(tmp_path / "ckpt"), model_id="e2e_en", vae_lr=1e-4)
+    model = ME.DrlClassifier(opt, M.encoder_config("en", vocab_size=1300, layers=2), seed=1).to("cuda")
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    optimizers = list(model.make_fused_optimizers(fuse_into_backward=True))
+    logs = []
+    best = T.train(train_loader, test_loader, model, optimizers, "cuda", num_unpred_pairs=unpred, opt=opt, log=logs.append)
+    torch.cuda.synchronize()
+    assert best is model
+    after = model.state_dict()
+    moved = {k for k in before if not torch.equal(before[k], after[k])}
+    for k in ("content_disc.weight", "ec_disc.bias", "emotion_disc.weight", "content_classifier.weight", "decoder.bias",
+              "encoder.encoder.layer.0.output.dense.weight", "encoder.embeddings.word_embeddings.weight"):
+        assert k in moved, k
+    assert "content_mu.weight" not in moved and "cause_log_var.bias" not in moved       # in no optimiser group (:357-376)
+    assert all(torch.isfinite(v).all() for v in after.values())
+    assert sum("f1 socre" in str(l) for l in logs) == 2
+    df = T.generate_self_train_data(sizes, test_df, test_loader, model, "extreme")
+    assert set(df["label"]) <= {0, 1}

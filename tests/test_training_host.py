@@ -101,3 +101,41 @@ def test_train_loop_vi_two_phase(tmp_path):
     assert model.calls == [0, 1] * 3
     assert not torch.equal(model.a.detach(), a0)            # the approximation optimiser stepped
     assert float(model.w.abs().sum()) > 0.0                 # and so did the main one
+
+
+class TinyEnModel(nn.Module):
+    """Stand-in with the surface of drl_classifier_en.py: forward -> seven losses, five discriminator groups + the rest,
+    get_pair_preds -> raw logits tensor."""
+
+    def __init__(self):
+        super().__init__()
+        self.d = nn.ParameterList([nn.Parameter(torch.ones(2)) for _ in range(5)])
+        self.w = nn.Parameter(torch.zeros(3))
+        self.emo_dtype = None
+
+    def forward(self, ids, att, tt, emo, cau, labels, bow, iteration):
+        self.emo_dtype = emo.dtype
+        z = self.w.detach()                                  # discriminators see detached features (:425-515)
+        dl = [((d * (z[:2] + 1.0)).sum() - 1.0) ** 2 for d in self.d]
+        vae = (self.w.sum() - 1.0) ** 2 + 0.1 * sum((d * (z[:2] + 1.0)).sum() for d in self.d)      # entropy-like term on the discriminators
+        return dl[0], dl[0] * 0.5, dl[1], dl[3], dl[2], dl[4], vae
+
+    def get_pair_preds(self, ids, att, tt):
+        return torch.tensor([[3.0 if i % 2 else -3.0] for i in range(ids.shape[0])])
+
+
+def test_train_loop_english_six_optimisers(tmp_path):
+    opt = make_opt(epochs=2, best_model_path=str(tmp_path / "ckpt"), model_id="en")
+    model = TinyEnModel()
+    opts = [torch.optim.RMSprop([d], lr=0.01) for d in model.d] + [torch.optim.Adam([model.w], lr=0.01)]
+    d0 = [d.detach().clone() for d in model.d]
+    logs = []
+    T.train(list(batches(8, 4)), list(batches(6, 6)), model, opts, "cpu", num_unpred_pairs=0, opt=opt, log=logs.append)
+    assert model.emo_dtype == torch.float32                  # the English dataset's emotion label is a float (:132, :909)
+    assert all(not torch.equal(d.detach(), d0[i]) for i, d in enumerate(model.d)) and float(model.w.abs().sum()) > 0
+    f1_lines = [l for l in logs if "f1 socre" in str(l)]
+    assert len(f1_lines) == 2 and "1.0000" in str(f1_lines[0])      # sigmoid(logits).round() equals the alternating labels
+    # each discriminator's .grad after the step = its own loss's gradient + the vae loss's share (zero_grad order of :919-939)
+    g = model.d[1].grad.clone()
+    z = model.w.detach()[:2] + 1.0
+    assert g.abs().sum() > 0 and torch.isfinite(g).all() and z.numel() == 2
