@@ -143,6 +143,7 @@ class EnTailArgs(C.Structure):
                 ("w_con_adv", C.c_float), ("w_ec_adv", C.c_float), ("w_ecce_adv", C.c_float), ("w_ec_mul", C.c_float),
                 ("w_con_mul", C.c_float), ("w_pair", C.c_float), ("kl_w_ec", C.c_float), ("kl_w_con", C.c_float),
                 ("label_smoothing", C.c_float), ("epsilon", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("drop_row_offset", C.c_uint32), ("global_label_sum", C.c_void_p), ("global_n", C.c_int32),
                 ("pooled", C.c_void_p), ("lat", C.c_void_p), ("z", C.c_void_p), ("terms", C.c_void_p), ("work", C.c_void_p),
                 ("g_cdisc_w", C.c_void_p * 3), ("g_cdisc_b", C.c_void_p * 3),
                 ("g_sdisc_w", C.c_void_p * 4), ("g_sdisc_b", C.c_void_p * 4),

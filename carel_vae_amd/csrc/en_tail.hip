@@ -246,6 +246,7 @@ struct EnHeads {
   const float* xd; long xoff[7]; int K[7];
   const float* w[7]; const float* b[7];
   const float* emo; const float* cau; const float* pair;
+  const float* label_sum_override; float n_override;      // data parallel: pos_weight of the global batch
   const float* lg_in;                // [7][B] pre-activations (en_sample_kernel)
   const float* klrow;                // [B][3]
   float w_con_adv, w_ec_adv, w_ecce_adv, w_ec_mul, w_con_mul, w_pair, kl_w_ec, kl_w_con, ls, eps;
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(1024) void en_heads_kernel(EnHeads a) {
   float ys = 0.f;
   for (int b = t; b < B; b += nthr) ys += a.pair[b];
   ys = block_sum(ys, red);           // also publishes lg
-  const float pw = ((float)B - ys) / ys;
+  if (a.label_sum_override) ys = a.label_sum_override[0];
+  const float pw = ((a.label_sum_override ? a.n_override : (float)B) - ys) / ys;
   const float invB = 1.0f / (float)B;
   float loss[7], ent[4];
 #pragma unroll
@@ -600,7 +602,7 @@ extern "C" int carel_en_tail_losses(const carel_en_tail_args* a, void* stream_) 
   for (int s = 0; s < EN_NSEG; ++s) {
     en_seg(s, D, Cd, sg.src[s], sg.K[s]);
     sg.dst[s] = w.xoff[s];
-    sg.d[s] = make_dropout(a->drop_seed, 110u + (uint32_t)s, a->drop_p, 0u);
+    sg.d[s] = make_dropout(a->drop_seed, 110u + (uint32_t)s, a->drop_p, a->drop_row_offset * (uint32_t)sg.K[s]);
   }
   const int seg_of_head[7] = {3, 6, 4, 7, 5, 8, 9};
   const void* hw[7] = {a->sdisc_w[0], a->sdisc_w[1], a->sdisc_w[2], a->sdisc_w[3], a->emo_w, a->cau_w, a->pair_w};
@@ -641,6 +643,7 @@ extern "C" int carel_en_tail_losses(const carel_en_tail_args* a, void* stream_) 
   }
   for (int i = 0; i < 4; ++i) { e.gew[i] = (float*)a->g_sdisc_ent_w[i]; e.geb[i] = (float*)a->g_sdisc_ent_b[i]; }
   e.emo = (const float*)a->emo_labels; e.cau = (const float*)a->cau_labels; e.pair = (const float*)a->pair_labels; e.lg_in = w.lg; e.klrow = w.klrow;
+  e.label_sum_override = (const float*)a->global_label_sum; e.n_override = (float)a->global_n;
   e.w_con_adv = a->w_con_adv; e.w_ec_adv = a->w_ec_adv; e.w_ecce_adv = a->w_ecce_adv; e.w_ec_mul = a->w_ec_mul; e.w_con_mul = a->w_con_mul;
   e.w_pair = a->w_pair; e.kl_w_ec = a->kl_w_ec; e.kl_w_con = a->kl_w_con; e.ls = a->label_smoothing; e.eps = a->epsilon;
   e.d_emul = sg.d[5]; e.d_caumul = sg.d[8]; e.d_pair = sg.d[9];

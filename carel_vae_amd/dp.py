@@ -99,6 +99,18 @@ class DataParallel:
             self._noise_gen.manual_seed(self._noise_seed)
         return (torch.randn(n, device=device, generator=self._noise_gen), torch.randn(n, device=device, generator=self._noise_gen))
 
+    def draw_noise_sizes(self, sizes, device):
+        """Noise vectors of the given sizes from the same shared generator (models with more than two samples)."""
+        if self._noise_gen is None or self._noise_gen.device != torch.device(device):
+            self._noise_gen = torch.Generator(device=device)
+            self._noise_gen.manual_seed(self._noise_seed)
+        return tuple(torch.randn(n, device=device, generator=self._noise_gen) for n in sizes)
+
+    def all_reduce_sum(self, t):
+        """In-place sum over ranks of a small device tensor (stream-ordered; e.g. the pair-label sum for pos_weight)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
     def prepare(self, call):
         """Called when the batch is known (before the encoder runs): park this rank's label sum behind the z buffer, so
         that nothing but the all-gather itself sits between the latents and the loss kernel."""

@@ -180,6 +180,8 @@ class DrlClassifier(_Base):
         if self._noise is not None:
             con, e, c = (t.to(dev, torch.float32).reshape(-1) for t in self._noise)
             self._noise = None
+        elif self._dp is not None:                                  # same draws on every rank, no collective
+            con, e, c = self._dp.draw_noise_sizes((self.opt.con_dim, self.opt.ec_dim, self.opt.ec_dim), dev)
         else:
             con = torch.randn(self.opt.con_dim, device=dev)        # content, emotion, cause (:238-240)
             e = torch.randn(self.opt.ec_dim, device=dev)
@@ -189,8 +191,6 @@ class DrlClassifier(_Base):
     def _make_call(self, input_ids, att_masks, token_type_ids, emotion_labels, cause_labels, pair_labels, content_bow, iteration, training,
                    seq_lengths=None):
         self._require_cuda()
-        if self._dp is not None:
-            raise L.CarelError("DataParallel is not wired for the drl_classifier_en model")
         ops._chk_cuda(input_ids, att_masks, token_type_ids, content_bow)
         B, S = input_ids.shape
         Bp = self._padded_batch(B, S)
@@ -207,7 +207,10 @@ class DrlClassifier(_Base):
         c.eps = self._draw_noise_en(dev)
         self._fwd_count += 1
         c.seed = (self.dropout_base_seed * 1000003 + self._fwd_count) & 0xFFFFFFFF
-        c.row_offset = 0
+        c.row_offset = 0 if self._dp is None else self._dp.row_offset(B)
+        c.label_sum = None
+        if self._dp is not None:            # pos_weight (:599) of the GLOBAL batch: one float summed over ranks
+            c.label_sum = self._dp.all_reduce_sum(c.labels["pair"].sum().reshape(1))
         c.pack = self._pack_info(c.att, B, Bp, S, seq_lengths)
         key = ("en_tail", B, S)
         buf = self._ws.get(key)
@@ -254,6 +257,9 @@ class DrlClassifier(_Base):
         a.w_ec_mul, a.w_con_mul, a.w_pair = o.ec_mul_loss_weight, o.con_mul_loss_weight, o.pair_mul_loss_weight
         a.label_smoothing, a.epsilon = o.label_smoothing, o.epsilon
         a.drop_p, a.drop_seed = (o.dropout if train_drop else 0.0), c.seed
+        a.drop_row_offset = getattr(c, "row_offset", 0)
+        if getattr(c, "label_sum", None) is not None:
+            a.global_label_sum, a.global_n = c.label_sum.data_ptr(), self._dp.world * c.B
         b = c.buf
         a.pooled, a.lat, a.z, a.terms, a.work = b.pooled.data_ptr(), b.lat.data_ptr(), b.z.data_ptr(), b.terms.data_ptr(), b.work.data_ptr()
         img = lambda i, k: self._disc_img[i].data_ptr() + 4 * (self._offs[k] - self._disc_lo)      # noqa: E731
@@ -278,7 +284,7 @@ class DrlClassifier(_Base):
         train_drop = self.training
         ws = self._workspace(c.Bp, c.S, inference=not training)
         c.cls = self._cls_info(c.B, c.Bp, c.S, c.pack, self._flat.device)
-        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, 0, c.pack, c.cls)
+        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset, c.pack, c.cls)
         lib, st = L.load(), L.current_stream()
         L.check(lib.carel_encoder_forward(C.byref(ea), st), "carel_encoder_forward")
         x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
@@ -337,7 +343,11 @@ class DrlClassifier(_Base):
             L.check(lib.carel_en_tail_backward(C.byref(c.ta), go.data_ptr(), st), "carel_en_tail_backward")
             h_lo = self._offs[OTHER_HEADS[0] + ".weight"]          # classifier / decoder gradients were produced for grad_output = 1
             ops.scale_(self._flat_grad[h_lo:hi], go)
+            if self._dp is not None:          # pooler, heads and (now complete) discriminator gradients: one bucket.  Under data
+                self._dp.tail_done()          # parallelism the discriminator backward calls must precede this one (the reference's order)
             self._backward_encoder(ea, accumulate)
+            if self._dp is not None:
+                self._dp.backward_done()
             if accumulate:
                 self._flat_grad[lo:hi].add_(prev)
             touched["vae"] = True

@@ -472,6 +472,10 @@ typedef struct carel_en_tail_args {
   float kl_w_ec, kl_w_con;                          /* annealed KL weights (1 once iteration >= kl_ann_iterations) */
   float label_smoothing, epsilon;
   float drop_p; uint32_t drop_seed;
+  uint32_t drop_row_offset;                         /* data parallel: first GLOBAL sample index of this shard (dropout masks hash
+                                                       the global element index) */
+  const void* global_label_sum;                     /* f32 [1] or NULL: sum of pair labels over the GLOBAL batch (pos_weight, :599) */
+  int32_t global_n;                                 /* global batch size (with global_label_sum) */
   /* outputs */
   void* pooled;                      /* f32 [B, 768] */
   void* lat;                         /* f32 [B, 2*con_dim + 4*ec_dim] */

@@ -111,7 +111,8 @@ def kl_anneal_weight(iteration: int, opt: OptEn, lam: float) -> float:
 
 
 def tail_forward(P, pooled, emo_labels, cau_labels, pair_labels, bow, iteration: int, opt: OptEn, eps: Dict[str, torch.Tensor],
-                 train: bool = False, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                 train: bool = False, seed: Optional[int] = None, row_offset: int = 0, global_label_sum: Optional[float] = None,
+                 global_n: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Everything after pooler_output (:220-334).  eps: {"con": [con_dim], "e": [ec_dim], "c": [ec_dim]} -- sample_prior
     is called for content, emotion, cause in that order (:238-240), one vector per call shared by the batch (:417-423).
     Labels are float [B, 1] (the `_en` dataset yields float emotion labels, :132)."""
@@ -131,7 +132,7 @@ def tail_forward(P, pooled, emo_labels, cau_labels, pair_labels, bow, iteration:
     pd = opt.dropout if train else 0.0
 
     def drop(t, site):
-        m = O.dropout_scale_mask(seed, site, tuple(t.shape), pd)
+        m = O.dropout_scale_mask(seed, site, tuple(t.shape), pd, row_offset)
         return t if m is None else t * m
     emo_y = emo_labels.view(B, -1).to(torch.float32)
     cau_y = cau_labels.view(B, -1).to(torch.float32)
@@ -161,7 +162,8 @@ def tail_forward(P, pooled, emo_labels, cau_labels, pair_labels, bow, iteration:
     cau_mul = O.bce_prob(torch.sigmoid(lin(drop(z_c, SITE_CAUMUL), "cause_classifier")), ec_t(cau_y)).mean()
     # pair (:283, :587-603): no infinity guard in this script
     xp = lin(drop(pair_emb, SITE_PAIR), "pair_classifier")
-    pw = (B - pair_y.sum()) / pair_y.sum()
+    sy = pair_y.sum() if global_label_sum is None else torch.tensor(float(global_label_sum))       # data-parallel shard: global batch
+    pw = ((B if global_n is None else global_n) - sy) / sy
     pair = O.bce_logits_posw(xp, ec_t(pair_y), pw).mean()
     # KL (:285-303)
 
@@ -182,12 +184,12 @@ def tail_forward(P, pooled, emo_labels, cau_labels, pair_labels, bow, iteration:
                 mu_e=mu_e, mu_c=mu_c, mu_con=mu_con, lv_e=lv_e, lv_c=lv_c, lv_con=lv_con, z=gen, pair_logit=xp)
 
 
-def forward_terms(P, batch, iteration, cfg, opt: OptEn, eps, train=False, seed=None, quant: O.Quant = None):
+def forward_terms(P, batch, iteration, cfg, opt: OptEn, eps, train=False, seed=None, quant: O.Quant = None, row_offset=0, **kw):
     """`DrlClassifier.forward` (:205-334) with every term exposed."""
     pooled = O.encoder_forward(P, batch["input_ids"], batch["attention_masks"], batch["token_type_ids"], cfg,
-                               train=train, seed=seed, quant=quant)
+                               train=train, seed=seed, row_offset=row_offset, quant=quant)
     out = tail_forward(P, pooled, batch["emo_labels"], batch["cau_labels"], batch["labels"], batch["bow_reps"], iteration, opt, eps,
-                       train=train, seed=seed)
+                       train=train, seed=seed, row_offset=row_offset, **kw)
     out["pooled"] = pooled
     return out
 
