@@ -271,3 +271,31 @@ def test_full_size_heads_finite_and_consistent():
     reference_step(losses, opts)
     assert relnorm(model.decoder.weight.grad, W.grad) < 1e-4
     assert relnorm(model.decoder.bias.grad, bvec.grad) < 1e-4
+
+
+@pytest.mark.parametrize("nb,S", [(3, 64), (1, 32), (7, 128)])
+def test_small_and_odd_batches(golden_dir, nb, S):
+    """Ragged sizes: odd batch, a single sample, shorter sequences (padding of the batch to a tile multiple must not leak into
+    any term or gradient)."""
+    opt = OE.OptEn(pair_bow_dim=211, dropout=0.0)
+    z, batch = load(golden_dir)
+    wseed = int(z["meta"][5])
+    model, P = build(opt, wseed)
+    model.train()
+    sub = {k: (v[:nb, :S] if v.dim() == 2 and v.shape[1] == 128 else v[:nb]).contiguous() for k, v in batch.items()}
+    sub["attention_masks"][:, 0] = 1
+    sub["labels"][0] = 1.0                                   # at least one positive pair (pos_weight divides by their number, :599)
+    eps = eps_of(z, 2)
+    model.set_noise(eps["con"], eps["e"], eps["c"])
+    losses = model(*call(sub, 5))
+    ref, grads = OE.loss_and_grads(P, sub, 5, CFG, opt, eps, quant=O.bf16_round)
+    got = np.array([float(v.detach()) for v in losses])
+    want = np.array([float(ref[n]) for n in OE.LOSS_NAMES])
+    np.testing.assert_allclose(got, want, rtol=4e-3, atol=1e-5)
+    gp = model.get_params()
+    opts = [torch.optim.RMSprop(g, lr=opt.adv_lr) for g in gp[:5]] + [torch.optim.Adam(gp[5], lr=opt.vae_lr)]
+    reference_step(losses, opts)
+    named = dict(model.named_parameters())
+    for k in ("content_disc.weight", "cause_disc.weight", "content_classifier.bias", "decoder.weight", "pair_classifier.weight",
+              "encoder.pooler.dense.weight", "encoder.encoder.layer.0.intermediate.dense.weight", "encoder.embeddings.word_embeddings.weight"):
+        assert relnorm(named[k].grad, grads[k]) < 4e-2, (k, relnorm(named[k].grad, grads[k]))
