@@ -12,15 +12,20 @@ runs unchanged.  All seven losses and every gradient are produced by the forward
 graph); a discriminator's backward call only adds its share into `.grad`, the last one runs the encoder backward.
 No CPU fallback: CPU tensors raise.
 """
+import ast
 import ctypes as C
 import math
+import random
 from types import SimpleNamespace
 
+import numpy as np
+import pandas as pd
 import torch
 import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+from . import data as _data
 from .drl_classifier import DrlClassifier as _Base, FusedAdam, H, _Call, _Holder, encoder_config
 
 DEFAULT_OPT = dict(language="en", max_len=128, ec_num_class=1, pair_num_class=1, ec_dim=24, con_dim=384, pair_bow_dim=23771, bert_dim=768,
@@ -47,6 +52,53 @@ def make_opt(**kw):
     d = dict(DEFAULT_OPT)
     d.update(kw)
     return SimpleNamespace(**d)
+
+
+def read_ECPE_data(file_path, test=False, rng=random):
+    """drl_classifier_en.py:748-813: (df[pair, label], docs_pair_size).  Same row order and the same use of random.sample for
+    the training negatives, so `random.seed(42)` (:26) reproduces the reference's rows; test=True keeps every negative."""
+    rows, docs_pair_size = [], []
+    with open(file_path, encoding="utf8") as f:
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            if not _data._DOC_HEADER.search(line):
+                continue
+            doc_len = int(line.strip().split(" ")[1])
+            pos_pairs = [(e, c) for e, c in ast.literal_eval("[" + f.readline().strip() + "]")]      # (:763-765)
+            emotions = list(dict.fromkeys(e for e, _ in pos_pairs))
+            causes = [c for _, c in pos_pairs]
+            non_causes = [i + 1 for i in range(doc_len) if (i + 1) not in causes]
+            neg_pairs = [(e, nc) for e in emotions for nc in non_causes]
+            if not test:                                                                           # (:779-785)
+                neg_pairs = rng.sample(neg_pairs, min(len(pos_pairs), len(neg_pairs)))
+            sentence_list = [f.readline() for _ in range(doc_len)]
+
+            def text(i):
+                return sentence_list[i - 1].strip().split(",")[3].replace(" ", "")
+            for e, c in pos_pairs:
+                rows.append((text(e) + "[SEP]" + text(c), 1))
+            for e, c in neg_pairs:
+                rows.append((text(e) + "[SEP]" + text(c), 0))
+            docs_pair_size.append(len(pos_pairs) + len(neg_pairs))
+    return pd.DataFrame(rows, columns=["pair", "label"]), docs_pair_size
+
+
+class ECPEDataset(_data.ECPEDataset):
+    """drl_classifier_en.py:77-138: the emotion label of every pair is 1 (:82) and is a FloatTensor (:132); everything else as
+    the main script's dataset."""
+
+    def __init__(self, df, tokenizer=None, bow=None, max_len=128, segmenter=None, pretokenize=True):
+        if "emotion" not in df.columns:
+            df = df.assign(emotion=1)
+        super().__init__(df, tokenizer=tokenizer, bow=bow, max_len=max_len, segmenter=segmenter, pretokenize=pretokenize)
+        self.emo_labels = np.ones(len(df), dtype=np.int64)
+
+    def __getitem__(self, index):
+        item = super().__getitem__(index)
+        item["emo_labels"] = torch.FloatTensor([float(self.emo_labels[index])])
+        return item
 
 
 class _EnLosses(torch.autograd.Function):

@@ -125,3 +125,24 @@ def test_batch_loader_equals_stock_dataloader():
             for k in a:
                 assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (k, shuffle)
             assert b["seq_lengths"] == a["attention_masks"].sum(1).tolist()
+
+
+@pytest.mark.parametrize("name", list(GOLD["samples_en_script"]))
+def test_english_script_reader_and_dataset(name):
+    """drl_classifier_en.py's own read_ECPE_data (:748-813: two return values, no emotion column) and dataset (:77-138: the
+    emotion label is the constant 1, as a FloatTensor) -- against the reference function run by gen_golden_data.py."""
+    from carel_vae_amd import drl_classifier_en as ME
+    g = GOLD["samples_en_script"][name]
+    random.seed(42)
+    df, sizes = ME.read_ECPE_data(os.path.join(HERE, "golden", "ecpe", name.split(":")[0]), test=g["test"])
+    assert list(df.columns) == g["columns"] and len(df) == g["rows"] and sizes == g["docs_pair_size"]
+    assert [[p, int(l)] for p, l in zip(df["pair"][:6], df["label"][:6])] == g["head"]
+    h = hashlib.sha1()
+    for p, l in zip(df["pair"], df["label"]):
+        h.update(("%s|%d\n" % (p, int(l))).encode("utf8"))
+    assert h.hexdigest() == g["digest"]
+    ds = ME.ECPEDataset(df, tokenizer=FakeTokenizer(), bow=["the", "letter"], max_len=32, segmenter=char_segmenter)
+    item = ds[0]
+    assert item["emo_labels"].dtype == torch.float32 and float(item["emo_labels"]) == 1.0
+    assert item["labels"].dtype == torch.float32 and item["input_ids"].shape == (32,)
+    assert set(item) == {"input_ids", "attention_masks", "token_type_ids", "labels", "emo_labels", "cau_labels", "bow_reps"}
