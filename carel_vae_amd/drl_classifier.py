@@ -865,6 +865,7 @@ class FusedAdam:
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.step_count = 0
         self._lo, self._hi = (0, model._n_opt) if param_range is None else param_range
+        self._clear_all = params is None      # the single-optimiser scripts: zero_grad() clears every .grad of the model
         if params is None:
             params = model.get_params() if not model._aprx_names else model.get_params()[1]
         self._params = list(params)
@@ -887,8 +888,7 @@ class FusedAdam:
             model._adam_hook = self
 
     def zero_grad(self, set_to_none=True):
-        for p in (self.model._named.values() if self._lo == 0 and self._hi == self.model._n_opt and not hasattr(self.model, "_group_ranges")
-                  else self._params):
+        for p in (self.model._named.values() if self._clear_all else self._params):
             p.grad = None
 
     def _launch(self, lo, hi, stream, with_skip):

@@ -470,10 +470,10 @@ class DrlClassifier(_Base):
             L.check(lib.carel_encoder_forward(C.byref(ea), L.current_stream()), "carel_encoder_forward")
             key = ("en_lat", B)
             buf = self._ws.get(key)
-            if buf is None:
-                buf = SimpleNamespace(pooled=torch.empty(B, H, device=dev), lat=torch.empty(B, LW, device=dev), z=None, terms=None, work=None,
-                                      dx_last=None)
-                buf.z = buf.terms = buf.work = buf.dx_last = SimpleNamespace(data_ptr=lambda: None)
+            if buf is None:       # latents only: the loss-side buffers of carel_en_tail_args stay NULL
+                null = SimpleNamespace(data_ptr=lambda: None)
+                buf = SimpleNamespace(pooled=torch.empty(B, H, device=dev), lat=torch.empty(B, LW, device=dev), z=null, terms=null, work=null,
+                                      dx_last=null)
                 self._ws[key] = buf
             c.buf = buf
             cls_rows = cls.compact if cls is not None else (None if pack is None else pack.cu)
