@@ -38,18 +38,31 @@ __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float ra[SG_NR], rb[SG_NR];
-  auto gload = [&](int k0) {
+  // loop-invariant element offsets; rows past M / N are CLAMPED, not skipped (their products only reach outputs that are never
+  // stored), so the steady-state loads carry no per-element guard -- only the last, partial K step is guarded (zeros matter there).
+  // (With per-element guards the 16 address computations + exec-mask branches took ~0.6 us of issue time per step, in program order
+  // AHEAD of the MFMA chain: the load phase added to the MFMA phase instead of hiding under it.)
+  long offa[SG_NR], offb[SG_NR];
 #pragma unroll
-    for (int i = 0; i < SG_NR; ++i) {
-      const int e = t + i * 256;
-      int m, k;
-      if (TA) { k = e >> 6; m = e & 63; } else { m = e / SG_BK; k = e % SG_BK; }
-      const int gm = m0 + m, gk = k0 + k;
-      ra[i] = (gm < M && gk < ke) ? (TA ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk]) : 0.f;
-      int n, k2;
-      if (TB) { k2 = e >> 6; n = e & 63; } else { n = e / SG_BK; k2 = e % SG_BK; }
-      const int gn = n0 + n, gk2 = k0 + k2;
-      rb[i] = (gn < N && gk2 < ke) ? (TB ? Bm[(long)gk2 * ldb + gn] : Bm[(long)gn * ldb + gk2]) : 0.f;
+  for (int i = 0; i < SG_NR; ++i) {
+    const int e = t + i * 256;
+    if (TA) offa[i] = (long)(e >> 6) * lda + min(m0 + (e & 63), M - 1); else offa[i] = (long)min(m0 + e / SG_BK, M - 1) * lda + e % SG_BK;
+    if (TB) offb[i] = (long)(e >> 6) * ldb + min(n0 + (e & 63), N - 1); else offb[i] = (long)min(n0 + e / SG_BK, N - 1) * ldb + e % SG_BK;
+  }
+  auto gload = [&](int k0) {
+    const float* Ak = A + (TA ? (long)k0 * lda : (long)k0);
+    const float* Bk = Bm + (TB ? (long)k0 * ldb : (long)k0);
+    if (k0 + SG_BK <= ke) {
+#pragma unroll
+      for (int i = 0; i < SG_NR; ++i) { ra[i] = Ak[offa[i]]; rb[i] = Bk[offb[i]]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SG_NR; ++i) {
+        const int e = t + i * 256;
+        const int ka = TA ? (e >> 6) : (e % SG_BK), kb2 = TB ? (e >> 6) : (e % SG_BK);
+        ra[i] = (k0 + ka < ke) ? Ak[offa[i]] : 0.f;
+        rb[i] = (k0 + kb2 < ke) ? Bk[offb[i]] : 0.f;
+      }
     }
   };
   gload(kb);
@@ -62,12 +75,14 @@ __global__ __launch_bounds__(256) void sgemm64_kernel(const float* __restrict__ 
     }
     __syncthreads();
     if (k0 + SG_BK < ke) gload(k0 + SG_BK);
+    float av[SG_BK / 2], bv2[SG_BK / 2];          // all operand reads first, then the MFMAs back to back
 #pragma unroll
     for (int s = 0; s < SG_BK / 2; ++s) {
-      const float a = As[2 * s + (l >> 5)][wm * 32 + (l & 31)];
-      const float b = Bs[2 * s + (l >> 5)][wn * 32 + (l & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      av[s] = As[2 * s + (l >> 5)][wm * 32 + (l & 31)];
+      bv2[s] = Bs[2 * s + (l >> 5)][wn * 32 + (l & 31)];
     }
+#pragma unroll
+    for (int s = 0; s < SG_BK / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv2[s], acc, 0, 0, 0);
     __syncthreads();
   }
   float* Cz = C + (long)blockIdx.z * c_split_stride;
