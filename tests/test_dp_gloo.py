@@ -55,6 +55,14 @@ def _worker(rank, world, port, q):
         both = [torch.empty(96) for _ in range(world)]
         dist.all_gather(both, torch.cat((e1, c1, e2, c2)))
         ok_noise = ok_noise and all(torch.equal(b, both[0]) for b in both) and not torch.equal(e1, e2) and not torch.equal(e1, c1)
+        # the three-sample model draws (con_dim, ec_dim, ec_dim) from the same shared generator; its pair-label sum is one float summed
+        # over ranks (pos_weight of the global batch)
+        n3 = dp.draw_noise_sizes((384, 24, 24), "cpu")
+        three = [torch.empty(432) for _ in range(world)]
+        dist.all_gather(three, torch.cat(n3))
+        ok_noise = ok_noise and [t.numel() for t in n3] == [384, 24, 24] and all(torch.equal(b, three[0]) for b in three)
+        ysum = dp.all_reduce_sum(torch.tensor([float(rank + 2)]))
+        ok_noise = ok_noise and float(ysum) == float(sum(r + 2 for r in range(world)))
         B = 4
         zpack = torch.zeros(B * 48 + 16)
         zpack[:B * 48] = float(rank)
