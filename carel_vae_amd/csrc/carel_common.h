@@ -104,6 +104,36 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return fmaf(x * 0.39894228040143268f, ez, cdf);
 }
 
+// Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per
+// instruction): the same operations in the same order as erf_as / gelu_erf / gelu_erf_grad, so the results are those of the
+// scalar functions; only the reciprocal and the exponential stay one per element.  The GEMM epilogues that evaluate GELU
+// 25 M times per layer are VALU-bound on exactly this arithmetic.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 erf_as2(f32x2 z, f32x2& ez) {
+  const f32x2 az = {fabsf(z.x), fabsf(z.y)};
+  const f32x2 den = pk_fma(pk_splat(0.3275911f), az, pk_splat(1.0f));
+  const f32x2 t = {__frcp_rn(den.x), __frcp_rn(den.y)};
+  const f32x2 m = -az * az;
+  ez = f32x2{__expf(m.x), __expf(m.y)};
+  f32x2 poly = pk_fma(pk_splat(1.061405429f), t, pk_splat(-1.453152027f));
+  poly = pk_fma(poly, t, pk_splat(1.421413741f));
+  poly = pk_fma(poly, t, pk_splat(-0.284496736f));
+  poly = pk_fma(poly, t, pk_splat(0.254829592f));
+  const f32x2 e = pk_splat(1.0f) - poly * t * ez;
+  return f32x2{copysignf(e.x, z.x), copysignf(e.y, z.y)};
+}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  f32x2 ez;
+  return pk_splat(0.5f) * x * (pk_splat(1.0f) + erf_as2(x * pk_splat(0.70710678118654752f), ez));
+}
+__device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {
+  f32x2 ez;
+  const f32x2 cdf = pk_splat(0.5f) * (pk_splat(1.0f) + erf_as2(x * pk_splat(0.70710678118654752f), ez));
+  return pk_fma(x * pk_splat(0.39894228040143268f), ez, cdf);
+}
+
 // =========================================================================================
 // LDS tile images.  Both are written by global_load_lds_dwordx4 (lane-linear 1 KiB per wave
 // instruction), so the XOR swizzle is applied to the per-lane SOURCE address and again on reads.

@@ -124,7 +124,7 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     float u[8];
     unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
 #pragma unroll
-    for (int e = 0; e < 8; ++e) u[e] = gelu_erf(u[e]);
+    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
     *(uint4*)(p.out1 + off) = pack8(u);
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     float u[8];
     unpack8(*(const uint4*)(p.aux + off), u);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(u[e]);
+    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf_grad2(f32x2{u[e], u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
     *(uint4*)(p.out0 + off) = pack8(v);
   } else if (EPI == EPI_ADD_F32) {
     float4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
