@@ -173,14 +173,17 @@ def test_pair_probs_matches_oracle():
     close(prob, ref, 1e-5, 1e-6, "pair prob")
 
 
+@pytest.mark.parametrize("dis", ["hsic", "mmd"])
 @pytest.mark.parametrize("train", [False, True])
-def test_hsic_variant_of_the_tail(train):
-    """Ablation head (config 5): +HSIC(z_e, z_c) instead of -30*MMD and the one-logit BCE emotion head of
-    drl_classifier_ec_hsic.py (:214, :253, :455-470), vs the oracle (whose HSIC is pinned to the reference's values)."""
+def test_hsic_variant_of_the_tail(train, dis):
+    """Ablation heads (config 5) with the one-logit BCE emotion head: +HSIC(z_e, z_c) instead of -30*MMD
+    (drl_classifier_ec_hsic.py :214, :253, :455-470), and the earlier MMD scripts (drl_classifier_ec_mmd.py /
+    drl_classifier_ec_mmd_final.py: the same RBF-MMD term, :211-212 / :235, with that emotion head), vs the oracle (whose
+    HSIC and MMD are pinned to the reference's values)."""
     B, S, V, it, seed = 32, 2, 200, 5, 17
     cfg = O.EncoderConfig(layers=0, vocab_size=50)
     opt = O.Opt(pair_bow_dim=V, e_num_class=1)
-    opt.disentangle, opt.emotion_head = "hsic", "bce"
+    opt.disentangle, opt.emotion_head = dis, "bce"
     P = {k: v for k, v in O.init_params(cfg, opt, seed=3).items() if k in TAIL_KEYS}
     g = torch.Generator().manual_seed(4)
     P["encoder.pooler.dense.weight"] = torch.randn((768, 768), generator=g) * 0.05
@@ -188,7 +191,7 @@ def test_hsic_variant_of_the_tail(train):
     batch = O.synthetic_batch(B, 8, O.EncoderConfig(layers=1, vocab_size=50), V, seed=6)
     batch["emo_labels"] = (batch["emo_labels"] > 2).to(torch.int64)
     eps_e, eps_c = torch.randn(24, generator=g), torch.randn(24, generator=g)
-    out, pooled, grads, dx = oracle_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, it, train, seed, disentangle="hsic", emotion_head="bce")
+    out, pooled, grads, dx = oracle_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, it, train, seed, disentangle=dis, emotion_head="bce")
     buf, G = hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, (opt.dropout if train else 0.0, seed, 0))
     t = buf.terms.cpu().numpy()
     for i, k in ((1, "mmd"), (2, "emo"), (3, "cau"), (4, "pair"), (7, "rec"), (8, "loss")):
