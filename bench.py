@@ -318,9 +318,17 @@ def main():
                     traffic = (float(f[2]) + float(f[3])) * 1e6        # bytes per GEMM launch (fetch x2-corrected + write)
         except OSError:
             pass
+        mfma_util = None
+        try:        # matrix-core occupancy of the same kernels from the committed PMC pass (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles))
+            for line in open(os.path.join(ROOT, "profiles", "r01_g_pmc_mfma_util.csv")):
+                if line.startswith('"ALL carel::gemm_kernel'):
+                    mfma_util = float(line.split(",")[4])
+        except (OSError, ValueError, IndexError):
+            pass
         roof = {"bound": "mfma", "kernel": "carel::gemm_kernel (all instantiations: fwd NT, dgrad NN, wgrad TN)",
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes per launch, HBM/fabric side", "traffic_source": "profiles/r01_f_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE x2 and --pmc WRITE_SIZE, separate passes of the serial dense run; algorithmic operand+output bytes average ~40e6)",
+                "mfma_util_pmc": mfma_util, "mfma_util_source": "profiles/r01_g_pmc_mfma_util.csv (tools/pmc_mfma.sh)",
                 "launches_per_step": n_t / nprof, "avg_launch_us": 1e3 * ms_t / n_t, "alg_gflop_per_launch": fl_t / n_t / 1e9,
                 "gemm_ms_per_step": ms_t / nprof,
                 "note": "per-kernel durations from a serial replay of the step (wgrad_side_stream off); the timed region overlaps them",
