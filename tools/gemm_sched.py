@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Static LDS-DMA schedule of the ping-pong GEMM (carel_vae_amd/csrc/gemm_pp.hip) -- generator AND checker.
+
+The kernel runs 8 waves as two groups of four (group = wave >> 2) that alternate between a "load" segment L(q)
+(fragment ds_reads of phase q, issue of this phase's DMA units, one counted s_waitcnt vmcnt) and a "matrix" segment
+M(q) (12 MFMAs), separated by workgroup barriers; group 1 runs one barrier behind group 0:
+
+    barrier index   ... B(2q-1) |   B(2q)   | B(2q+1) ...
+    group 0             L(q)    |   M(q)    |  L(q+1)
+    group 1             M(q-1)  |   L(q)    |  M(q)
+
+A K tile (64 deep) is NP = 2 * NPN phases: (M half h of each wave's 64 rows) x (B part j of 96 columns), walked in
+serpentine order.  DMA units, all 2 global_load_lds_dwordx4 per wave: A0, A1 (the two M halves, 16 KiB each) and
+B0..B{NPN-1} (12 KiB ROW images / 16 KiB COL images).  S LDS stages (tile t lives in stage t % S).
+
+Rules (MI355X guide, "Read a staged buffer one phase AFTER the wait that retires it"; derived for this barrier
+pattern in DESIGN.md section 4):
+  RAW  a unit first read in phase n must have been waited for (vmcnt) by EVERY wave in L(n-1) or earlier.
+  WAR  a unit may be issued in L(i) only if the previous occupant of its LDS slot was last read in phase <= i-2.
+vmcnt retires in issue order, so "wait for unit X" = s_waitcnt vmcnt(2 * units issued after X so far).
+
+Output: per phase p the units issued (type, tile delta) and the vmcnt immediates for the steady state and for the
+last tiles (R = tiles remaining, counting the current one), plus the prologue issue list.  `check()` replays the
+schedule event by event for many tiles and asserts both rules; tests/test_gemm_sched.py runs it and compares the
+tables with the constexpr copies in gemm_pp.hip.
+"""
+import sys
+
+
+def phases(npn):
+    """serpentine (h, j) order of a K tile"""
+    out = []
+    h = 0
+    for j in range(npn):
+        out.append((h, j))
+        h ^= 1
+        out.append((h, j))
+    return out
+
+
+def unit_span(npn):
+    """unit -> (first phase, last phase) inside a tile"""
+    ph = phases(npn)
+    span = {}
+    for p, (h, j) in enumerate(ph):
+        for u in ("A%d" % h, "B%d" % j):
+            f, l = span.get(u, (p, p))
+            span[u] = (min(f, p), max(l, p))
+    return span
+
+
+def make(npn, stages, max_lead=None):
+    NP = 2 * npn
+    span = unit_span(npn)
+    units = ["A0", "A1"] + ["B%d" % j for j in range(npn)]
+    lead = {}
+    for u in units:
+        first, last = span[u]
+        d = stages * NP - last + first - 2           # WAR: n - d >= (t - S) * NP + last + 2
+        if max_lead is not None:
+            d = min(d, max_lead)
+        if d < 2:
+            raise ValueError("no legal issue phase for %s (npn=%d stages=%d)" % (u, npn, stages))
+        lead[u] = d
+    # issue[p] = [(unit, tile delta)], ordered by need phase
+    issue = [[] for _ in range(NP)]
+    for u in units:
+        first, _ = span[u]
+        i = first - lead[u]                           # relative to tile t's phase 0
+        delta = 0
+        while i < 0:
+            i += NP
+            delta += 1
+        issue[i].append((u, delta, first))
+    for p in range(NP):
+        issue[p].sort(key=lambda x: (x[1] * NP + x[2], x[0]))
+        issue[p] = [(u, d) for (u, d, _) in issue[p]]
+    return dict(npn=npn, stages=stages, NP=NP, span=span, units=units, lead=lead, issue=issue)
+
+
+def program(s, nk):
+    """Event list of ONE wave: ('issue', unit, tile) / ('read', unit, tile, q) / ('wait', q) in program order, with the
+    prologue first.  The prologue issues every (unit, tile) the steady-state schedule would have issued in a phase < 0."""
+    NP = s["NP"]
+    span = s["span"]
+    ev = []
+    pro = []
+    for p in range(NP):
+        for (u, d) in s["issue"][p]:
+            # steady state: phase (t, p) issues (u, t + d).  Tiles t + d with t < 0:
+            for t in range(-d, 0):
+                if 0 <= t + d < nk:
+                    pro.append(((t * NP + p), (t + d) * NP + span[u][0], u, t + d))
+    pro.sort()
+    for (_, _, u, tt) in pro:
+        ev.append(("issue", u, tt))
+    ph = phases(s["npn"])
+    for t in range(nk):
+        for p in range(NP):
+            q = t * NP + p
+            h, j = ph[p]
+            ev.append(("read", "A%d" % h, t, q))
+            ev.append(("read", "B%d" % j, t, q))
+            for (u, d) in s["issue"][p]:
+                if t + d < nk:
+                    ev.append(("issue", u, t + d))
+            ev.append(("wait", q))
+    return ev
+
+
+def wait_counts(s, nk):
+    """vmcnt immediate of every wait: 2 * (units issued after the last unit whose FIRST read is in phase q+1)."""
+    NP = s["NP"]
+    span = s["span"]
+    ev = program(s, nk)
+    issued = []        # program-order list of (unit, tile)
+    waits = {}
+    for e in ev:
+        if e[0] == "issue":
+            issued.append((e[1], e[2]))
+        elif e[0] == "wait":
+            q = e[1]
+            need = [k for k, (u, tt) in enumerate(issued) if tt * NP + span[u][0] == q + 1]
+            if q + 1 >= nk * NP:
+                waits[q] = None
+            elif not need:
+                waits[q] = None
+            else:
+                waits[q] = 2 * (len(issued) - 1 - max(need))
+    return waits
+
+
+def tables(s):
+    """steady-state and tail vmcnt tables: W[R][p], R = 0 steady, 1 = last tile, 2 = second to last ..."""
+    NP = s["NP"]
+    nk = 12
+    w = wait_counts(s, nk)
+    maxd = max(d for p in range(NP) for (_, d) in s["issue"][p]) if any(s["issue"]) else 0
+    tabs = {}
+    t_mid = nk // 2
+    tabs[0] = [w[t_mid * NP + p] for p in range(NP)]
+    for R in range(1, maxd + 2):
+        t = nk - R
+        tabs[R] = [w[t * NP + p] for p in range(NP)]
+    # the steady table must hold for every tile that is not in a tail table
+    for t in range(0, nk - (maxd + 1)):
+        assert [w[t * NP + p] for p in range(NP)] == tabs[0], (t, [w[t * NP + p] for p in range(NP)], tabs[0])
+    return tabs, maxd + 1
+
+
+def check(s, nk):
+    """Replay both groups against the barrier pattern and assert RAW / WAR."""
+    NP = s["NP"]
+    S = s["stages"]
+    span = s["span"]
+    ev = program(s, nk)
+    w = wait_counts(s, nk)
+    # time stamps in half-slots: group g's L(q) lies in barrier interval 2q - 1 + g, M(q) in 2q + g.
+    # "retired[u,t]" = barrier interval after which EVERY wave has waited for it = (2q + 1) with q the wait phase
+    issued = []
+    retired_at = {}         # (unit, tile) -> phase q of the wait that retires it (same for both groups)
+    issue_phase = {}        # (unit, tile) -> phase in whose L segment it is issued (-1 = prologue)
+    cur_q = -1
+    for e in ev:
+        if e[0] == "issue":
+            issued.append((e[1], e[2]))
+            issue_phase[(e[1], e[2])] = cur_q if cur_q >= 0 else -1
+        elif e[0] == "read":
+            cur_q = e[3]
+        elif e[0] == "wait":
+            q = e[1]
+            n = w[q]
+            if n is not None:
+                done = len(issued) - n // 2
+                for k in range(done):
+                    retired_at.setdefault(issued[k], q)
+    last_read = {}
+    for e in ev:
+        if e[0] == "read":
+            _, u, t, q = e
+            key = (u, t)
+            # RAW: retired in a phase <= q - 1 (prologue units of phase 0 are drained by the prologue's vmcnt(0) + barrier)
+            if q == 0:
+                continue
+            assert key in retired_at and retired_at[key] <= q - 1, ("RAW", key, q, retired_at.get(key))
+            last_read[key] = q
+    for e in ev:
+        if e[0] == "read":
+            last_read[(e[1], e[2])] = e[3]
+    for (u, t), i in issue_phase.items():
+        prev = (u, t - S)
+        if prev in last_read:
+            assert i >= last_read[prev] + 2, ("WAR", (u, t), i, last_read[prev])
+    # in-flight bound: vmcnt is a 6-bit counter
+    assert max([x for x in w.values() if x is not None] + [0]) <= 63
+    return True
+
+
+def describe(npn, stages, max_lead=None):
+    s = make(npn, stages, max_lead)
+    for nk in (4, 5, 6, 7, 12, 13, 36, 48):
+        check(s, nk)
+    tabs, ntail = tables(s)
+    return s, tabs, ntail
+
+
+CONFIGS = {1: 3, 2: 2, 3: 2}     # NPN -> LDS stages
+
+
+def emit():
+    out = []
+    for npn, st in CONFIGS.items():
+        s, tabs, ntail = describe(npn, st)
+        out.append("NPN=%d stages=%d phases=%s" % (npn, st, phases(npn)))
+        out.append("  lead   %s" % s["lead"])
+        for p in range(s["NP"]):
+            out.append("  phase %d issue %s" % (p, s["issue"][p]))
+        for R in sorted(tabs):
+            out.append("  vmcnt R=%d %s" % (R, tabs[R]))
+        pro = [e for e in program(s, 12) if e[0] == "issue"]
+        first_read = next(k for k, e in enumerate(program(s, 12)) if e[0] == "read")
+        out.append("  prologue %s" % [(e[1], e[2]) for e in program(s, 12)[:first_read]])
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    print(emit())
