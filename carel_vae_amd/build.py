@@ -23,7 +23,7 @@ def _sources():
 
 
 def _headers_mtime():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(ROOT, "include", "carel_hip.h"))
     return max(os.path.getmtime(h) for h in hs)
 

@@ -12,147 +12,9 @@
 // 2 blocks/CU); images are XOR-swizzled (carel_common.h) so fragment reads are bank-conflict free.
 // The MFMA is issued with the operands swapped (a = B fragment, b = A fragment) so that each lane's 4
 // accumulator registers are 4 CONSECUTIVE columns of one C row -> 8/16-byte epilogue accesses.
-#include "carel_common.h"
-#include "carel_hip_internal.h"
+#include "gemm_epilogue.h"
 
 namespace carel {
-
-enum : int {
-  EPI_BIAS_BF16 = 0,        // out0(bf16) = acc + bias?            (QKV, dgrad of out-proj)
-  EPI_BIAS_GELU = 1,        // out0(bf16) = u = acc+bias ; out1(bf16) = gelu(u)       (FFN1)
-  EPI_BIAS_DROP_RESID = 2,  // outf(f32) = dropout(acc + bias) + resid(f32)           (out-proj, FFN2)
-  EPI_DGELU_BF16 = 3,       // out0(bf16) = acc * gelu'(aux_bf16)                     (dgrad of FFN2)
-  EPI_ADD_F32 = 4,          // outf(f32) = acc + resid(f32)?                          (dgrad of QKV / FFN1)
-  EPI_SLAB_F32 = 5,         // outf[z](f32) = acc                                     (wgrad split-K)
-};
-
-struct GemmParams {
-  const bf16_t* A; const bf16_t* B;
-  long lda, ldb;
-  int M, N, K;              // K = contraction length handled by ONE z-slice
-  bf16_t* out0; bf16_t* out1; float* outf;
-  long ldc;
-  const float* bias;        // [N] or null
-  const float* resid;       // [M,ldc] f32 or null
-  const bf16_t* aux;        // [M,ldc] bf16 (pre-GELU) for EPI_DGELU
-  Dropout drop;
-  int tiles_m, tiles_n;
-  const int* drop_row_map;  // optional [M]: original row of each packed row (dropout element index)
-  float* splitk_ws; size_t splitk_ws_bytes;   // optional workspace enabling the internal split-K path
-  float* colsum_a;          // optional, TN form: [splits][M] sums of A over this K-slice (bias gradient)
-  float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
-  int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
-};
-
-// ---------------------------------------------------------------------------------------------
-// Epilogue for 4 consecutive columns (col..col+3) of C row `row`, accumulator values v.
-// ---------------------------------------------------------------------------------------------
-template <int EPI>
-__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
-  const long off = row * p.ldc + col;
-  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
-    if (p.bias) {
-      const float4 b = *(const float4*)(p.bias + col);
-      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-  }
-  if (EPI == EPI_BIAS_BF16) {
-    uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-    *(uint2*)(p.out0 + off) = o;
-  } else if (EPI == EPI_BIAS_GELU) {
-    uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-    *(uint2*)(p.out0 + off) = o;
-    // GELU is evaluated on the bf16-rounded pre-activation that backward will read back
-    float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
-    uint2 g = {pack2bf(gelu_erf(u0), gelu_erf(u1)), pack2bf(gelu_erf(u2), gelu_erf(u3))};
-    *(uint2*)(p.out1 + off) = g;
-  } else if (EPI == EPI_BIAS_DROP_RESID) {
-    const float4 r = *(const float4*)(p.resid + off);
-    const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
-    float4 o;
-    o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
-    o.y = v[1] * dropout_mult(p.drop, e + 1) + r.y;
-    o.z = v[2] * dropout_mult(p.drop, e + 2) + r.z;
-    o.w = v[3] * dropout_mult(p.drop, e + 3) + r.w;
-    *(float4*)(p.outf + off) = o;
-  } else if (EPI == EPI_DGELU_BF16) {
-    const uint2 a = *(const uint2*)(p.aux + off);
-    const float u0 = bf2f((bf16_t)(a.x & 0xffff)), u1 = bf2f((bf16_t)(a.x >> 16));
-    const float u2 = bf2f((bf16_t)(a.y & 0xffff)), u3 = bf2f((bf16_t)(a.y >> 16));
-    uint2 o = {pack2bf(v[0] * gelu_erf_grad(u0), v[1] * gelu_erf_grad(u1)),
-               pack2bf(v[2] * gelu_erf_grad(u2), v[3] * gelu_erf_grad(u3))};
-    *(uint2*)(p.out0 + off) = o;
-  } else if (EPI == EPI_ADD_F32) {
-    float4 o = {v[0], v[1], v[2], v[3]};
-    if (p.resid) {
-      const float4 r = *(const float4*)(p.resid + off);
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-    }
-    *(float4*)(p.outf + off) = o;
-  } else {  // EPI_SLAB_F32
-    float4 o = {v[0], v[1], v[2], v[3]};
-    *(float4*)(p.outf + (long)blockIdx.z * p.M * p.ldc + off) = o;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Coalesced epilogue: 8 consecutive columns (col..col+7) of C row `row`; v = fp32 accumulators read back
-// from the LDS-staged tile.  8 threads cover 64 columns of one row -> full 128/256-byte lines.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void unpack8(const uint4 a, float* u) {
-  u[0] = bf2f((bf16_t)(a.x & 0xffff)); u[1] = bf2f((bf16_t)(a.x >> 16)); u[2] = bf2f((bf16_t)(a.y & 0xffff)); u[3] = bf2f((bf16_t)(a.y >> 16));
-  u[4] = bf2f((bf16_t)(a.z & 0xffff)); u[5] = bf2f((bf16_t)(a.z >> 16)); u[6] = bf2f((bf16_t)(a.w & 0xffff)); u[7] = bf2f((bf16_t)(a.w >> 16));
-}
-__device__ __forceinline__ uint4 pack8(const float* v) {
-  return uint4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-}
-// after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
-template <int EPI>
-__device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
-  const long off = row * p.ldc + col;
-  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
-    if (p.bias) {
-      const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-  }
-  if (EPI == EPI_BIAS_BF16) {
-    *(uint4*)(p.out0 + off) = pack8(v);
-  } else if (EPI == EPI_BIAS_GELU) {
-    const uint4 o = pack8(v);
-    *(uint4*)(p.out0 + off) = o;
-    float u[8];
-    unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
-    *(uint4*)(p.out1 + off) = pack8(u);
-  } else if (EPI == EPI_BIAS_DROP_RESID) {
-    const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
-    const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
-    float4 o0, o1;
-    o0.x = v[0] * dropout_mult(p.drop, e + 0) + r0.x; o0.y = v[1] * dropout_mult(p.drop, e + 1) + r0.y;
-    o0.z = v[2] * dropout_mult(p.drop, e + 2) + r0.z; o0.w = v[3] * dropout_mult(p.drop, e + 3) + r0.w;
-    o1.x = v[4] * dropout_mult(p.drop, e + 4) + r1.x; o1.y = v[5] * dropout_mult(p.drop, e + 5) + r1.y;
-    o1.z = v[6] * dropout_mult(p.drop, e + 6) + r1.z; o1.w = v[7] * dropout_mult(p.drop, e + 7) + r1.w;
-    *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
-  } else if (EPI == EPI_DGELU_BF16) {
-    float u[8];
-    unpack8(*(const uint4*)(p.aux + off), u);
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf_grad2(f32x2{u[e], u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
-    *(uint4*)(p.out0 + off) = pack8(v);
-  } else if (EPI == EPI_ADD_F32) {
-    float4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-    if (p.resid) {
-      const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
-      o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w; o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
-    }
-    *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
-  } else {  // EPI_SLAB_F32
-    float* o = p.outf + (long)blockIdx.z * p.M * p.ldc + off;
-    *(float4*)o = float4{v[0], v[1], v[2], v[3]}; *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
-  }
-}
 
 // Epilogue of an internally split-K GEMM: v = sum_z slabs[z][row][col..col+7], then the normal fused epilogue.
 template <int EPI>
@@ -556,7 +418,7 @@ static int launch_big(GemmParams p, int splits, hipStream_t s) {
   return check_launch("gemm_kernel_big");
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x96 kernel
+static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x192 kernel, 3 force the ping-pong kernel (NT / NN)
 static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-major chunks (default), 0 = row bands walked M-fastest, 2/4/8 = patches
 
 // Small-M GEMMs (packed ECPE batches: ~1.8 k tokens) launch only 84-170 workgroups of 12-48 K steps each on 256 CUs.
@@ -583,6 +445,11 @@ static bool big_auto(const GemmParams& p, int splits) {
 
 template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
+  if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
+    // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
+    const int npn = gemm_pp_pick(p, BT, EPI, g_gemm_variant == 3);
+    if (npn) return gemm_pp_launch(p, BT, EPI, npn, s);
+  }
   const bool big_ok = (p.M % 256 == 0) && (p.N % 192 == 0);
   const bool v1_ok = (p.M % 128 == 0) && (p.N % 128 == 0);
   // big tile when asked for (variant 2) or, automatically, where it wins: wide outputs / weight gradients with enough
@@ -591,7 +458,8 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (use_big) return launch_big<AT, BT, EPI>(p, splits, s);
   if (!v1_ok) return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: shape fits neither tile (M=%d N=%d)", p.M, p.N);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 19) {   // timing ablations / variants
+#ifdef CAREL_GEMM_ABLATE     // timing ablations (wrong results) are not part of the product library: build with -DCAREL_GEMM_ABLATE
+  if (!AT && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 11 && g_gemm_variant <= 19) {
     if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 1>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 2>), grid, dim3(256), 0, s, p);
     if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 3>), grid, dim3(256), 0, s, p);
@@ -603,6 +471,7 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     if (g_gemm_variant == 19) hipLaunchKernelGGL((gemm_kernel<false, false, EPI_BIAS_BF16, 9>), grid, dim3(256), 0, s, p);
     return check_launch("gemm_kernel<dbg>");
   }
+#endif
   if (EPI != EPI_SLAB_F32 && p.splitk_ws) {
     const int sp = auto_splits(p, p.splitk_ws_bytes);
     if (sp > 1) {
@@ -722,9 +591,10 @@ extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, in
   return CAREL_OK;
 }
 
-static int gemm_shape_ok(int M, int N, int K, int splits) {
+static int gemm_shape_ok(int M, int N, int K, int splits, int form) {
   if (M <= 0 || N <= 0 || K <= 0 || splits <= 0) return 0;
-  if (!((M % 128 == 0 && N % 128 == 0) || (M % 256 == 0 && N % 192 == 0))) return 0;
+  const bool pp = form != CAREL_GEMM_TN && N % 96 == 0 && K >= 256;     // ping-pong kernel: any M (edge rows masked)
+  if (!((M % 128 == 0 && N % 128 == 0) || (M % 256 == 0 && N % 192 == 0) || pp)) return 0;
   if (K % (64 * splits)) return 0;
   return 1;
 }
@@ -741,7 +611,7 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null args");
   const int splits = a->splits > 0 ? a->splits : 1;
-  if (!gemm_shape_ok(a->M, a->N, a->K, splits))
+  if (!gemm_shape_ok(a->M, a->N, a->K, splits, a->form))
     return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: (M,N) must be multiples of (128,128) or (256,192) and K of 64*splits (M=%d N=%d K=%d splits=%d)",
                      a->M, a->N, a->K, splits);
   if (!a->A || !a->B) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null operand");

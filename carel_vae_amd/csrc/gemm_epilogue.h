@@ -1,0 +1,152 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip: 128x128 tile; gemm_pp.hip: 256 x 96n ping-pong tile):
+// the launch parameter block and the fused epilogues.  Replaces nn.Linear forward / backward inside the HF encoder
+// layers (drl_classifier_ec_mmd_final_mul.py:202-206, :841).
+#pragma once
+#include "carel_common.h"
+#include "carel_hip_internal.h"
+
+namespace carel {
+
+enum : int {
+  EPI_BIAS_BF16 = 0,        // out0(bf16) = acc + bias?            (QKV, dgrad of out-proj)
+  EPI_BIAS_GELU = 1,        // out0(bf16) = u = acc+bias ; out1(bf16) = gelu(u)       (FFN1)
+  EPI_BIAS_DROP_RESID = 2,  // outf(f32) = dropout(acc + bias) + resid(f32)           (out-proj, FFN2)
+  EPI_DGELU_BF16 = 3,       // out0(bf16) = acc * gelu'(aux_bf16)                     (dgrad of FFN2)
+  EPI_ADD_F32 = 4,          // outf(f32) = acc + resid(f32)?                          (dgrad of QKV / FFN1)
+  EPI_SLAB_F32 = 5,         // outf[z](f32) = acc                                     (wgrad split-K)
+};
+
+struct GemmParams {
+  const bf16_t* A; const bf16_t* B;
+  long lda, ldb;
+  int M, N, K;              // K = contraction length handled by ONE z-slice
+  bf16_t* out0; bf16_t* out1; float* outf;
+  long ldc;
+  const float* bias;        // [N] or null
+  const float* resid;       // [M,ldc] f32 or null
+  const bf16_t* aux;        // [M,ldc] bf16 (pre-GELU) for EPI_DGELU
+  Dropout drop;
+  int tiles_m, tiles_n;
+  const int* drop_row_map;  // optional [M]: original row of each packed row (dropout element index)
+  float* splitk_ws; size_t splitk_ws_bytes;   // optional workspace enabling the internal split-K path
+  float* colsum_a;          // optional, TN form: [splits][M] sums of A over this K-slice (bias gradient)
+  float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
+  int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
+};
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue for 4 consecutive columns (col..col+3) of C row `row`, accumulator values v.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
+  const long off = row * p.ldc + col;
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
+    if (p.bias) {
+      const float4 b = *(const float4*)(p.bias + col);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+  }
+  if (EPI == EPI_BIAS_BF16) {
+    uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(p.out0 + off) = o;
+  } else if (EPI == EPI_BIAS_GELU) {
+    uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(p.out0 + off) = o;
+    // GELU is evaluated on the bf16-rounded pre-activation that backward will read back
+    float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
+    uint2 g = {pack2bf(gelu_erf(u0), gelu_erf(u1)), pack2bf(gelu_erf(u2), gelu_erf(u3))};
+    *(uint2*)(p.out1 + off) = g;
+  } else if (EPI == EPI_BIAS_DROP_RESID) {
+    const float4 r = *(const float4*)(p.resid + off);
+    const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
+    float4 o;
+    o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
+    o.y = v[1] * dropout_mult(p.drop, e + 1) + r.y;
+    o.z = v[2] * dropout_mult(p.drop, e + 2) + r.z;
+    o.w = v[3] * dropout_mult(p.drop, e + 3) + r.w;
+    *(float4*)(p.outf + off) = o;
+  } else if (EPI == EPI_DGELU_BF16) {
+    const uint2 a = *(const uint2*)(p.aux + off);
+    const float u0 = bf2f((bf16_t)(a.x & 0xffff)), u1 = bf2f((bf16_t)(a.x >> 16));
+    const float u2 = bf2f((bf16_t)(a.y & 0xffff)), u3 = bf2f((bf16_t)(a.y >> 16));
+    uint2 o = {pack2bf(v[0] * gelu_erf_grad(u0), v[1] * gelu_erf_grad(u1)),
+               pack2bf(v[2] * gelu_erf_grad(u2), v[3] * gelu_erf_grad(u3))};
+    *(uint2*)(p.out0 + off) = o;
+  } else if (EPI == EPI_ADD_F32) {
+    float4 o = {v[0], v[1], v[2], v[3]};
+    if (p.resid) {
+      const float4 r = *(const float4*)(p.resid + off);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *(float4*)(p.outf + off) = o;
+  } else {  // EPI_SLAB_F32
+    float4 o = {v[0], v[1], v[2], v[3]};
+    *(float4*)(p.outf + (long)blockIdx.z * p.M * p.ldc + off) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coalesced epilogue: 8 consecutive columns (col..col+7) of C row `row`; v = fp32 accumulators read back
+// from the LDS-staged tile.  8 threads cover 64 columns of one row -> full 128/256-byte lines.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4 a, float* u) {
+  u[0] = bf2f((bf16_t)(a.x & 0xffff)); u[1] = bf2f((bf16_t)(a.x >> 16)); u[2] = bf2f((bf16_t)(a.y & 0xffff)); u[3] = bf2f((bf16_t)(a.y >> 16));
+  u[4] = bf2f((bf16_t)(a.z & 0xffff)); u[5] = bf2f((bf16_t)(a.z >> 16)); u[6] = bf2f((bf16_t)(a.w & 0xffff)); u[7] = bf2f((bf16_t)(a.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  return uint4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+// after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
+  const long off = row * p.ldc + col;
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
+    if (p.bias) {
+      const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+  }
+  if (EPI == EPI_BIAS_BF16) {
+    *(uint4*)(p.out0 + off) = pack8(v);
+  } else if (EPI == EPI_BIAS_GELU) {
+    const uint4 o = pack8(v);
+    *(uint4*)(p.out0 + off) = o;
+    float u[8];
+    unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
+    *(uint4*)(p.out1 + off) = pack8(u);
+  } else if (EPI == EPI_BIAS_DROP_RESID) {
+    const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
+    const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
+    float4 o0, o1;
+    o0.x = v[0] * dropout_mult(p.drop, e + 0) + r0.x; o0.y = v[1] * dropout_mult(p.drop, e + 1) + r0.y;
+    o0.z = v[2] * dropout_mult(p.drop, e + 2) + r0.z; o0.w = v[3] * dropout_mult(p.drop, e + 3) + r0.w;
+    o1.x = v[4] * dropout_mult(p.drop, e + 4) + r1.x; o1.y = v[5] * dropout_mult(p.drop, e + 5) + r1.y;
+    o1.z = v[6] * dropout_mult(p.drop, e + 6) + r1.z; o1.w = v[7] * dropout_mult(p.drop, e + 7) + r1.w;
+    *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
+  } else if (EPI == EPI_DGELU_BF16) {
+    float u[8];
+    unpack8(*(const uint4*)(p.aux + off), u);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf_grad2(f32x2{u[e], u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
+    *(uint4*)(p.out0 + off) = pack8(v);
+  } else if (EPI == EPI_ADD_F32) {
+    float4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+    if (p.resid) {
+      const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
+      o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w; o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+    }
+    *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
+  } else {  // EPI_SLAB_F32
+    float* o = p.outf + (long)blockIdx.z * p.M * p.ldc + off;
+    *(float4*)o = float4{v[0], v[1], v[2], v[3]}; *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
+  }
+}
+
+// gemm_pp.hip: the 256 x (96 * npn) ping-pong kernel for the NT / NN forms.  gemm_pp_pick returns npn (1..3) if the kernel
+// should run this problem, 0 otherwise; force = 1 ignores the "enough tiles to fill the chip" part of the heuristic.
+int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force);
+int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s);
+
+}  // namespace carel

@@ -1,0 +1,330 @@
+// Ping-pong bf16 MFMA GEMM for the row-major-A forms of the encoder linears (forward NT, data gradient NN) of CAREL-VAE:
+// replaces nn.Linear.forward / the dX half of its backward inside HF BertSelfAttention / BertSelfOutput /
+// BertIntermediate / BertOutput (drl_classifier_ec_mmd_final_mul.py:202-206, :841).
+//
+// Why a second kernel: the 128x128 kernel (gemm.hip) stages 64 FLOP per LDS-DMA byte and its main loop runs at the
+// L2->LDS rate of a CU (~65 GB/s, MI355X_MICROARCH.md "Indexed rows"), with one barrier + vmcnt(0) per K step.  Here:
+//   * macro tile 256 x (96 * NPN), NPN = 1..3, one 512-thread workgroup per CU.  96 divides every encoder width
+//     (768 / 2304 / 3072), so at M = 8192 the tile counts are exactly 256 (N = 768 with NPN = 1, N = 2304 with NPN = 3)
+//     or 512 (N = 3072 with NPN = 2): no partial last round on the 256 CUs.  110-135 FLOP per staged byte at NPN 2-3.
+//   * 8 waves = 4 (M) x 2 (N); wave tile 64 x 48*NPN = 2 M-halves x 2 x (3*NPN) MFMA 16x16x32 accumulators.
+//   * the two wave columns are the two PING-PONG GROUPS (waves w and w+4 share a SIMD): group 1 runs one barrier behind
+//     group 0, so while one group issues its 12 MFMAs of a phase the other issues the next phase's fragment reads and
+//     DMA -- the matrix pipe of every SIMD always has one wave feeding it.
+//   * LDS-DMA stays in flight ACROSS the barriers: raw s_barrier, counted s_waitcnt vmcnt(N) from a static schedule
+//     (gemm_pp_sched.inc, generated and hazard-checked by tools/gemm_sched.py; rules in its docstring).  Never vmcnt(0) in
+//     the steady state.
+//   * a K tile (64 deep) = 2*NPN phases (M half) x (B part of 96 columns) in serpentine order, so each phase re-reads only
+//     the operand that changed: 4 (A) or 6 (B) ds_read_b128 per 12 MFMAs.
+//   * epilogue straight from the accumulators: v_permlane16_swap pairs two 16-column fragments so that every lane owns 8
+//     consecutive columns of one row -> 16-byte bf16 stores / 2 x 16-byte f32 accesses, no LDS round trip, no barrier.
+//
+// DMA units (all exactly 2 global_load_lds_dwordx4 per wave, which is what makes the vmcnt immediates static):
+//   A_h   rows {wr*64 + h*32 .. +32 | wr = 0..3} x 64 k   16 KiB of the stage's 256-row ROW image
+//   B_j   NT: 96 weight rows x 64 k = 12 KiB ROW image (second instruction half-populated)
+//         NN: 64 k-rows x 96 columns in a 256-B-pitch COL image = 16 KiB (12 of 16 chunks per row populated)
+//   image row r of B_j <-> tile column (r / 48) * 48*NPN + j*48 + r % 48, i.e. each wave's columns are contiguous.
+#include <utility>
+#include "gemm_epilogue.h"
+
+namespace carel {
+
+#include "gemm_pp_sched.inc"
+
+namespace {
+
+template <int V> struct IC { static constexpr int value = V; };
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int PP_A_BYTES = 32768;
+template <int NPN, bool BT> struct PPGeom {
+  static constexpr int BPART = BT ? 16384 : 12288;
+  static constexpr int STAGE = PP_A_BYTES + NPN * BPART;
+  static constexpr int LDS = PPSched<NPN>::STAGES * STAGE;
+};
+
+template <int NPN, bool BT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+  using S = PPSched<NPN>;
+  using G = PPGeom<NPN, BT>;
+  constexpr int NP = S::NP, ST = S::STAGES;
+  constexpr int BN = 96 * NPN, WN = 48 * NPN, NF = 3 * NPN;
+  constexpr int BPART = G::BPART, STAGE = G::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave & 3, wc = wave >> 2;                     // wc = ping-pong group
+
+  // XCD-aware tile map: blocks with equal bid % 8 share an XCD (round-robin dispatch; speed only); each XCD walks a
+  // contiguous chunk of the row-major tile order (bijective for any tile count)
+  int tm, tn;
+  {
+    const int nwg = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    tm = tid / p.tiles_n; tn = tid - tm * p.tiles_n;
+  }
+  const long m0 = (long)tm * 256, n0 = (long)tn * BN;
+
+  // ---- per-lane DMA source offsets (bytes, constant over K) and wave-uniform LDS destinations ------------------------
+  uint32_t aoff[2][2];                                         // [M half][instruction]
+  int adst[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int piece = wr * 8 + h * 4 + wc * 2 + k;           // 8-row piece of the 256-row image
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (lane >> 3);                  // source chunk = physical chunk ^ (row & 7)
+      long rg = m0 + row; if (rg > (long)p.M - 1) rg = (long)p.M - 1;       // rows past M re-read the last row (never stored)
+      aoff[h][k] = (uint32_t)(((rg - m0) * p.lda + c * 8) * 2);
+      adst[h][k] = piece * 1024;
+    }
+  uint32_t boff[2];
+  int bdst[2];
+  bool bact[2];
+  if (!BT) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int base_row = k == 0 ? wave * 8 : (8 + (wave >> 1)) * 8 + (wave & 1) * 4;
+      const int r = base_row + (lane >> 3);                    // k = 1: lanes 0..31 only (4 rows)
+      const int c = (lane & 7) ^ (r & 7);
+      boff[k] = (uint32_t)((((long)(r / 48) * WN + r % 48) * p.ldb + c * 8) * 2);
+      bdst[k] = base_row * 128;
+      bact[k] = k == 0 || lane < 32;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = wave * 2 + k;                              // 4 k-rows per piece
+      const int r = q * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ swz_col(r);                  // logical 8-column chunk 0..11 (12..15 unused)
+      boff[k] = (uint32_t)(((long)r * p.ldb + (c / 6) * WN + (c % 6) * 8) * 2);
+      bdst[k] = q * 1024;
+      bact[k] = c < 12;
+    }
+  }
+  const char* a_ptr = (const char*)(p.A + m0 * p.lda);         // K tile 0
+  const char* b_ptr = (const char*)(BT ? p.B + n0 : p.B + n0 * p.ldb);
+  const long a_step = 128, b_step = BT ? 64 * p.ldb * 2 : 128;
+  const long b_part_step = BT ? 48 * 2 : 48 * p.ldb * 2;       // part j -> j + 1
+
+  // issue unit `u` (0/1 = A halves, 2+j = B parts) of K tile (t + d) into LDS stage `stg`; ap / bp = pointers of tile t
+  auto issue = [&](auto U, const char* ap, const char* bp, int d, int stg) {
+    constexpr int u = decltype(U)::value;
+    char* sb = smem + stg * STAGE;
+    if constexpr (u < 2) {
+      const char* g = ap + (long)d * a_step;
+      __builtin_amdgcn_global_load_lds((const void*)(g + aoff[u][0]), (CAREL_LDS void*)(sb + adst[u][0]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(g + aoff[u][1]), (CAREL_LDS void*)(sb + adst[u][1]), 16, 0, 0);
+    } else {
+      constexpr int j = u - 2;
+      const char* g = bp + (long)d * b_step + j * b_part_step;
+      char* pb = sb + PP_A_BYTES + j * BPART;
+      if (bact[0]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[0]), (CAREL_LDS void*)(pb + bdst[0]), 16, 0, 0);
+      if (bact[1]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[1]), (CAREL_LDS void*)(pb + bdst[1]), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[2][2][NF];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][2], fb[3][2];                                   // [16-row block][k32 step], [16-column block][k32 step]
+
+  const int nk = p.K >> 6;
+  // ---- prologue: the units the steady-state schedule would have issued before phase 0 ------------------------------
+  static_for<S::NPRO>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    issue(IC<S::pro_unit[i]>{}, a_ptr, b_ptr, S::pro_tile[i], S::pro_tile[i] % ST);
+  });
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::PRO_WAIT) : "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wc == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind group 0
+
+  int sidx = 0;                                                // LDS stage of the current K tile
+  // one K tile; R = 0: steady state, R = r > 0: r tiles remain including this one (tail vmcnt tables, no issue past K)
+  auto tile = [&](auto RR) {
+    constexpr int R = decltype(RR)::value;
+    const char* st = smem + sidx * STAGE;
+    static_for<NP>([&](auto PP) {
+      constexpr int P = decltype(PP)::value;
+      constexpr int h = S::phase_h[P], j = S::phase_j[P];
+      // ---------------- load segment L(P): fragments of this phase, this phase's DMA units, counted wait -------------
+      if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fa[i][ks] = frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
+      }
+      if constexpr (P == 0 || S::phase_j[P] != S::phase_j[P == 0 ? 0 : P - 1]) {
+        const char* pb = st + PP_A_BYTES + j * BPART;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            fb[jj][ks] = BT ? frag16_col(pb, wc * 48 + jj * 16, ks * 32) : frag16_row(pb, wc * 48 + jj * 16, ks * 32);
+      }
+      static_for<S::n_issue[P]>([&](auto E) {
+        constexpr int e = decltype(E)::value;
+        constexpr int u = S::issue_unit[P][e], d = S::issue_delta[P][e];
+        if constexpr (R == 0 || d < R) {
+          int stg = sidx + d;
+          if (stg >= ST) stg -= ST;
+          issue(IC<u>{}, a_ptr, b_ptr, d, stg);
+        }
+      });
+      if constexpr (S::wait[R][P] >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- matrix segment M(P) --------------------------------------------------------------------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) acc[h][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[i][ks], acc[h][i][j * 3 + jj]);   // swapped: D[n][m]
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    a_ptr += a_step; b_ptr += b_step;
+    sidx = sidx + 1 == ST ? 0 : sidx + 1;
+  };
+  for (int t = 0; t < nk - S::NTAIL; ++t) tile(IC<0>{});
+  static_for<S::NTAIL>([&](auto I) { tile(IC<S::NTAIL - decltype(I)::value>{}); });
+  if (wc == 0) __builtin_amdgcn_s_barrier();                   // both groups have now passed the same number of barriers
+
+  // ---- epilogue: accumulators -> fused epilogue, 8 consecutive columns per lane ---------------------------------------
+  const int rho = lane >> 4;
+  float cs[NF / 2 > 0 ? NF / 2 : 1][8];
+#pragma unroll
+  for (int q = 0; q < (NF / 2 > 0 ? NF / 2 : 1); ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[q][e] = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long row = m0 + wr * 64 + h * 32 + i * 16 + (lane & 15);
+      const bool ok = row < (long)p.M;
+#pragma unroll
+      for (int q = 0; q < NF / 2; ++q) {
+        // fragments 2q, 2q+1: after the swaps, 16-lane row rho holds fragment 2q + (rho & 1), columns (rho >> 1) * 8 .. +8
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[h][i][2 * q][e]), __float_as_uint(acc[h][i][2 * q + 1][e]), false, false);
+          v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+        }
+        const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
+        if (ok) {
+          epi_store8<EPI>(p, v, row, col);
+          if (EPI == EPI_DGELU_BF16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
+          }
+        }
+      }
+      if constexpr (NF & 1) {
+        if (ok) epi_store<EPI>(p, acc[h][i][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
+      }
+    }
+  if (EPI == EPI_DGELU_BF16 && p.colsum_part) {                // block-uniform; dispatcher guarantees NF even here
+    // per-128-row column sums of the stored values (the FFN1 bias gradient): 16 lanes -> 1, then wave rows 2r, 2r+1
+    float* sc = (float*)smem;                                  // [4 wave rows][BN]; every LDS read / DMA has retired
+#pragma unroll
+    for (int q = 0; q < NF / 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = cs[q][e];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        if ((lane & 15) == 0) sc[wr * BN + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8 + e] = t;
+      }
+    __syncthreads();
+    for (int x = threadIdx.x; x < 2 * BN; x += 512) {
+      const int half = x / BN, c = x - half * BN;
+      const long prow = (long)tm * 2 + half;
+      if (prow * 128 < (long)p.M) p.colsum_part[prow * p.N + n0 + c] = sc[(2 * half) * BN + c] + sc[(2 * half + 1) * BN + c];
+    }
+  }
+}
+
+template <int NPN, bool BT, int EPI>
+int launch_pp(GemmParams p, hipStream_t s) {
+  using G = PPGeom<NPN, BT>;
+  static bool attr = false;      // per process; setting it again is harmless if two threads race
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = true;
+  }
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, BT, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(512), G::LDS, s, p);
+  return check_launch("gemm_pp_kernel");
+}
+
+template <bool BT, int EPI>
+int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
+  if (npn == 1) return launch_pp<1, BT, EPI>(p, s);
+  if (npn == 2) return launch_pp<2, BT, EPI>(p, s);
+  if constexpr (!BT) { if (npn == 3) return launch_pp<3, BT, EPI>(p, s); }
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch: npn = %d not built for this form", npn);
+}
+
+}  // namespace
+
+// npn (1..3) when the ping-pong kernel should run this GEMM, 0 when it cannot or should not.
+int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
+  if (p.N % 96 || p.K % 64 || p.K < 256 || p.M < 1) return 0;
+  if (bt ? !(epi == EPI_BIAS_BF16 || epi == EPI_DGELU_BF16 || epi == EPI_ADD_F32)
+         : !(epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RESID || epi == EPI_ADD_F32)) return 0;
+  const int tiles_m = (p.M + 255) / 256;
+  int best = 0; double best_score = 0.0;
+  for (int npn = bt ? 2 : 3; npn >= 1; --npn) {
+    if (p.N % (96 * npn)) continue;
+    if (epi == EPI_DGELU_BF16 && p.colsum_part && (npn & 1)) continue;      // the fused column sums need fragment pairs
+    const long tiles = (long)tiles_m * (p.N / (96 * npn));
+    const long rounds = (tiles + 255) / 256;
+    const double fill = (double)tiles / (double)(rounds * 256);           // share of the CU-rounds that do work
+    // staged bytes per FLOP fall with the tile width: (256 + 96 npn) / (256 * 96 npn)
+    const double intensity = (256.0 * 96.0 * npn) / (256.0 + 96.0 * npn);
+    const double score = fill * (intensity < 110.0 ? intensity : 110.0);  // past ~110 FLOP/B the loop is MFMA-bound
+    if (score > best_score) { best_score = score; best = npn; }
+  }
+  if (!best) return 0;
+  if (!force) {
+    const long tiles = (long)tiles_m * (p.N / (96 * best));
+    if (tiles < 192) return 0;                                            // small grids: the 128x128 kernel (+ split-K) fills the chip better
+  }
+  return best;
+}
+
+int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {
+  if (!bt) {
+    switch (epi) {
+      case EPI_BIAS_BF16: return launch_pp_n<false, EPI_BIAS_BF16>(p, npn, s);
+      case EPI_BIAS_GELU: return launch_pp_n<false, EPI_BIAS_GELU>(p, npn, s);
+      case EPI_BIAS_DROP_RESID: return launch_pp_n<false, EPI_BIAS_DROP_RESID>(p, npn, s);
+      case EPI_ADD_F32: return launch_pp_n<false, EPI_ADD_F32>(p, npn, s);
+    }
+  } else {
+    switch (epi) {
+      case EPI_BIAS_BF16: return launch_pp_n<true, EPI_BIAS_BF16>(p, npn, s);
+      case EPI_DGELU_BF16: return launch_pp_n<true, EPI_DGELU_BF16>(p, npn, s);
+      case EPI_ADD_F32: return launch_pp_n<true, EPI_ADD_F32>(p, npn, s);
+    }
+  }
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch: unsupported form/epilogue (%d,%d)", (int)bt, epi);
+}
+
+}  // namespace carel

@@ -1,0 +1,40 @@
+"""The static LDS-DMA schedule of the ping-pong GEMM (carel_vae_amd/csrc/gemm_pp.hip): the generator's own hazard replay
+(RAW: a unit is waited for by every wave one phase before its first read; WAR: a slot is refilled two phases after its
+last read) for many K lengths, the vmcnt tables against an event-by-event recount, and the committed C++ tables against
+the generator (so an edit of either side alone fails here, on CPU)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gemm_sched as G  # noqa: E402
+
+
+def test_schedules_have_no_hazards_and_tables_reproduce_every_wait():
+    for npn, stages in G.CONFIGS.items():
+        s, tabs, ntail = G.describe(npn, stages, G.LEADS[npn])
+        while ntail > 1 and tabs[ntail] == tabs[0]:
+            ntail -= 1
+        NP = s["NP"]
+        pro12 = G.prologue_of(s, 12)
+        for nk in range(2, 64):
+            G.check(s, nk)
+            w = G.wait_counts(s, nk)
+            for t in range(nk):
+                R = nk - t
+                tab = tabs[R] if R <= ntail else tabs[0]
+                assert [w[t * NP + p] for p in range(NP)] == tab, (npn, nk, t)
+            assert G.prologue_of(s, nk) == pro12
+
+
+def test_every_unit_is_two_dma_instructions_and_lds_fits():
+    for npn, stages in G.CONFIGS.items():
+        for bpart in (12288, 16384):
+            if npn == 3 and bpart == 16384:
+                continue                                   # NN form is built for npn 1, 2
+            assert stages * (32768 + npn * bpart) <= 160 * 1024
+
+
+def test_committed_tables_match_generator():
+    inc = os.path.join(ROOT, "carel_vae_amd", "csrc", "gemm_pp_sched.inc")
+    assert open(inc).read() == G.header()

@@ -186,3 +186,91 @@ def test_internal_split_k_with_workspace_matches_single_pass():
     gemm(A2, W2, L.GEMM_NN, L.EPI_ADD_F32, M, N, 2304, out_f32=o1, resid=r)
     gemm(A2, W2, L.GEMM_NN, L.EPI_ADD_F32, M, N, 2304, out_f32=o2, resid=r, splitk_ws=ws)
     assert rel_err(o2, o1) < 1e-6 and rel_err(o2, A2.double() @ W2.double() + r.double()) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ping-pong kernel (gemm_pp.hip: 256 x 96n tiles, two wave groups alternating load / MFMA segments, LDS-DMA in flight
+# across raw barriers behind counted vmcnt waits).  Variant 3 forces it; variant 1 forces the 128x128 kernel.  Both
+# kernels add the K tiles in the same order with the same MFMA, so on shapes both accept they must agree BIT FOR BIT.
+# ---------------------------------------------------------------------------------------------------------------
+class _variant:
+    def __init__(self, v): self.v = v
+    def __enter__(self): L.check(L.load().carel_gemm_set_variant(self.v))
+    def __exit__(self, *a): L.check(L.load().carel_gemm_set_variant(0))
+
+
+def _ints(shape, seed, lo=-3, hi=4):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float().cuda().bfloat16()
+
+
+@pytest.mark.parametrize("form", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (8192, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 2304),
+                                   (256, 96, 256), (2176, 192, 320), (1000, 288, 448), (3000, 576, 1024)])
+def test_pp_exact_integers(form, M, N, K):
+    """Exact small-integer data at the production shapes (M = 8192 x {768, 2304, 3072}) and at ragged M (edge rows are
+    masked) / every npn: any stale LDS tile, wrong fragment map or missed k step shows as an integer difference."""
+    A = _ints((M, K), 1)
+    B = _ints((N, K), 2) if form == "NT" else _ints((K, N), 2)
+    out = torch.full((M + 8, N), 7.0, device="cuda")          # 8 guard rows: nothing past row M may be written
+    with _variant(3):
+        gemm(A, B, L.GEMM_NT if form == "NT" else L.GEMM_NN, L.EPI_ADD_F32, M, N, K, out_f32=out)
+    ref = A.double() @ (B.double().t() if form == "NT" else B.double())
+    assert torch.equal(out[:M].double(), ref), float((out[:M].double() - ref).abs().max())
+    assert torch.equal(out[M:], torch.full((8, N), 7.0, device="cuda"))
+
+
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
+def test_pp_bitwise_equals_128_tile_every_epilogue(N, K):
+    M = 1024
+    A, W, b = _rand((M, K), 1, 41).bfloat16(), _rand((N, K), 0.05, 42).bfloat16(), _rand((N,), 0.1, 43)
+    Wn = _rand((K, N), 0.05, 44).bfloat16()
+    r, u = _rand((M, N), 1, 45), _rand((M, N), 1.5, 46).bfloat16()
+    res = {}
+    for v in (1, 3):
+        with _variant(v):
+            o = {}
+            o["qkv"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_BF16, M, N, K, out_bf16=o["qkv"], bias=b)
+            o["u"], o["g"] = torch.empty_like(o["qkv"]), torch.empty_like(o["qkv"])
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out_bf16=o["u"], out2_bf16=o["g"], bias=b)
+            o["h"] = torch.empty((M, N), device="cuda")
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=o["h"], bias=b, resid=r, drop=(9, 5, 3 * N, 0.1))
+            o["dx"] = torch.empty((M, N), device="cuda")
+            gemm(A, Wn, L.GEMM_NN, L.EPI_ADD_F32, M, N, K, out_f32=o["dx"], resid=r)
+            o["dc"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+            gemm(A, Wn, L.GEMM_NN, L.EPI_BIAS_BF16, M, N, K, out_bf16=o["dc"])
+            if N % 192 == 0:           # the fused column sums pair two 16-column fragments: even npn
+                o["du"], o["cs"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M // 128, N), device="cuda")
+                gemm(A, Wn, L.GEMM_NN, L.EPI_DGELU_BF16, M, N, K, out_bf16=o["du"], aux=u, colsum_part=o["cs"])
+            res[v] = o
+    for k in res[1]:
+        if k == "cs":       # column sums: same addends, different summation tree
+            assert rel_err(res[3][k], res[1][k]) < 1e-5
+        else:
+            assert torch.equal(res[3][k], res[1][k]), (k, float((res[3][k].float() - res[1][k].float()).abs().max()))
+
+
+def test_pp_race_screen_repeated_launches():
+    """20 launches of each production shape on fresh random data, compared with the first launch bit for bit while a
+    second stream keeps the memory system busy (uneven load is what exposes a too-early LDS read)."""
+    M = 8192
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device="cuda")
+    with _variant(3):
+        for (N, K, form) in [(2304, 768, "NT"), (3072, 768, "NT"), (768, 3072, "NT"), (3072, 768, "NN"), (768, 2304, "NN")]:
+            A = _rand((M, K), 1, 51).bfloat16()
+            B = (_rand((N, K), 0.05, 52) if form == "NT" else _rand((K, N), 0.05, 52)).bfloat16()
+            ref = None
+            for it in range(20):
+                if it % 3 == 0:
+                    with torch.cuda.stream(side):
+                        junk.add_(1.0)
+                out = torch.empty((M, N), device="cuda")
+                gemm(A, B, L.GEMM_NT if form == "NT" else L.GEMM_NN, L.EPI_ADD_F32, M, N, K, out_f32=out)
+                if ref is None:
+                    ref = out.clone()
+                    assert rel_err(out, A.double() @ (B.double().t() if form == "NT" else B.double())) < TOL
+                else:
+                    assert torch.equal(out, ref), (N, K, form, it)
+    torch.cuda.synchronize()

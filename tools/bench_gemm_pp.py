@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Encoder GEMM shapes at T = 8192 (random data): the 128x128 kernel (variant 1) vs the ping-pong kernel (variant 3),
+interleaved rounds in one process (median of 5 rounds x 20 launches), plus the vendor BLAS (torch.mm, plain GEMM without
+epilogue) as the reference point.  Measurement only; the product never calls the vendor library."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from carel_vae_amd import _lib as L
+from tests.gpu_util import gemm
+
+lib = L.load()
+T = int(os.environ.get("T", 8192))
+shapes = [("fwd QKV   NT", L.GEMM_NT, L.EPI_BIAS_BF16, T, 2304, 768),
+          ("fwd out   NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, T, 768, 768),
+          ("fwd FFN1  NT", L.GEMM_NT, L.EPI_BIAS_GELU, T, 3072, 768),
+          ("fwd FFN2  NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, T, 768, 3072),
+          ("dgrad FFN2 NN", L.GEMM_NN, L.EPI_DGELU_BF16, T, 3072, 768),
+          ("dgrad FFN1 NN", L.GEMM_NN, L.EPI_ADD_F32, T, 768, 3072),
+          ("dgrad out  NN", L.GEMM_NN, L.EPI_BIAS_BF16, T, 768, 768),
+          ("dgrad QKV  NN", L.GEMM_NN, L.EPI_ADD_F32, T, 768, 2304),
+          ("plain QKV  NT", L.GEMM_NT, L.EPI_ADD_F32, T, 2304, 768)]
+g = torch.Generator().manual_seed(0)
+def rnd(*s): return (torch.randn(s, generator=g) * 0.5).cuda().bfloat16()
+def timed(fn, n=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+tot = {1: 0.0, 3: 0.0, "blas": 0.0}
+for name, form, epi, M, N, K in shapes:
+    A = rnd(M, K)
+    B = rnd(N, K) if form == L.GEMM_NT else rnd(K, N)
+    kw = dict(out_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16), out2_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16),
+              out_f32=torch.empty((M, N), device="cuda"), bias=torch.zeros(N, device="cuda"), resid=torch.zeros((M, N), device="cuda"),
+              aux=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), drop=(1, 2, 0, 0.1))
+    if epi == L.EPI_DGELU_BF16: kw["colsum_part"] = torch.empty((M // 128, N), device="cuda")
+    def run(v):
+        L.check(lib.carel_gemm_set_variant(v))
+        return lambda: gemm(A, B, form, epi, M, N, K, **kw)
+    Bm = B.t() if form == L.GEMM_NT else B
+    fns = {1: run, 3: run}
+    ts = {1: [], 3: [], "blas": []}
+    for rnd_i in range(6):
+        for v in (1, 3):
+            f = run(v); f(); t = timed(f)
+            if rnd_i: ts[v].append(t)
+        f = lambda: torch.mm(A, Bm); f(); t = timed(f)
+        if rnd_i: ts["blas"].append(t)
+    med = {k: statistics.median(v) for k, v in ts.items()}
+    fl = 2.0 * M * N * K
+    for k in tot: tot[k] += med[k]
+    print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp %6.1f us %5.0f TF (min %6.1f) | blas %6.1f us %5.0f TF" % (
+        name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, min(ts[3]), med["blas"], fl / med["blas"] / 1e6), flush=True)
+print("sum: v1 %.1f us  pp %.1f us  blas %.1f us" % (tot[1], tot[3], tot["blas"]))
+L.check(lib.carel_gemm_set_variant(0))

@@ -205,12 +205,56 @@ def describe(npn, stages, max_lead=None):
 
 
 CONFIGS = {1: 3, 2: 2, 3: 2}     # NPN -> LDS stages
+LEADS = {1: 4, 2: 4, 3: 5}       # NPN -> cap on the issue lead in phases (about 3-4 units = 45-60 KiB in flight per CU)
+UNIT_ID = {"A0": 0, "A1": 1, "B0": 2, "B1": 3, "B2": 4}
+
+
+def prologue_of(s, nk=12):
+    ev = program(s, nk)
+    first_read = next(k for k, e in enumerate(ev) if e[0] == "read")
+    pro = [(e[1], e[2]) for e in ev[:first_read]]
+    span = s["span"]
+    need0 = [k for k, (u, t) in enumerate(pro) if t * s["NP"] + span[u][0] == 0]
+    return pro, 2 * (len(pro) - 1 - max(need0))
+
+
+def header():
+    """C++ tables included by carel_vae_amd/csrc/gemm_pp.hip (committed as gemm_pp_sched.inc; test_gemm_sched.py diffs it)"""
+    out = ["// generated by tools/gemm_sched.py (python tools/gemm_sched.py --header) -- do not edit by hand.",
+           "// Units: 0 = A0, 1 = A1, 2 + j = Bj.  wait[R][p]: vmcnt immediate at the end of L(p); R = 0 steady state,",
+           "// R = r: r tiles remain including the current one; -1 = no wait.",
+           "template <int NPN> struct PPSched;"]
+    for npn, st in CONFIGS.items():
+        s, tabs, ntail = describe(npn, st, LEADS[npn])
+        while ntail > 1 and tabs[ntail] == tabs[0]:
+            ntail -= 1
+        NP = s["NP"]
+        maxi = max(1, max(len(x) for x in s["issue"]))
+        pro, pro_wait = prologue_of(s)
+        ph = phases(npn)
+        def arr(rows):
+            return "{" + ", ".join("{" + ", ".join(str(v) for v in r) + "}" for r in rows) + "}"
+        iu = [[UNIT_ID[x[0]] for x in s["issue"][p]] + [-1] * (maxi - len(s["issue"][p])) for p in range(NP)]
+        idl = [[x[1] for x in s["issue"][p]] + [0] * (maxi - len(s["issue"][p])) for p in range(NP)]
+        wt = [[(-1 if v is None else v) for v in tabs[R]] for R in range(ntail + 1)]
+        out += ["template <> struct PPSched<%d> {" % npn,
+                "  static constexpr int NP = %d, STAGES = %d, NTAIL = %d, MAXI = %d, NPRO = %d, PRO_WAIT = %d;" % (NP, st, ntail, maxi, len(pro), pro_wait),
+                "  static constexpr int phase_h[NP] = {%s};" % ", ".join(str(h) for h, _ in ph),
+                "  static constexpr int phase_j[NP] = {%s};" % ", ".join(str(j) for _, j in ph),
+                "  static constexpr int n_issue[NP] = {%s};" % ", ".join(str(len(x)) for x in s["issue"]),
+                "  static constexpr int issue_unit[NP][MAXI] = %s;" % arr(iu),
+                "  static constexpr int issue_delta[NP][MAXI] = %s;" % arr(idl),
+                "  static constexpr int wait[NTAIL + 1][NP] = %s;" % arr(wt),
+                "  static constexpr int pro_unit[NPRO] = {%s};" % ", ".join(str(UNIT_ID[u]) for u, _ in pro),
+                "  static constexpr int pro_tile[NPRO] = {%s};" % ", ".join(str(t) for _, t in pro),
+                "};"]
+    return "\n".join(out) + "\n"
 
 
 def emit():
     out = []
     for npn, st in CONFIGS.items():
-        s, tabs, ntail = describe(npn, st)
+        s, tabs, ntail = describe(npn, st, LEADS[npn])
         out.append("NPN=%d stages=%d phases=%s" % (npn, st, phases(npn)))
         out.append("  lead   %s" % s["lead"])
         for p in range(s["NP"]):
@@ -224,4 +268,7 @@ def emit():
 
 
 if __name__ == "__main__":
-    print(emit())
+    if "--header" in sys.argv:
+        sys.stdout.write(header())
+    else:
+        print(emit())
