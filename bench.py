@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-adam-in-backward", action="store_true",
                     help="run the whole fused Adam in optim.step() instead of layer by layer beside the backward pass")
     ap.add_argument("--no-forward-chains", action="store_true", help="forward pass as one chain (keeps the weight-gradient side stream)")
+    ap.add_argument("--gemm-variant", type=int, action="append", default=[],
+                    help="tuning hook passed to carel_gemm_set_variant before the run (repeatable; 1 = 128x128 kernel only, 5x = ping-pong tile threshold)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="weight-gradient GEMMs on the main stream (serial kernels: the run to put under rocprofv3 --kernel-trace)")
     return ap.parse_args()
@@ -165,6 +167,8 @@ def main():
     from carel_vae_amd import drl_classifier as M
     lib = L.load()
     L.check(lib.carel_init(local_rank), "carel_init")
+    for v in a.gemm_variant:
+        L.check(lib.carel_gemm_set_variant(v), "carel_gemm_set_variant")
     force_dp = os.environ.get("CAREL_FORCE_DP") == "1"      # exercise the RCCL path with a single rank (self-test)
     if world > 1 or force_dp:
         import torch.distributed as dist

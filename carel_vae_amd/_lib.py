@@ -163,6 +163,7 @@ SIGNATURES = {
     "carel_init": (C.c_int, [C.c_int]),
     "carel_last_error": (C.c_char_p, []),
     "carel_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "carel_gemm_wgrad_splits": (C.c_int32, [C.c_int32, C.c_int32, C.c_int64]),
     "carel_gemm_set_variant": (C.c_int, [C.c_int32]),
     "carel_profile_gemm": (C.c_int, [C.c_int32, C.c_int32]),
     "carel_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -22,6 +22,8 @@ int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void*
 
 // split-K heuristics of carel_gemm_bf16: treat the grid as `f` times larger (f equal GEMMs run side by side); gemm.hip
 void gemm_split_tile_factor(int f);
+// largest value carel_gemm_wgrad_splits(M, N, T) can take under any tuning-hook setting (slab buffer sizing); gemm.hip
+int gemm_wgrad_splits_max(int M, int N, long T);
 int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,
                     void* partials, void* row_scratch, hipStream_t stream);
 

@@ -61,17 +61,8 @@ LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
 struct Scratch { char* dy; char* dyb; char* dyb2; char* du; char* dctx; char* dqkv; char* slabs; char* ws; char* part; char* part2; char* part3; };
 struct ScratchLayout { size_t o_dy, o_dyb, o_dyb2, o_du, o_dctx, o_dqkv, o_slabs, o_ws, o_part, o_part2, o_part3, ws_bytes, total; };
 
-// split-K factor of the weight-gradient GEMMs (K = tokens).  Measured at T = 8192 in the whole step with the
-// weight gradients on the side stream: 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 4
-// (stand-alone the FFN shape is faster at 8, 66 vs 82 us, but beside the dgrad chain the CUs are filled anyway and
-// half the slab traffic wins: 10.33 vs 10.58 ms per step).
-int wgrad_splits(long T, int M, int N) {
-  const int tiles = (M / 128) * (N / 128);
-  const int want = tiles < 64 ? 8 : 4;
-  int s = 1;
-  while (s < want && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
-  return s;
-}
+// split-K factor of the weight-gradient GEMMs (K = tokens): chosen by the GEMM library for the kernel it will run
+int wgrad_splits(long T, int M, int N) { return carel_gemm_wgrad_splits(M, N, T); }
 
 ScratchLayout scratch_layout(long B, long S) {
   const size_t T = (size_t)B * S;
@@ -84,7 +75,10 @@ ScratchLayout scratch_layout(long B, long S) {
   s.o_dqkv = o; o += al(T * 3 * EH * 2);
   size_t slab = 0;
   const int shapes[4][2] = {{EH, EI}, {EI, EH}, {EH, EH}, {3 * EH, EH}};
-  for (auto& sh : shapes) { size_t n = (size_t)wgrad_splits((long)T, sh[0], sh[1]) * ((size_t)sh[0] * sh[1] + sh[0]) * 4; slab = n > slab ? n : slab; }
+  for (auto& sh : shapes) {     // sized for the largest split count either GEMM kernel may choose (the tuning hooks can switch kernels later)
+    const size_t n = (size_t)gemm_wgrad_splits_max(sh[0], sh[1], (long)T) * ((size_t)sh[0] * sh[1] + sh[0]) * 4;
+    slab = n > slab ? n : slab;
+  }
   s.o_slabs = o; o += al(slab);             // weight-gradient slabs (side stream when overlapping)
   s.o_ws = o; o += al(slab); s.ws_bytes = al(slab);      // split-K workspace of the forward / data-gradient GEMMs (main stream)
   size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;

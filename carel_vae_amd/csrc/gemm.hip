@@ -436,6 +436,7 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   return s;
 }
 
+static int g_pp_min_tiles = 192; // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles
 static int g_big_auto = 0;       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
 static bool big_auto(const GemmParams& p, int splits) {
   if (!g_big_auto) return false;
@@ -447,7 +448,7 @@ template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
-    const int npn = gemm_pp_pick(p, BT, EPI, g_gemm_variant == 3);
+    const int npn = gemm_pp_pick(p, BT, EPI, g_gemm_variant == 3 ? 1 : -g_pp_min_tiles);
     if (npn) return gemm_pp_launch(p, BT, EPI, npn, s);
   }
   const bool big_ok = (p.M % 256 == 0) && (p.N % 192 == 0);
@@ -593,6 +594,9 @@ extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, in
 
 static int gemm_shape_ok(int M, int N, int K, int splits, int form) {
   if (M <= 0 || N <= 0 || K <= 0 || splits <= 0) return 0;
+  if (form == CAREL_GEMM_TN) {                                          // ping-pong kernel: unequal K slices are fine
+    if (M % 256 == 0 && N % 96 == 0 && K % 64 == 0 && (K >> 6) / splits >= 4) return 1;
+  }
   const bool pp = form != CAREL_GEMM_TN && N % 96 == 0 && K >= 256;     // ping-pong kernel: any M (edge rows masked)
   if (!((M % 128 == 0 && N % 128 == 0) || (M % 256 == 0 && N % 192 == 0) || pp)) return 0;
   if (K % (64 * splits)) return 0;
@@ -602,7 +606,8 @@ static int gemm_shape_ok(int M, int N, int K, int splits, int form) {
 extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
   if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
-  if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }         // automatic use of the 256x192 tile off / on
+  if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }
+  if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }         // automatic use of the 256x192 tile off / on
   g_gemm_variant = v;
   return CAREL_OK;
 }
@@ -658,10 +663,50 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
       case EPI_ADD_F32: return launch<false, true, EPI_ADD_F32>(p, 1, stream);
     }
   } else if (form == CAREL_GEMM_TN) {
-    if (epi == EPI_SLAB_F32) return launch<true, true, EPI_SLAB_F32>(p, splits, stream);
+    if (epi == EPI_SLAB_F32) {
+      if (g_gemm_variant != 1 && g_gemm_variant != 2) {      // ping-pong kernel: K tiles dealt to the slices as evenly as possible
+        GemmParams q = p;
+        q.K = a->K;
+        const int npn = gemm_pp_pick_tn(q, splits);
+        const long wgs = npn ? (long)(q.M / 256) * (q.N / (96 * npn)) * splits : 0;
+        if (npn && (g_gemm_variant == 3 || wgs >= g_pp_min_tiles)) return gemm_pp_launch_tn(q, npn, splits, stream);
+      }
+      if (a->K % (64 * splits) || !((a->M % 128 == 0 && a->N % 128 == 0) || (a->M % 256 == 0 && a->N % 192 == 0)))
+        return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: this (M,N,K,splits) fits neither weight-gradient kernel (M=%d N=%d K=%d splits=%d)", a->M, a->N, a->K, splits);
+      return launch<true, true, EPI_SLAB_F32>(p, splits, stream);
+    }
   }
   return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: unsupported form/epilogue combination (%d,%d)", form, epi);
 }
+
+// Split-K factor for the weight gradient dW[M,N] = dY^T X over T tokens (the slab buffer must hold that many [M][N] planes,
+// plus [splits][M] floats when the bias gradient rides along).  Ping-pong kernel: enough slices to fill the 256 CUs.
+// 128x128 kernel (variant 1, or shapes the ping-pong kernel does not take): measured at T = 8192 in the whole step with
+// the weight gradients on the side stream -- 36 tiles (768x768) -> 8, 108 tiles (2304x768) -> 4, 144 tiles (FFN) -> 4.
+static int wgrad_splits_128(int M, int N, long T) {
+  const int tiles = (M / 128) * (N / 128);
+  const int want = tiles < 64 ? 8 : 4;
+  int s = 1;
+  while (s < want && T % (64L * s * 2) == 0 && T / (s * 2) >= 256) s *= 2;
+  return s;
+}
+extern "C" int32_t carel_gemm_wgrad_splits(int32_t M, int32_t N, int64_t T) {
+  if (g_gemm_variant != 1 && g_gemm_variant != 2) {
+    const int s = gemm_pp_wgrad_splits(M, N, (long)T);
+    if (s > 0) {
+      const int npn = N % 192 == 0 ? 2 : 1;
+      if (g_gemm_variant == 3 || (long)(M / 256) * (N / (96 * npn)) * s >= g_pp_min_tiles) return s;
+    }
+  }
+  return wgrad_splits_128(M, N, (long)T);
+}
+namespace carel {
+// the largest factor carel_gemm_wgrad_splits can return for this shape under ANY tuning-hook setting (buffer sizing)
+int gemm_wgrad_splits_max(int M, int N, long T) {
+  const int a = gemm_pp_wgrad_splits(M, N, T), b = wgrad_splits_128(M, N, T);
+  return a > b ? a : b;
+}
+}  // namespace carel
 
 extern "C" int carel_slab_reduce_f32(const void* slabs, void* out, long n, int splits, int accumulate,
                                      void* stream_) {

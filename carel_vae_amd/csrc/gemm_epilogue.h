@@ -145,8 +145,13 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
 }
 
 // gemm_pp.hip: the 256 x (96 * npn) ping-pong kernel for the NT / NN forms.  gemm_pp_pick returns npn (1..3) if the kernel
-// should run this problem, 0 otherwise; force = 1 ignores the "enough tiles to fill the chip" part of the heuristic.
+// should run this problem, 0 otherwise; force = 1: whenever the shape allows, force = -n: grids of at least n tiles.
 int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force);
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s);
+// weight-gradient form (A^T B into fp32 slabs; p.K = the WHOLE contraction length, dealt to `splits` z slices as evenly
+// as possible -- the slices need not be equal, so any split factor works)
+int gemm_pp_pick_tn(const GemmParams& p, int splits);
+int gemm_pp_wgrad_splits(int M, int N, long K);
+int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
 
 }  // namespace carel

@@ -46,8 +46,9 @@ template <int NPN, bool BT> struct PPGeom {
   static constexpr int LDS = PPSched<NPN>::STAGES * STAGE;
 };
 
-template <int NPN, bool BT, int EPI>
+template <int NPN, bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+  static_assert(!AT || BT, "the A^T form (weight gradient) has both operands K-strided");
   using S = PPSched<NPN>;
   using G = PPGeom<NPN, BT>;
   constexpr int NP = S::NP, ST = S::STAGES;
@@ -76,12 +77,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int piece = wr * 8 + h * 4 + wc * 2 + k;           // 8-row piece of the 256-row image
-      const int row = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ (lane >> 3);                  // source chunk = physical chunk ^ (row & 7)
-      long rg = m0 + row; if (rg > (long)p.M - 1) rg = (long)p.M - 1;       // rows past M re-read the last row (never stored)
-      aoff[h][k] = (uint32_t)(((rg - m0) * p.lda + c * 8) * 2);
-      adst[h][k] = piece * 1024;
+      if (!AT) {                                               // ROW image of 256 rows; half h = rows wr*64 + h*32 .. +32
+        const int piece = wr * 8 + h * 4 + wc * 2 + k;         // 8-row piece
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (lane >> 3);                // source chunk = physical chunk ^ (row & 7)
+        long rg = m0 + row; if (rg > (long)p.M - 1) rg = (long)p.M - 1;     // rows past M re-read the last row (never stored)
+        aoff[h][k] = (uint32_t)(((rg - m0) * p.lda + c * 8) * 2);
+        adst[h][k] = piece * 1024;
+      } else {                                                 // two COL images [64 k][128 m]; half h = image h = m h*128 .. +128
+        const int q = wave * 2 + k;                            // 4 k-rows per piece
+        const int r = q * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ swz_col(r);
+        aoff[h][k] = (uint32_t)(((long)r * p.lda + h * 128 + c * 8) * 2);
+        adst[h][k] = h * 16384 + q * 1024;
+      }
     }
   uint32_t boff[2];
   int bdst[2];
@@ -107,9 +116,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       bact[k] = c < 12;
     }
   }
-  const char* a_ptr = (const char*)(p.A + m0 * p.lda);         // K tile 0
-  const char* b_ptr = (const char*)(BT ? p.B + n0 : p.B + n0 * p.ldb);
-  const long a_step = 128, b_step = BT ? 64 * p.ldb * 2 : 128;
+  // K range of this z slice: the K tiles are dealt to gridDim.z slices as evenly as possible (slices may differ by one)
+  const int nk_all = p.K >> 6;
+  const int kt0 = (int)(((long)blockIdx.z * nk_all) / gridDim.z), kt1 = (int)(((long)(blockIdx.z + 1) * nk_all) / gridDim.z);
+  const int nk = kt1 - kt0;
+  const long a_step = AT ? 64 * p.lda * 2 : 128, b_step = BT ? 64 * p.ldb * 2 : 128;
+  const char* a_ptr = (const char*)(AT ? p.A + m0 : p.A + m0 * p.lda) + kt0 * a_step;      // first K tile of the slice
+  const char* b_ptr = (const char*)(BT ? p.B + n0 : p.B + n0 * p.ldb) + kt0 * b_step;
   const long b_part_step = BT ? 48 * 2 : 48 * p.ldb * 2;       // part j -> j + 1
 
   // issue unit `u` (0/1 = A halves, 2+j = B parts) of K tile (t + d) into LDS stage `stg`; ap / bp = pointers of tile t
@@ -137,8 +150,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa[2][2], fb[3][2];                                   // [16-row block][k32 step], [16-column block][k32 step]
+  // A^T form, first tile column, group 0: sum_k A[k][m] through a ones-vector MFMA -> the bias gradient (colsum_a)
+  const bool do_cs = AT && p.colsum_a != nullptr && tn == 0 && wc == 0;     // wave-uniform
+  f32x4 acc1[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc1[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
-  const int nk = p.K >> 6;
   // ---- prologue: the units the steady-state schedule would have issued before phase 0 ------------------------------
   static_for<S::NPRO>([&](auto I) {
     constexpr int i = decltype(I)::value;
@@ -161,7 +182,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fa[i][ks] = frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
+          for (int ks = 0; ks < 2; ++ks)
+            fa[i][ks] = AT ? frag16_col(st + h * 16384, wr * 32 + i * 16, ks * 32) : frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
       }
       if constexpr (P == 0 || S::phase_j[P] != S::phase_j[P == 0 ? 0 : P - 1]) {
         const char* pb = st + PP_A_BYTES + j * BPART;
@@ -192,6 +214,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) acc[h][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[i][ks], acc[h][i][j * 3 + jj]);   // swapped: D[n][m]
+      if constexpr (AT && j == 0) {
+        if (do_cs) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc1[h][i] = mfma16(ones, fa[i][ks], acc1[h][i]);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -204,6 +234,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   static_for<S::NTAIL>([&](auto I) { tile(IC<S::NTAIL - decltype(I)::value>{}); });
   if (wc == 0) __builtin_amdgcn_s_barrier();                   // both groups have now passed the same number of barriers
 
+  if (AT && do_cs && lane < 16) {                              // D[n][m]: every row n holds the same sum; lane = m
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) p.colsum_a[(long)blockIdx.z * p.M + m0 + h * 128 + wr * 32 + i * 16 + lane] = acc1[h][i][0];
+  }
   // ---- epilogue: accumulators -> fused epilogue, 8 consecutive columns per lane ---------------------------------------
   const int rho = lane >> 4;
   float cs[NF / 2 > 0 ? NF / 2 : 1][8];
@@ -215,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const long row = m0 + wr * 64 + h * 32 + i * 16 + (lane & 15);
+      const long row = m0 + (AT ? h * 128 + wr * 32 : wr * 64 + h * 32) + i * 16 + (lane & 15);
       const bool ok = row < (long)p.M;
 #pragma unroll
       for (int q = 0; q < NF / 2; ++q) {
@@ -259,25 +295,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 }
 
-template <int NPN, bool BT, int EPI>
-int launch_pp(GemmParams p, hipStream_t s) {
+template <int NPN, bool AT, bool BT, int EPI>
+int launch_pp(GemmParams p, int splits, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
   static bool attr = false;      // per process; setting it again is harmless if two threads race
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
-  hipLaunchKernelGGL((gemm_pp_kernel<NPN, BT, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(512), G::LDS, s, p);
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
   return check_launch("gemm_pp_kernel");
 }
 
 template <bool BT, int EPI>
 int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
-  if (npn == 1) return launch_pp<1, BT, EPI>(p, s);
-  if (npn == 2) return launch_pp<2, BT, EPI>(p, s);
-  if constexpr (!BT) { if (npn == 3) return launch_pp<3, BT, EPI>(p, s); }
+  if (npn == 1) return launch_pp<1, false, BT, EPI>(p, 1, s);
+  if (npn == 2) return launch_pp<2, false, BT, EPI>(p, 1, s);
+  if constexpr (!BT) { if (npn == 3) return launch_pp<3, false, BT, EPI>(p, 1, s); }
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch: npn = %d not built for this form", npn);
 }
 
@@ -302,11 +338,49 @@ int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
     if (score > best_score) { best_score = score; best = npn; }
   }
   if (!best) return 0;
-  if (!force) {
+  if (force <= 0) {                                                       // force = -(minimum tile count)
     const long tiles = (long)tiles_m * (p.N / (96 * best));
-    if (tiles < 192) return 0;                                            // small grids: the 128x128 kernel (+ split-K) fills the chip better
+    if (tiles < (long)(-force)) return 0;                                 // small grids: the 128x128 kernel (+ split-K) fills the chip better
   }
   return best;
+}
+
+// Weight-gradient form (A^T B, K = tokens, fp32 slabs): npn for a split-K factor the caller has already fixed; 0 = cannot.
+int gemm_pp_pick_tn(const GemmParams& p, int splits) {
+  if (p.M % 256 || p.N % 96 || p.K % 64 || splits < 1) return 0;
+  const int nk = p.K >> 6;
+  if (nk / splits < 4) return 0;                                          // every slice needs a few K tiles (static schedule)
+  int best = 0; double best_score = 0.0;
+  for (int npn = 2; npn >= 1; --npn) {
+    if (p.N % (96 * npn)) continue;
+    const long wgs = (long)(p.M / 256) * (p.N / (96 * npn)) * splits;
+    const long rounds = (wgs + 255) / 256;
+    const double fill = (double)wgs / (double)(rounds * 256);
+    const double intensity = (256.0 * 96.0 * npn) / (256.0 + 96.0 * npn);
+    const double score = fill * (intensity < 110.0 ? intensity : 110.0);
+    if (score > best_score) { best_score = score; best = npn; }
+  }
+  return best;
+}
+
+// The split-K factor the ping-pong kernel wants for dW[M,N] = A^T B over K tokens: as many slices as keep <= 256
+// workgroups of the wider tile, each with at least 8 K tiles, at most 16 slabs.  0 = shape not supported.
+int gemm_pp_wgrad_splits(int M, int N, long K) {
+  if (M % 256 || N % 96 || K % 64 || K < 512) return 0;
+  const int npn = N % 192 == 0 ? 2 : 1;
+  const long tiles = (long)(M / 256) * (N / (96 * npn));
+  long s = 256 / tiles;
+  const long nk = K >> 6;
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s) {
+  if (npn == 1) return launch_pp<1, true, true, EPI_SLAB_F32>(p, splits, s);
+  if (npn == 2) return launch_pp<2, true, true, EPI_SLAB_F32>(p, splits, s);
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch_tn: npn = %d not built", npn);
 }
 
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {

@@ -9,8 +9,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc / torch tensor.data_ptr()) unless marked "host";
  *   - plain-old-data argument structs, no torch types; row-major tensors;
- *   - every call only ENQUEUES work on `stream` (void* = hipStream_t): no allocation, no host sync, no
- *     global mutable state besides the thread-local error string;
+ *   - every call only ENQUEUES work on `stream` (void* = hipStream_t): no device allocation, no host sync.  Process-wide
+ *     state the library does keep: the thread-local error string; per device, three library-owned streams and ten events
+ *     created on first use (overlap_wgrad / forward chains, see carel_encoder_args); the tuning hooks set through
+ *     carel_gemm_set_variant; the carel_profile_gemm event log.  None of it changes results;
  *   - return 0 on success, a negative CAREL_ERR_* otherwise; carel_last_error() gives the message;
  *   - "bf16" = raw bfloat16 bits (uint16_t); "f32" = IEEE float.
  */
@@ -65,7 +67,8 @@ typedef struct carel_gemm_args {
   const void* A;        /* bf16 */
   const void* B;        /* bf16 */
   int64_t lda, ldb, ldc; /* leading dimensions in elements */
-  int32_t M, N, K;      /* (M,N) multiples of (128,128) or of (256,192); K multiple of 64*splits */
+  int32_t M, N, K;      /* NT / NN: N multiple of 96 (any M; 256 x 96n kernel) or (M,N) multiples of (128,128) / (256,192);
+                           TN: (M,N) multiples of (256,96) or (128,128); K multiple of 64 (of 64*splits for the 128x128 kernel) */
   int32_t form;         /* CAREL_GEMM_* */
   int32_t epilogue;     /* CAREL_EPI_*  */
   int32_t splits;       /* split-K factor (slab epilogue only), else 1 */
@@ -90,8 +93,15 @@ typedef struct carel_gemm_args {
 } carel_gemm_args;
 
 int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
-/* test / tuning hook: 0 = choose the tile automatically, 1 = force 128x128, 2 = force 256x192; 30/31 = automatic use of
- * the 256x192 tile off/on; 20..23 XCD patch layouts; 11..18 timing ablations (wrong results) */
+/* Split-K factor the library wants for the weight gradient dW[M,N] = dY^T X over T tokens (CAREL_GEMM_TN): pass it as
+ * `splits` with an out_f32 of [splits][M][ldc] floats, then carel_slab_reduce_f32.  With the 256 x 96n kernel the T/64
+ * K tiles are dealt to the slices as evenly as possible, so T need not be a multiple of 64 * splits. */
+int32_t carel_gemm_wgrad_splits(int32_t M, int32_t N, int64_t T);
+/* test / tuning hook (process-wide, not thread-safe: set it before any other thread calls the library): 0 = choose the
+ * kernel automatically, 1 = 128x128 kernel only, 2 = force the old 256x192 kernel, 3 = the 256 x 96n ping-pong kernel
+ * wherever the shape allows; 50+k = the ping-pong kernel takes grids of at least 32*k workgroups (default 192);
+ * 30/31 = automatic use of the old 256x192 tile off/on; 20..24 XCD tile layouts of the 128x128 kernel; 11..19 timing
+ * ablations (wrong results; only in a -DCAREL_GEMM_ABLATE build) */
 int carel_gemm_set_variant(int32_t variant);
 /* Measurement aid (bench.py roofline leg): while enabled, every carel_gemm_bf16 launch is bracketed by
  * HIP events on its stream.  carel_profile_gemm_read() synchronises and returns the summed kernel time

@@ -18,7 +18,7 @@ def lib_path():
 def header_functions():
     src = open(os.path.join(ROOT, "include", "carel_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:int|int64_t|void\*|const char\*)\s+(carel_\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:int|int32_t|int64_t|void\*|const char\*)\s+(carel_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 

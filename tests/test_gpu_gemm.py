@@ -274,3 +274,52 @@ def test_pp_race_screen_repeated_launches():
                 else:
                     assert torch.equal(out, ref), (N, K, form, it)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("T,Nout,Nin,splits", [(8192, 768, 3072, 5), (8192, 3072, 768, 5), (8192, 768, 768, 16), (8192, 2304, 768, 7),
+                                              (1920, 768, 768, 3), (1024, 256, 96, 1), (4096, 512, 288, 4)])
+def test_pp_wgrad_exact_integers_uneven_slices(T, Nout, Nin, splits):
+    """A^T B form of the ping-pong kernel (weight gradients): K tiles dealt unevenly to the z slices (T/64 is not a
+    multiple of `splits`), exact integer data, slabs summed against the fp64 product; the bias gradient (column sums
+    of dY per slice, ones-vector MFMA) comes out of the same launch."""
+    dY, X = _ints((T, Nout), 61, -2, 3), _ints((T, Nin), 62, -2, 3)
+    slabs = torch.full((splits, Nout, Nin), float("nan"), device="cuda")
+    cs = torch.full((splits, Nout), float("nan"), device="cuda")
+    with _variant(3):
+        gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, Nout, Nin, T, splits=splits, out_f32=slabs, colsum_a=cs)
+    ref = dY.double().t() @ X.double()
+    assert torch.equal(slabs.double().sum(0), ref), float((slabs.double().sum(0) - ref).abs().max())
+    assert torch.equal(cs.double().sum(0), dY.double().sum(0))
+    # slice z covers K tiles [z*nk/splits, (z+1)*nk/splits)
+    nk = T // 64
+    z = splits - 1
+    k0, k1 = (z * nk // splits) * 64, ((z + 1) * nk // splits) * 64
+    assert torch.equal(slabs[z].double(), dY[k0:k1].double().t() @ X[k0:k1].double())
+
+
+def test_pp_wgrad_equal_slices_bitwise_equal_128_tile():
+    T, Nout, Nin, splits = 4096, 768, 768, 4
+    dY, X = _rand((T, Nout), 1, 63).bfloat16(), _rand((T, Nin), 1, 64).bfloat16()
+    out = {}
+    for v in (1, 3):
+        slabs = torch.empty((splits, Nout, Nin), device="cuda")
+        cs = torch.empty((splits, Nout), device="cuda")
+        with _variant(v):
+            gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, Nout, Nin, T, splits=splits, out_f32=slabs, colsum_a=cs)
+        out[v] = (slabs, cs)
+    assert torch.equal(out[1][0], out[3][0]) and torch.equal(out[1][1], out[3][1])
+
+
+def test_wgrad_splits_helper_matches_what_the_kernels_accept():
+    lib = L.load()
+    for (M, N) in [(768, 3072), (3072, 768), (768, 768), (2304, 768)]:
+        for T in (8192, 4096, 1920, 1024):
+            for v in (0, 1, 3):
+                with _variant(v):
+                    s = lib.carel_gemm_wgrad_splits(M, N, T)
+                    assert 1 <= s <= 16
+                    dY, X = _rand((T, M), 1, 65).bfloat16(), _rand((T, N), 1, 66).bfloat16()
+                    slabs = torch.empty((s, M, N), device="cuda")
+                    gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, M, N, T, splits=s, out_f32=slabs)
+                    if T == 1024 and v != 1:
+                        assert rel_err(slabs.sum(0), dY.double().t() @ X.double()) < TOL

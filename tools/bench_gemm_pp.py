@@ -53,4 +53,25 @@ for name, form, epi, M, N, K in shapes:
     print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp %6.1f us %5.0f TF (min %6.1f) | blas %6.1f us %5.0f TF" % (
         name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, min(ts[3]), med["blas"], fl / med["blas"] / 1e6), flush=True)
 print("sum: v1 %.1f us  pp %.1f us  blas %.1f us" % (tot[1], tot[3], tot["blas"]))
+# weight gradients: GEMM into slabs + the slab reduction, split factor chosen by the library for each kernel
+wt = {1: 0.0, 3: 0.0}
+for name, M, N in [("wgrad FFN2 TN", 768, 3072), ("wgrad FFN1 TN", 3072, 768), ("wgrad out  TN", 768, 768), ("wgrad QKV  TN", 2304, 768)]:
+    A, B = rnd(T, M), rnd(T, N)
+    dW = torch.empty((M, N), device="cuda")
+    res = {}
+    for rnd_i in range(4):
+        for v in (1, 3):
+            L.check(lib.carel_gemm_set_variant(v))
+            sp = lib.carel_gemm_wgrad_splits(M, N, T)
+            slabs = torch.empty((sp, M, N), device="cuda")
+            def f():
+                gemm(A, B, L.GEMM_TN, L.EPI_SLAB_F32, M, N, T, splits=sp, out_f32=slabs)
+                L.check(lib.carel_slab_reduce_f32(slabs.data_ptr(), dW.data_ptr(), M * N, sp, 0, L.current_stream()))
+            f(); t = timed(f)
+            if rnd_i: res.setdefault(v, []).append((t, sp))
+    m1, m3 = statistics.median(x[0] for x in res[1]), statistics.median(x[0] for x in res[3])
+    wt[1] += m1; wt[3] += m3
+    fl = 2.0 * M * N * T
+    print("%-14s M=%5d N=%5d K=%5d | v1/s%d %6.1f us %5.0f TF | pp/s%d %6.1f us %5.0f TF" % (name, M, N, T, res[1][0][1], m1, fl / m1 / 1e6, res[3][0][1], m3, fl / m3 / 1e6), flush=True)
+print("wgrad sum (GEMM + reduce): v1 %.1f us  pp %.1f us" % (wt[1], wt[3]))
 L.check(lib.carel_gemm_set_variant(0))
