@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libcarel_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
-         "-I" + os.path.join(ROOT, "include")]
+         "-I" + os.path.join(ROOT, "include")] + os.environ.get("CAREL_EXTRA_FLAGS", "").split()
 
 
 def _sources():

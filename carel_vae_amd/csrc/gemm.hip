@@ -448,7 +448,10 @@ template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
-    const int npn = gemm_pp_pick(p, BT, EPI, g_gemm_variant == 3 ? 1 : -g_pp_min_tiles);
+    const int npn = gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60) ? 1 : -g_pp_min_tiles);
+#ifdef CAREL_GEMM_ABLATE
+    if (npn && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 61 && g_gemm_variant <= 69) return gemm_pp_launch_dbg(p, npn, g_gemm_variant - 60, s);
+#endif
     if (npn) return gemm_pp_launch(p, BT, EPI, npn, s);
   }
   const bool big_ok = (p.M % 256 == 0) && (p.N % 192 == 0);
@@ -607,7 +610,8 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
   if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
   if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }
-  if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }         // automatic use of the 256x192 tile off / on
+  if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
+  if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }         // automatic use of the 256x192 tile off / on
   g_gemm_variant = v;
   return CAREL_OK;
 }

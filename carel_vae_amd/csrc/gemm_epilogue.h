@@ -96,14 +96,31 @@ __device__ __forceinline__ void unpack8(const uint4 a, float* u) {
 __device__ __forceinline__ uint4 pack8(const float* v) {
   return uint4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
+// The 8-column epilogue in three steps, so that a kernel can issue the loads of the NEXT row block before the stores of
+// the current one (a load's s_waitcnt also waits for every older store: loads queued behind stores serialise the store
+// round trips).  epi_store8 = the three steps back to back; every kernel's results are those of this one code path.
+struct EpiIn8 { float4 r0, r1; uint4 a; };
+template <int EPI>
+__device__ __forceinline__ void epi_bias8(const GemmParams& p, long col, float* b) {
+  if ((EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) && p.bias) {
+    const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
+    b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+  }
+}
+template <int EPI>
+__device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col, EpiIn8& in) {
+  const long off = row * p.ldc + col;
+  if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) { in.r0 = *(const float4*)(p.resid + off); in.r1 = *(const float4*)(p.resid + off + 4); }
+  if (EPI == EPI_DGELU_BF16) in.a = *(const uint4*)(p.aux + off);
+}
 // after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
 template <int EPI>
-__device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
+__device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col) {
   const long off = row * p.ldc + col;
   if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
     if (p.bias) {
-      const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += b[e];
     }
   }
   if (EPI == EPI_BIAS_BF16) {
@@ -117,7 +134,7 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
     *(uint4*)(p.out1 + off) = pack8(u);
   } else if (EPI == EPI_BIAS_DROP_RESID) {
-    const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
+    const float4 r0 = in.r0, r1 = in.r1;
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o0, o1;
     o0.x = v[0] * dropout_mult(p.drop, e + 0) + r0.x; o0.y = v[1] * dropout_mult(p.drop, e + 1) + r0.y;
@@ -127,14 +144,14 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
   } else if (EPI == EPI_DGELU_BF16) {
     float u[8];
-    unpack8(*(const uint4*)(p.aux + off), u);
+    unpack8(in.a, u);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf_grad2(f32x2{u[e], u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
     *(uint4*)(p.out0 + off) = pack8(v);
   } else if (EPI == EPI_ADD_F32) {
     float4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
     if (p.resid) {
-      const float4 r0 = *(const float4*)(p.resid + off), r1 = *(const float4*)(p.resid + off + 4);
+      const float4 r0 = in.r0, r1 = in.r1;
       o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w; o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
     }
     *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
@@ -143,13 +160,25 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
     *(float4*)o = float4{v[0], v[1], v[2], v[3]}; *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
   }
 }
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
+  float b[8];
+  EpiIn8 in;
+  epi_bias8<EPI>(p, col, b);
+  epi_in8<EPI>(p, row, col, in);
+  epi_out8<EPI>(p, v, b, in, row, col);
+}
 
 // gemm_pp.hip: the 256 x (96 * npn) ping-pong kernel for the NT / NN forms.  gemm_pp_pick returns npn (1..3) if the kernel
 // should run this problem, 0 otherwise; force = 1: whenever the shape allows, force = -n: grids of at least n tiles.
 int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force);
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s);
+#ifdef CAREL_GEMM_ABLATE
+int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s);   // timing ablations (wrong results)
+#endif
 // weight-gradient form (A^T B into fp32 slabs; p.K = the WHOLE contraction length, dealt to `splits` z slices as evenly
 // as possible -- the slices need not be equal, so any split factor works)
+void gemm_pp_force_npn(int n);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);

@@ -46,7 +46,9 @@ template <int NPN, bool BT> struct PPGeom {
   static constexpr int LDS = PPSched<NPN>::STAGES * STAGE;
 };
 
-template <int NPN, bool AT, bool BT, int EPI>
+// DBG (timing ablations, results wrong, only instantiated in a -DCAREL_GEMM_ABLATE build): 1 no DMA after the prologue,
+// 2 no MFMA, 3 no fragment reads after the first tile, 4 no epilogue, 5 the half-populated second B instruction dropped
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   static_assert(!AT || BT, "the A^T form (weight gradient) has both operands K-strided");
   using S = PPSched<NPN>;
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 
   // XCD-aware tile map: blocks with equal bid % 8 share an XCD (round-robin dispatch; speed only); each XCD walks a
   // contiguous chunk of the row-major tile order (bijective for any tile count)
+  // One tile per workgroup.  (A persistent loop over tiles was built and measured: the next tile's first counted vmcnt
+  // wait then absorbs the previous tile's store acknowledgements, and those arrive at the HBM write rate -- an XCD's 32 CUs
+  // write more per round than its L2 holds -- so nothing overlapped, and the loop-carried state cost 40-60 VGPRs.)
   int tm, tn;
   {
     const int nwg = p.tiles_m * p.tiles_n, bid = blockIdx.x;
@@ -138,7 +143,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       const char* g = bp + (long)d * b_step + j * b_part_step;
       char* pb = sb + PP_A_BYTES + j * BPART;
       if (bact[0]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[0]), (CAREL_LDS void*)(pb + bdst[0]), 16, 0, 0);
-      if (bact[1]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[1]), (CAREL_LDS void*)(pb + bdst[1]), 16, 0, 0);
+      if (bact[1] && DBG != 5) __builtin_amdgcn_global_load_lds((const void*)(g + boff[1]), (CAREL_LDS void*)(pb + bdst[1]), 16, 0, 0);
+      if (DBG == 5) __builtin_amdgcn_global_load_lds((const void*)(g + boff[0]), (CAREL_LDS void*)(pb + bdst[0]), 16, 0, 0);   // keeps the vmcnt arithmetic
     }
   };
 
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   if (wc == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind group 0
 
   int sidx = 0;                                                // LDS stage of the current K tile
+  bool first_tile = true;                                      // (ablation builds only)
   // one K tile; R = 0: steady state, R = r > 0: r tiles remain including this one (tail vmcnt tables, no issue past K)
   auto tile = [&](auto RR) {
     constexpr int R = decltype(RR)::value;
@@ -178,7 +185,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       constexpr int P = decltype(PP)::value;
       constexpr int h = S::phase_h[P], j = S::phase_j[P];
       // ---------------- load segment L(P): fragments of this phase, this phase's DMA units, counted wait -------------
+      const bool do_reads = DBG != 3 || first_tile;
       if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
+        if (do_reads)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       }
       if constexpr (P == 0 || S::phase_j[P] != S::phase_j[P == 0 ? 0 : P - 1]) {
         const char* pb = st + PP_A_BYTES + j * BPART;
+        if (do_reads)
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
@@ -196,13 +206,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       static_for<S::n_issue[P]>([&](auto E) {
         constexpr int e = decltype(E)::value;
         constexpr int u = S::issue_unit[P][e], d = S::issue_delta[P][e];
-        if constexpr (R == 0 || d < R) {
+        if constexpr ((R == 0 || d < R) && DBG != 1) {
           int stg = sidx + d;
           if (stg >= ST) stg -= ST;
           issue(IC<u>{}, a_ptr, b_ptr, d, stg);
         }
       });
-      if constexpr (S::wait[R][P] >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
+      if constexpr (S::wait[R][P] >= 0 && DBG != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -213,7 +223,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int jj = 0; jj < 3; ++jj) acc[h][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[i][ks], acc[h][i][j * 3 + jj]);   // swapped: D[n][m]
+          for (int jj = 0; jj < 3; ++jj) {
+            if (DBG == 2) asm volatile("" ::"v"(fb[jj][ks]), "v"(fa[i][ks]));
+            else acc[h][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[i][ks], acc[h][i][j * 3 + jj]);   // swapped: D[n][m]
+          }
       if constexpr (AT && j == 0) {
         if (do_cs) {
 #pragma unroll
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     });
     a_ptr += a_step; b_ptr += b_step;
     sidx = sidx + 1 == ST ? 0 : sidx + 1;
+    first_tile = false;
   };
   for (int t = 0; t < nk - S::NTAIL; ++t) tile(IC<0>{});
   static_for<S::NTAIL>([&](auto I) { tile(IC<S::NTAIL - decltype(I)::value>{}); });
@@ -240,41 +254,74 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) p.colsum_a[(long)blockIdx.z * p.M + m0 + h * 128 + wr * 32 + i * 16 + lane] = acc1[h][i][0];
   }
-  // ---- epilogue: accumulators -> fused epilogue, 8 consecutive columns per lane ---------------------------------------
-  const int rho = lane >> 4;
-  float cs[NF / 2 > 0 ? NF / 2 : 1][8];
+  if (DBG == 4) {
 #pragma unroll
-  for (int q = 0; q < (NF / 2 > 0 ? NF / 2 : 1); ++q)
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(acc[h][i][j]));
+    return;
+  }
+  // ---- epilogue: accumulators -> fused epilogue, 8 consecutive columns per lane ---------------------------------------
+  // Row blocks b = (h, i) of 16 rows; the inputs (residual / pre-GELU rows) of block b + 1 are requested before block b is
+  // stored, the bias once per column group up front: no load ever queues behind a store of its own wave (see epi_in8).
+  const int rho = lane >> 4;
+  constexpr int NQ = NF / 2;
+  float cs[NQ > 0 ? NQ : 1][8];
+#pragma unroll
+  for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q)
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[q][e] = 0.f;
+  float bias8[NQ > 0 ? NQ : 1][8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int q = 0; q < NQ; ++q) epi_bias8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, bias8[q]);
+  auto row_of = [&](int b) { return m0 + (AT ? (b >> 1) * 128 + wr * 32 : wr * 64 + (b >> 1) * 32) + (b & 1) * 16 + (lane & 15); };
+  // (npn 3 with a residual / aux input has no registers for two blocks of inputs: load and use block by block there;
+  // the encoder never runs that combination -- N = 2304 is the bias-only QKV projection)
+  constexpr bool PIPE = NPN < 3 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_SLAB_F32;
+  EpiIn8 in[PIPE ? 2 : 1][NQ > 0 ? NQ : 1];
+  auto load_block = [&](int b, EpiIn8* dst) {
+    const long row = row_of(b);
+    if (row < (long)p.M) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long row = m0 + (AT ? h * 128 + wr * 32 : wr * 64 + h * 32) + i * 16 + (lane & 15);
-      const bool ok = row < (long)p.M;
+      for (int q = 0; q < NQ; ++q) epi_in8<EPI>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, dst[q]);
+    }
+  };
+  if (PIPE) load_block(0, in[0]);
 #pragma unroll
-      for (int q = 0; q < NF / 2; ++q) {
-        // fragments 2q, 2q+1: after the swaps, 16-lane row rho holds fragment 2q + (rho & 1), columns (rho >> 1) * 8 .. +8
-        float v[8];
+  for (int b = 0; b < 4; ++b) {
+    if (PIPE) { if (b + 1 < 4) load_block(b + 1, in[(b + 1) & 1]); }
+    else load_block(b, in[0]);
+    const int h = b >> 1, i = b & 1;
+    const long row = row_of(b);
+    const bool ok = row < (long)p.M;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[h][i][2 * q][e]), __float_as_uint(acc[h][i][2 * q + 1][e]), false, false);
-          v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
-        }
-        const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
-        if (ok) {
-          epi_store8<EPI>(p, v, row, col);
-          if (EPI == EPI_DGELU_BF16) {
+    for (int q = 0; q < NQ; ++q) {
+      // fragments 2q, 2q+1: after the swaps, 16-lane row rho holds fragment 2q + (rho & 1), columns (rho >> 1) * 8 .. +8
+      float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[h][i][2 * q][e]), __float_as_uint(acc[h][i][2 * q + 1][e]), false, false);
+        v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
       }
-      if constexpr (NF & 1) {
-        if (ok) epi_store<EPI>(p, acc[h][i][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
+      const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
+      if (ok) {
+        epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col);
+        if (EPI == EPI_DGELU_BF16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
+        }
       }
     }
+  }
+  if constexpr (NF & 1) {      // the odd last fragment: 4 columns per lane, after all paired stores
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const long row = row_of(b);
+      if (row < (long)p.M) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
+    }
+  }
   if (EPI == EPI_DGELU_BF16 && p.colsum_part) {                // block-uniform; dispatcher guarantees NF even here
     // per-128-row column sums of the stored values (the FFN1 bias gradient): 16 lanes -> 1, then wave rows 2r, 2r+1
     float* sc = (float*)smem;                                  // [4 wave rows][BN]; every LDS read / DMA has retired
@@ -286,7 +333,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
         if ((lane & 15) == 0) sc[wr * BN + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8 + e] = t;
       }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // raw barriers: a __syncthreads here would also drain the stores
+    __builtin_amdgcn_s_barrier();
     for (int x = threadIdx.x; x < 2 * BN; x += 512) {
       const int half = x / BN, c = x - half * BN;
       const long prow = (long)tm * 2 + half;
@@ -295,17 +343,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 }
 
-template <int NPN, bool AT, bool BT, int EPI>
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0>
 int launch_pp(GemmParams p, int splits, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
   static bool attr = false;      // per process; setting it again is harmless if two threads race
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
-  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
   return check_launch("gemm_pp_kernel");
 }
 
@@ -319,6 +367,9 @@ int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
 
 }  // namespace
 
+static int g_pp_force_npn = 0;     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
+void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
+
 // npn (1..3) when the ping-pong kernel should run this GEMM, 0 when it cannot or should not.
 int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
   if (p.N % 96 || p.K % 64 || p.K < 256 || p.M < 1) return 0;
@@ -328,6 +379,7 @@ int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
   int best = 0; double best_score = 0.0;
   for (int npn = bt ? 2 : 3; npn >= 1; --npn) {
     if (p.N % (96 * npn)) continue;
+    if (g_pp_force_npn && npn != g_pp_force_npn && p.N % (96 * g_pp_force_npn) == 0 && !(bt && g_pp_force_npn == 3)) continue;
     if (epi == EPI_DGELU_BF16 && p.colsum_part && (npn & 1)) continue;      // the fused column sums need fragment pairs
     const long tiles = (long)tiles_m * (p.N / (96 * npn));
     const long rounds = (tiles + 255) / 256;
@@ -382,6 +434,15 @@ int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s) {
   if (npn == 2) return launch_pp<2, true, true, EPI_SLAB_F32>(p, splits, s);
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_tn: npn = %d not built", npn);
 }
+
+#ifdef CAREL_GEMM_ABLATE
+int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s) {     // NT, bias -> bf16 epilogue only
+#define PPD(N, D) if (npn == N && dbg == D) return launch_pp<N, false, false, EPI_BIAS_BF16, D>(p, 1, s)
+  PPD(3, 1); PPD(3, 2); PPD(3, 3); PPD(3, 4); PPD(3, 5); PPD(1, 1); PPD(1, 2); PPD(1, 3); PPD(1, 4); PPD(1, 5);
+#undef PPD
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch_dbg: (npn, dbg) = (%d, %d) not built", npn, dbg);
+}
+#endif
 
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {
   if (!bt) {

@@ -53,6 +53,21 @@ for name, form, epi, M, N, K in shapes:
     print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp %6.1f us %5.0f TF (min %6.1f) | blas %6.1f us %5.0f TF" % (
         name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, min(ts[3]), med["blas"], fl / med["blas"] / 1e6), flush=True)
 print("sum: v1 %.1f us  pp %.1f us  blas %.1f us" % (tot[1], tot[3], tot["blas"]))
+# tile width experiments: npn forced (variant 70 + n) on the wide GEMMs
+for name, form, epi, M, N, K in [s for s in shapes if s[4] >= 2304]:
+    A = rnd(M, K); B = rnd(N, K) if form == L.GEMM_NT else rnd(K, N)
+    kw = dict(out_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16), out2_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16),
+              out_f32=torch.empty((M, N), device="cuda"), bias=torch.zeros(N, device="cuda"), resid=torch.zeros((M, N), device="cuda"),
+              aux=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), drop=(1, 2, 0, 0.1))
+    L.check(lib.carel_gemm_set_variant(3))
+    r = []
+    for n in (1, 2, 3):
+        L.check(lib.carel_gemm_set_variant(70 + n))
+        f = lambda: gemm(A, B, form, epi, M, N, K, **kw)
+        f(); ts = [timed(f) for _ in range(4)]
+        r.append("npn%d %6.1f us" % (n, statistics.median(ts)))
+    L.check(lib.carel_gemm_set_variant(70))
+    print("%-14s %s" % (name, " | ".join(r)), flush=True)
 # weight gradients: GEMM into slabs + the slab reduction, split factor chosen by the library for each kernel
 wt = {1: 0.0, 3: 0.0}
 for name, M, N in [("wgrad FFN2 TN", 768, 3072), ("wgrad FFN1 TN", 3072, 768), ("wgrad out  TN", 768, 768), ("wgrad QKV  TN", 2304, 768)]:
