@@ -35,6 +35,12 @@ class MmdArgs(C.Structure):
                 ("grad_mmd", C.c_void_p), ("g1", C.c_void_p), ("g2", C.c_void_p)]
 
 
+class PdistArgs(C.Structure):
+    _fields_ = [("s1", C.c_void_p), ("s2", C.c_void_p), ("ld1", C.c_int64), ("ld2", C.c_int64),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("d", C.c_int32), ("eps", C.c_float),
+                ("dist_out", C.c_void_p), ("grad_dist", C.c_void_p), ("g1", C.c_void_p), ("g2", C.c_void_p)]
+
+
 class EmbedArgs(C.Structure):
     _fields_ = [("input_ids", C.c_void_p), ("token_type_ids", C.c_void_p),
                 ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p),
@@ -170,6 +176,8 @@ SIGNATURES = {
     "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
+    "carel_pdist_fwd": (C.c_int, [C.POINTER(PdistArgs), C.c_void_p]),
+    "carel_pdist_bwd": (C.c_int, [C.POINTER(PdistArgs), C.c_void_p]),
     "carel_hsic_fwd": (C.c_int, [C.POINTER(HsicArgs), C.c_void_p]),
     "carel_hsic_bwd": (C.c_int, [C.POINTER(HsicArgs), C.c_void_p]),
     "carel_selftest_layouts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -70,9 +70,73 @@ __global__ __launch_bounds__(1024) void mmd_bwd_kernel(MmdKernelArgs a) {
   }
 }
 
+// ---- pdist (ref :580-589, the live norm = 2 branch): dist[i][j] = sqrt(eps + |n1_i + n2_j - 2 s1_i . s2_j|) ----------------
+// One wave per row i; lane = feature k (d <= 64), so the dot product is one wave reduction per partner j.  A utility of the
+// drop-in surface, not on the training path (the fused tail / MMD kernels never materialise distances).
+struct PdistArgs { const float* s1; const float* s2; long ld1, ld2; int n1, n2, d; float eps; float* out; const float* gout; float* g1; float* g2; };
+
+__global__ __launch_bounds__(64) void pdist_fwd_kernel(PdistArgs a) {
+  const int i = blockIdx.x, k = threadIdx.x;
+  const float x = k < a.d ? a.s1[(long)i * a.ld1 + k] : 0.f;
+  const float nx = wave_sum(x * x);
+  for (int j = 0; j < a.n2; ++j) {
+    const float y = k < a.d ? a.s2[(long)j * a.ld2 + k] : 0.f;
+    const float ny = wave_sum(y * y), dot = wave_sum(x * y);
+    if (k == 0) a.out[(long)i * a.n2 + j] = sqrtf(a.eps + fabsf(nx + ny - 2.0f * dot));
+  }
+}
+// SIDE 0: g1[i][k] = sum_j G_ij sign(d2_ij) (s1_ik - s2_jk) / dist_ij ; SIDE 1: g2[j][k] = -sum_i (same summand)
+template <int SIDE>
+__global__ __launch_bounds__(64) void pdist_bwd_kernel(PdistArgs a) {
+  const int r = blockIdx.x, k = threadIdx.x;
+  const float* mine = SIDE == 0 ? a.s1 + (long)r * a.ld1 : a.s2 + (long)r * a.ld2;
+  const float x = k < a.d ? mine[k] : 0.f;
+  const float nx = wave_sum(x * x);
+  const int nother = SIDE == 0 ? a.n2 : a.n1;
+  float g = 0.f;
+  for (int o = 0; o < nother; ++o) {
+    const float* other = SIDE == 0 ? a.s2 + (long)o * a.ld2 : a.s1 + (long)o * a.ld1;
+    const float y = k < a.d ? other[k] : 0.f;
+    const float ny = wave_sum(y * y), dot = wave_sum(x * y);
+    const float d2 = nx + ny - 2.0f * dot;
+    const float dist = sqrtf(a.eps + fabsf(d2));
+    const float up = SIDE == 0 ? a.gout[(long)r * a.n2 + o] : a.gout[(long)o * a.n2 + r];
+    const float sg = d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f);
+    g = fmaf(up * sg / dist, x - y, g);        // d|d2|/d mine = sign * 2 (mine - other); d sqrt = 1 / (2 dist)
+  }
+  if (k < a.d) (SIDE == 0 ? a.g1 : a.g2)[(long)r * a.d + k] = g;
+}
+
 }  // namespace carel
 
 using namespace carel;
+
+static int pdist_prepare(const carel_pdist_args* a, PdistArgs* k, const char* who) {
+  if (!a || !a->s1 || !a->s2) return set_error(CAREL_ERR_ARG, "%s: null sample pointer", who);
+  if (a->n1 < 1 || a->n2 < 1) return set_error(CAREL_ERR_SHAPE, "%s: empty sample", who);
+  if (a->d < 1 || a->d > 64) return set_error(CAREL_ERR_SHAPE, "%s: d must be in 1..64 (got %d)", who, a->d);
+  k->s1 = (const float*)a->s1; k->s2 = (const float*)a->s2; k->ld1 = a->ld1; k->ld2 = a->ld2;
+  k->n1 = a->n1; k->n2 = a->n2; k->d = a->d; k->eps = a->eps;
+  k->out = (float*)a->dist_out; k->gout = (const float*)a->grad_dist; k->g1 = (float*)a->g1; k->g2 = (float*)a->g2;
+  return CAREL_OK;
+}
+extern "C" int carel_pdist_fwd(const carel_pdist_args* a, void* stream) {
+  PdistArgs k;
+  int rc = pdist_prepare(a, &k, "carel_pdist_fwd");
+  if (rc) return rc;
+  if (!k.out) return set_error(CAREL_ERR_ARG, "carel_pdist_fwd: null dist_out");
+  hipLaunchKernelGGL(pdist_fwd_kernel, dim3(k.n1), dim3(64), 0, (hipStream_t)stream, k);
+  return check_launch("pdist_fwd_kernel");
+}
+extern "C" int carel_pdist_bwd(const carel_pdist_args* a, void* stream) {
+  PdistArgs k;
+  int rc = pdist_prepare(a, &k, "carel_pdist_bwd");
+  if (rc) return rc;
+  if (!k.gout || !k.g1 || !k.g2) return set_error(CAREL_ERR_ARG, "carel_pdist_bwd: null gradient pointer");
+  hipLaunchKernelGGL(pdist_bwd_kernel<0>, dim3(k.n1), dim3(64), 0, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(pdist_bwd_kernel<1>, dim3(k.n2), dim3(64), 0, (hipStream_t)stream, k);
+  return check_launch("pdist_bwd_kernel");
+}
 
 static int mmd_prepare(const carel_mmd_args* a, MmdKernelArgs* k, size_t* lds, const char* who) {
   if (!a || !a->s1 || !a->s2) return set_error(CAREL_ERR_ARG, "%s: null sample pointer", who);

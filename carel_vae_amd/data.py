@@ -296,3 +296,45 @@ class BatchLoader:
                 torch.set_num_threads(nt)
             batch["seq_lengths"] = [self.lengths[i] for i in idx.tolist()]
             yield batch
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic ECPE-shaped batches: the tokenizer vocabulary and the corpus' BoW vocabulary
+# cannot be built offline, so benchmarks and smoke runs draw batches with the measured statistics of
+# data/all_data_pair_zh.txt -- pair-length distribution (mean 26.9 tokens, clipped to [4, S]), label balance 0.5 with at
+# least one positive, the emotion histogram of the train split, 3-12 bag-of-words entries per pair.
+# ----------------------------------------------------------------------------------------------
+EMOTION_HISTOGRAM = np.array([578, 705, 234, 98, 535, 437], dtype=np.float64)      # society_num train split, classes 0..5
+
+
+def synthetic_ecpe_batch(B, S, vocab_size, V, seed=1, shape="A", pad_id=0, first_id=1, binary_emotion=False):
+    """One batch with the keys / dtypes of `ECPEDataset.__getitem__` after collation (ref :136-144).
+    shape "A": every position attended (the dense roofline workload); "B": ECPE-like lengths (~77 % padding).
+    first_id: smallest token id drawn (2 for RoBERTa, whose id 1 is <pad>); binary_emotion: the float 0/1 emotion label of
+    drl_classifier_en.py (:132) instead of the six-way class index."""
+    rs = np.random.RandomState(seed)
+    ids = rs.randint(first_id, vocab_size, size=(B, S)).astype(np.int64)
+    att = np.ones((B, S), dtype=np.int64)
+    if shape == "B":
+        ln = np.clip(np.round(rs.gamma(shape=6.0, scale=26.9 / 6.0, size=B)), 4, S).astype(np.int64)
+        for b in range(B):
+            ids[b, ln[b]:] = pad_id
+            att[b, ln[b]:] = 0
+    tt = np.zeros((B, S), dtype=np.int64)
+    y = (rs.uniform(size=(B, 1)) < 0.5).astype(np.float32)
+    if y.sum() == 0:
+        y[0, 0] = 1.0
+    emo = rs.choice(6, size=(B, 1), p=EMOTION_HISTOGRAM / EMOTION_HISTOGRAM.sum()).astype(np.int64)
+    bow = np.zeros((B, V), dtype=np.float32)
+    for b in range(B):
+        k = rs.randint(3, 13)
+        cols = rs.randint(0, V, size=k)
+        np.add.at(bow[b], cols, 1.0)
+        bow[b] /= max(bow[b].sum(), 1.0)
+    t = torch.from_numpy
+    out = dict(input_ids=t(ids), attention_masks=t(att), token_type_ids=t(tt), labels=t(y), emo_labels=t(emo),
+               cau_labels=t(y.copy()), bow_reps=t(bow))
+    if binary_emotion:
+        rs2 = np.random.RandomState(seed + 7919)
+        out["emo_labels"] = t((rs2.uniform(size=(B, 1)) < 0.5).astype(np.float32))
+    return out

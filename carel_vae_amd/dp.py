@@ -18,33 +18,67 @@ import torch
 import torch.distributed as dist
 
 
-class FlatGradReducer:
-    """Bucketed, asynchronous gradient averaging over named contiguous ranges of one flat tensor.
-    Device-agnostic (gloo on CPU in the tests, RCCL on the GPUs)."""
+class _Pending:
+    """One bucket's collective.  `wait()` is what the consumer of the averaged gradients calls on ITS stream: it makes
+    that stream wait for the collective (RCCL: stream-side; gloo: host-side) and, with a reduced-precision wire format,
+    widens the result back into the fp32 gradient range.  Idempotent."""
 
-    def __init__(self, flat_grad, buckets, group=None):
+    def __init__(self, work, view, wire):
+        self.work, self.view, self.wire, self.done = work, view, wire, False
+
+    def wait(self):
+        if self.done:
+            return
+        self.work.wait()
+        if self.wire is not None:
+            self.view.copy_(self.wire)
+        self.done = True
+
+
+class FlatGradReducer:
+    """Bucketed, asynchronous gradient averaging over named contiguous ranges of one flat fp32 tensor.
+    Device-agnostic (gloo on CPU in the tests, RCCL on the GPUs) and with ONE control flow for both: every bucket is
+    averaged by the collective itself -- RCCL's ReduceOp.AVG, or a pre-division by the world size followed by SUM where the
+    backend has no AVG (gloo) -- so the handle that `reduce` returns is all a consumer has to wait for; there is no
+    host-side post-processing step that only one backend would take.
+    wire_dtype = torch.bfloat16 halves the bytes on the links (207 instead of 414 MB per step for BERT-base; xGMI rings are
+    per-link bound): the bucket is rounded to bf16 once, summed by the collective in bf16, and widened back into the fp32
+    buffer that Adam reads (fp32 master gradients, moments and weights are untouched).  Off by default: it perturbs every
+    gradient by up to 2^-9 relative, which the single-process equality tests of this path would have to absorb, and its
+    benefit can only be measured on a multi-GPU node."""
+
+    def __init__(self, flat_grad, buckets, group=None, wire_dtype=None):
         self.flat, self.buckets, self.group = flat_grad, dict(buckets), group
         self.world = dist.get_world_size(group)
         backend = dist.get_backend(group)
         self.use_avg = backend == "nccl"
+        self.wire_dtype = wire_dtype
+        self._wire = {}            # bucket name -> preallocated wire buffer
         self.pending = []
 
     def reduce(self, name):
-        """Start the all-reduce of one bucket; returns its work handle (None for an empty bucket)."""
+        """Start the averaging all-reduce of one bucket; returns its handle (None for an empty bucket)."""
         lo, hi = self.buckets[name]
         if hi <= lo:
             return None
         view = self.flat[lo:hi]
+        if not self.use_avg:
+            view.mul_(1.0 / self.world)
+        wire = None
+        if self.wire_dtype is not None:
+            wire = self._wire.get(name)
+            if wire is None:
+                wire = self._wire[name] = torch.empty(hi - lo, dtype=self.wire_dtype, device=view.device)
+            wire.copy_(view)
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
-        work = dist.all_reduce(view, op=op, group=self.group, async_op=True)
-        self.pending.append((work, view))
-        return work
+        work = dist.all_reduce(view if wire is None else wire, op=op, group=self.group, async_op=True)
+        pend = _Pending(work, view, wire)
+        self.pending.append(pend)
+        return pend
 
     def wait(self):
-        for work, view in self.pending:
-            work.wait()
-            if not self.use_avg:
-                view.div_(self.world)
+        for pend in self.pending:
+            pend.wait()
         self.pending = []
 
 
@@ -52,7 +86,7 @@ class DataParallel:
     """Attach to a DrlClassifier: `dp = DataParallel(model)`; then train as usual (same forward / backward /
     optimiser calls).  Every rank must call forward with the same local batch size."""
 
-    def __init__(self, model, group=None, global_batch_terms=True):
+    def __init__(self, model, group=None, global_batch_terms=True, wire_dtype=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (init_process_group) before DataParallel")
         self.model, self.group = model, group
@@ -69,7 +103,8 @@ class DataParallel:
         dist.broadcast(seed, src=0, group=group)
         self._noise_seed, self._noise_gen = int(seed.item()), None
         model._shadow_versions = None
-        self.reducer = FlatGradReducer(model._flat_grad, self._buckets(model), group)
+        self.reducer = FlatGradReducer(model._flat_grad, self._buckets(model), group, wire_dtype=wire_dtype)
+        self._gather = None        # the all-gather's receive buffer, allocated once (same size every step)
 
     @staticmethod
     def _buckets(model):
@@ -125,7 +160,9 @@ class DataParallel:
             return
         z, mine = call.buf.z, call.buf.zpack
         n, stride = z.numel(), call.buf.zpack.numel()
-        flat = torch.empty(self.world * stride, device=z.device, dtype=z.dtype)
+        if self._gather is None or self._gather.numel() != self.world * stride or self._gather.device != z.device:
+            self._gather = torch.empty(self.world * stride, device=z.device, dtype=z.dtype)
+        flat = self._gather        # read by this step's loss kernels only; the next step's gather is stream-ordered behind them
         dist.all_gather_into_tensor(flat, mine, group=self.group)
         ta.z_global, ta.global_n, ta.global_rank_stride = flat.data_ptr(), self.world * z.shape[0], stride
         ta.global_row_offset = self.rank * z.shape[0]
@@ -137,10 +174,9 @@ class DataParallel:
         self.reducer.reduce("tail")
 
     def layer_done(self, layer):
-        """-> work handle of the layer's all-reduce when the averaged gradients need no further host-side step (RCCL's
-        AVG), else None (gloo: the division happens in backward_done)."""
-        work = self.reducer.reduce(f"layer{layer}")
-        return work if self.reducer.use_avg else None
+        """-> handle of the layer's averaging all-reduce; `handle.wait()` on a stream is all the consumer (the fused Adam
+        update of that layer) needs before it reads the gradients -- the same under RCCL and gloo."""
+        return self.reducer.reduce(f"layer{layer}")
 
     def backward_done(self):
         self.reducer.reduce("embeddings")

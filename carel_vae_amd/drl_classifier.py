@@ -274,15 +274,29 @@ def permutation_test_mat(*args, **kwargs):  # the reference's stub (:599-600)
     pass
 
 
+class _PdistFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s1, s2, eps):
+        s1c, s2c = s1.contiguous().float(), s2.contiguous().float()
+        ctx.save_for_backward(s1c, s2c)
+        ctx.eps = eps
+        return ops.pdist(s1c, s2c, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        s1, s2 = ctx.saved_tensors
+        g1, g2 = ops.pdist_backward(s1, s2, g, ctx.eps)
+        return g1, g2, None
+
+
 def pdist(sample_1, sample_2, norm=2, eps=1e-5):
-    """Reference `pdist` (:580-596), L2 only (the only live branch): sqrt(eps + |d2|), from the Gram matrix
-    the MMD kernel computes for alpha = 1 (K = exp(-(eps + |d2|)))."""
+    """Reference `pdist` (:580-596), L2 only (the only live branch): sqrt(eps + |d2|) from the squared distance itself
+    (HIP kernel `carel_pdist_fwd`, differentiable) -- no exp / log round trip, so samples that are far apart (d2 > 100,
+    where exp(-d2) underflows in fp32) and samples that nearly coincide both come out to fp32 rounding."""
     if float(norm) != 2.:
         raise NotImplementedError("only norm=2 is on the hot path (:583)")
     ops._chk_cuda(sample_1, sample_2)
-    n1 = sample_1.shape[0]
-    _, kern = ops.rbf_mmd(sample_1.contiguous().float(), sample_2.contiguous().float(), [1.0], eps=eps, ret_matrix=True)
-    return torch.sqrt(-torch.log(kern[:n1, n1:]))
+    return _PdistFn.apply(sample_1, sample_2, float(eps))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -64,6 +64,37 @@ def rbf_mmd_backward(s1, s2, alphas, grad, eps=1e-5):
     return g1, g2
 
 
+def _pdist_args(s1, s2, eps):
+    if s1.dtype != torch.float32 or s2.dtype != torch.float32:
+        raise L.CarelError("pdist: float32 samples required")
+    if s1.stride(1) != 1 or s2.stride(1) != 1 or s1.shape[1] != s2.shape[1]:
+        raise L.CarelError("pdist: samples must share the feature width and be contiguous along it")
+    a = L.PdistArgs()
+    a.s1, a.s2, a.ld1, a.ld2 = s1.data_ptr(), s2.data_ptr(), s1.stride(0), s2.stride(0)
+    a.n1, a.n2, a.d, a.eps = s1.shape[0], s2.shape[0], s1.shape[1], eps
+    return a
+
+
+def pdist(s1, s2, eps=1e-5):
+    """ref :580-589 (norm = 2): [n1, n2] distances."""
+    _chk_cuda(s1, s2)
+    a = _pdist_args(s1, s2, eps)
+    out = torch.empty((s1.shape[0], s2.shape[0]), device=s1.device, dtype=torch.float32)
+    a.dist_out = out.data_ptr()
+    L.check(L.load().carel_pdist_fwd(C.byref(a), L.current_stream()), "carel_pdist_fwd")
+    return out
+
+
+def pdist_backward(s1, s2, grad, eps=1e-5):
+    a = _pdist_args(s1, s2, eps)
+    grad = grad.to(torch.float32).contiguous()
+    g1 = torch.empty((s1.shape[0], s1.shape[1]), device=s1.device, dtype=torch.float32)
+    g2 = torch.empty((s2.shape[0], s2.shape[1]), device=s1.device, dtype=torch.float32)
+    a.grad_dist, a.g1, a.g2 = grad.data_ptr(), g1.data_ptr(), g2.data_ptr()
+    L.check(L.load().carel_pdist_bwd(C.byref(a), L.current_stream()), "carel_pdist_bwd")
+    return g1, g2
+
+
 def _mmd_args(s1, s2, alphas, eps):
     if s1.dtype != torch.float32 or s2.dtype != torch.float32:
         raise L.CarelError("rbf_mmd: float32 samples required")

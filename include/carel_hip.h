@@ -398,6 +398,23 @@ typedef struct carel_mmd_args {
 int carel_rbf_mmd_fwd(const carel_mmd_args* args, void* stream);
 int carel_rbf_mmd_bwd(const carel_mmd_args* args, void* stream);
 
+/* Replaces `pdist(sample_1, sample_2, norm=2, eps)` (ref :580-589, the live L2 branch) and its autograd backward:
+ * dist[i][j] = sqrt(eps + |  |s1_i|^2 + |s2_j|^2 - 2 s1_i . s2_j  |), computed from the squared distance itself (no
+ * exp / log round trip), so far-apart samples (d2 >> 100) and near-coincident ones are both exact to fp32 rounding. */
+typedef struct carel_pdist_args {
+  const void* s1;       /* f32 [n1, d], row stride ld1 */
+  const void* s2;       /* f32 [n2, d], row stride ld2 */
+  int64_t ld1, ld2;
+  int32_t n1, n2, d;    /* d <= 64 */
+  float eps;            /* 1e-5 in the reference */
+  void* dist_out;       /* fwd: f32 [n1, n2] */
+  const void* grad_dist;/* bwd: f32 [n1, n2] upstream gradient */
+  void* g1;             /* bwd: f32 [n1, d] contiguous */
+  void* g2;             /* bwd: f32 [n2, d] contiguous */
+} carel_pdist_args;
+int carel_pdist_fwd(const carel_pdist_args* args, void* stream);
+int carel_pdist_bwd(const carel_pdist_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * HSIC statistic (ablation head).  Replaces HSIC / GaussianKernelMatrix / pairwise_distances of
  * drl_classifier_ec_hsic.py:529-547 and their backward: tr(L H K H)/(m-1)^2, K = exp(-D(x)/s_x),

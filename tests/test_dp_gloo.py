@@ -77,8 +77,24 @@ def _worker(rank, world, port, q):
                      and bool((gathered[0, :B * 48] == 0).all()) and bool((gathered[1, :B * 48] == 1).all())
                      and float(gathered[0, B * 48]) == B and float(gathered[1, B * 48]) == 0.0
                      and ta.z_global == gathered.data_ptr())
-        dp.tail_done(); dp.layer_done(1); dp.layer_done(0); dp.backward_done()
-        ok_avg = bool(torch.allclose(model._flat_grad, torch.full((total,), (1.0 + 2.0) / 2)))
+        g1 = dp._gather
+        dp.fill_global(ta, call)
+        ok_global = ok_global and dp._gather is g1 and ta.z_global == g1.data_ptr()        # receive buffer allocated once
+        dp.tail_done()
+        h1 = dp.layer_done(1)
+        # the handle is all a consumer waits for (what FusedAdam._layer_ready does on its stream): averaged, no later step
+        h1.wait()
+        lo1, hi1 = dp.reducer.buckets["layer1"]
+        ok_avg = h1 is not None and bool(torch.allclose(model._flat_grad[lo1:hi1], torch.full((hi1 - lo1,), 1.5)))
+        h0 = dp.layer_done(0)
+        dp.backward_done()
+        ok_avg = ok_avg and h0.done and bool(torch.allclose(model._flat_grad, torch.full((total,), (1.0 + 2.0) / 2)))
+        # reduced-precision wire format: bf16 on the wire, fp32 result, within bf16 rounding of the exact average
+        flat2 = (torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1)
+        red2 = FlatGradReducer(flat2, {"all": (0, 1000)}, wire_dtype=torch.bfloat16)
+        red2.reduce("all"); red2.wait()
+        exact = (torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0) * (sum(range(1, world + 1)) / world)
+        ok_avg = ok_avg and flat2.dtype == torch.float32 and bool(((flat2 - exact).abs() <= exact.abs() * 2 ** -7).all())
         ok_rows = dp.row_offset(B) == rank * B
         q.put((rank, ok_reduce, ok_bcast, ok_buckets, ok_noise, ok_global, ok_avg, ok_rows))
     finally:

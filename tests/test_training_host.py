@@ -1,6 +1,7 @@
 """Control flow of the reference's training driver (train / generate_self_train_data / save_ckp / load_ckp)
 with a stand-in model on CPU (the numeric step itself is covered by the -m gpu tests)."""
 import os
+import sys
 import random
 
 import pandas as pd
@@ -139,3 +140,30 @@ def test_train_loop_english_six_optimisers(tmp_path):
     g = model.d[1].grad.clone()
     z = model.w.detach()[:2] + 1.0
     assert g.abs().sum() > 0 and torch.isfinite(g).all() and z.numel() == 2
+
+
+def test_bench_launches_its_own_ranks_and_checks_the_count(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must start N rank processes as a child (before any GPU call),
+    relay rank 0's JSON line and fail unless exactly N ranks reported (it used to run one GPU and say so)."""
+    import importlib
+    import json
+    import subprocess
+    import types
+    import pytest
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, stdout=None, text=None):
+        seen["cmd"] = cmd
+        return types.SimpleNamespace(returncode=0, stdout="RCCL banner\n" + json.dumps({"metric": "clause-pairs/sec (training step)", "n_gpus": seen["n"]}) + "\n")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    a = types.SimpleNamespace(gpus=4)
+    seen["n"] = 4
+    bench.launch_ranks(a)
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    seen["n"] = 1                                    # a run that silently used one GPU is an error, not a result
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(a)

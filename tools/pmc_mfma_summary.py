@@ -28,7 +28,7 @@ for k, c in tot.items():
 rows.sort(key=lambda r: -r[8])
 for r in rows:
     print('"%s",%d,%.0f,%.0f,%.4f,%.3f,%.3f,%.3f' % r[:8])
-g = [r for r in rows if "gemm_kernel" in r[0]]
+g = [r for r in rows if "gemm_kernel" in r[0] or "gemm_pp_kernel" in r[0]]
 if g:
     cyc, mf = sum(r[8] for r in g), sum(r[9] for r in g)
-    print('"ALL carel::gemm_kernel instantiations",%d,%.0f,%.0f,%.4f,,,' % (sum(r[1] for r in g), cyc / sum(r[1] for r in g), mf / sum(r[1] for r in g), mf / (1024.0 * cyc)))
+    print('"ALL carel::gemm_pp_kernel + carel::gemm_kernel instantiations",%d,%.0f,%.0f,%.4f,,,' % (sum(r[1] for r in g), cyc / sum(r[1] for r in g), mf / sum(r[1] for r in g), mf / (1024.0 * cyc)))

@@ -21,9 +21,9 @@ rows = []
 for k in ft:
     rows.append((k, fc[k], 2 * ft[k] * 1024 / fc[k] / 1e6, wt.get(k, 0.0) * 1024 / max(1, wc.get(k, 1)) / 1e6))
 rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
-g = [r for r in rows if "gemm_kernel" in r[0]]
+g = [r for r in rows if "gemm_kernel" in r[0] or "gemm_pp_kernel" in r[0]]
 for k, n, f, w in rows:
     print('"%s",%d,%.3f,%.3f' % (k, n, f, w))
 if g:
     n = sum(r[1] for r in g)
-    print('"ALL carel::gemm_kernel instantiations",%d,%.3f,%.3f' % (n, sum(r[1] * r[2] for r in g) / n, sum(r[1] * r[3] for r in g) / n))
+    print('"ALL carel::gemm_pp_kernel + carel::gemm_kernel instantiations",%d,%.3f,%.3f' % (n, sum(r[1] * r[2] for r in g) / n, sum(r[1] * r[3] for r in g) / n))
