@@ -20,8 +20,9 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        hipStream_t stream);
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);
 
-// split-K heuristics of carel_gemm_bf16: treat the grid as `f` times larger (f equal GEMMs run side by side); gemm.hip
-void gemm_split_tile_factor(int f);
+// carel_gemm_bf16 with the split-K heuristic told that `split_tile_factor` equal GEMMs run side by side (the forward's
+// half-batch chains): the split factor is then chosen as for ONE GEMM over all their rows -- same K partition, same bits; gemm.hip
+int gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream);
 // largest value carel_gemm_wgrad_splits(M, N, T) can take under any tuning-hook setting (slab buffer sizing); gemm.hip
 int gemm_wgrad_splits_max(int M, int N, long T);
 int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,

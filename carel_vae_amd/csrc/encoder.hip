@@ -143,13 +143,13 @@ SideStream* side_stream() {
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
               uint32_t off, float p, void* stream, void* colsum_part = nullptr, const void* row_map = nullptr, void* ws = nullptr,
-              size_t ws_bytes = 0) {
+              size_t ws_bytes = 0, int split_tile_factor = 1) {
   carel_gemm_args g;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
   g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map; g.colsum_a = nullptr;
   g.splitk_ws = ws; g.splitk_ws_bytes = (int64_t)ws_bytes;
-  return carel_gemm_bf16(&g, stream);
+  return gemm_bf16_ex(&g, split_tile_factor, stream);
 }
 
 // dW[M,N] = A^T[M x T] * B[T x N]  (A = dY [T,M], B = X [T,N])  via split-K slabs.  With db != null the bias gradient
@@ -209,7 +209,7 @@ static carel_embed_args embed_args_of(const carel_encoder_args* a, const ActLayo
 
 // Layers [l0, l1) of the forward pass for the samples [b0, b0 + nb).  Dense mode: their rows [b0*S, (b0+nb)*S) of every
 // activation buffer; packed mode and the [CLS]-only last layer exist for the whole batch only (b0 = 0, nb = batch).
-static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, long nb, void* stream, char* ws, size_t ws_bytes) {
+static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, long nb, void* stream, char* ws, size_t ws_bytes, int chains = 1) {
   int rc;
   const long B = a->batch, S = a->seq_len;
   const bool whole = b0 == 0 && nb == B;
@@ -251,7 +251,7 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_GELU, 1, la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes))) return rc;
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains))) return rc;
     char* next_bf16 = nullptr;
     if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16 + (size_t)r0 * EH * 2;
     if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, xa, next_bf16, la.st2, stream))) return rc;
@@ -282,10 +282,9 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   if (hipEventRecord(sd->ev[0], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd->peer, sd->ev[0], 0) != hipSuccess)
     return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event fork failed");
   char* ws2 = (char*)a->scratch + sl.o_slabs;                    // the weight-gradient slabs are idle during the forward pass
-  gemm_split_tile_factor(2);                                     // same split-K choices (same bits) as the one-chain forward
-  rc = forward_layers(a, 0, lsplit, hb, hb, (void*)sd->peer, ws2, sl.ws_bytes);
-  if (!rc) rc = forward_layers(a, 0, lsplit, 0, hb, stream, ws, ws_bytes);
-  gemm_split_tile_factor(1);
+  // chains = 2: same split-K choices (same bits) as the one-chain forward
+  rc = forward_layers(a, 0, lsplit, hb, hb, (void*)sd->peer, ws2, sl.ws_bytes, 2);
+  if (!rc) rc = forward_layers(a, 0, lsplit, 0, hb, stream, ws, ws_bytes, 2);
   if (rc) return rc;
   if (hipEventRecord(sd->ev[1], sd->peer) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, sd->ev[1], 0) != hipSuccess)
     return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event join failed");

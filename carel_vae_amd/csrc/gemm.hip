@@ -423,13 +423,12 @@ static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-m
 
 // Small-M GEMMs (packed ECPE batches: ~1.8 k tokens) launch only 84-170 workgroups of 12-48 K steps each on 256 CUs.
 // With a workspace they are run split-K into fp32 slabs + one fused-epilogue pass instead.
-// g_split_tile_factor (carel::gemm_split_tile_factor, internal): the caller runs this many equal GEMMs side by side (the
+// GemmParams::split_tile_factor (carel::gemm_bf16_ex, internal): the caller runs this many equal GEMMs side by side (the
 // forward's half-batch chains), so the split factor is chosen as for ONE GEMM over all of their rows -- the same K
 // partition, hence the same bits, as the single-chain forward.
-static int g_split_tile_factor = 1;
 static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   if (g_gemm_variant != 0) return 1;
-  const int tiles = p.tiles_m * p.tiles_n * g_split_tile_factor;
+  const int tiles = p.tiles_m * p.tiles_n * (p.split_tile_factor > 0 ? p.split_tile_factor : 1);
   int s = 1;
   while (tiles * s < 256 && p.K >= 768 && (p.K / (s * 2)) >= 384 && p.K % (128 * s) == 0 &&
          (size_t)(s * 2) * p.M * p.N * 4 <= ws_bytes) s *= 2;
@@ -510,7 +509,6 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   }
 }
 
-void gemm_split_tile_factor(int f) { g_split_tile_factor = f > 0 ? f : 1; }
 
 }  // namespace carel
 
@@ -616,7 +614,9 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   return CAREL_OK;
 }
 
-extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
+extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) { return carel::gemm_bf16_ex(a, 1, stream_); }
+
+int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null args");
   const int splits = a->splits > 0 ? a->splits : 1;
@@ -633,6 +633,7 @@ extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) {
   p.bias = (const float*)a->bias; p.resid = (const float*)a->resid_f32; p.aux = (const bf16_t*)a->aux_bf16;
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
+  p.split_tile_factor = split_tile_factor;
   p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n <= 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
   p.splitk_ws = (float*)a->splitk_ws; p.splitk_ws_bytes = a->splitk_ws ? (size_t)a->splitk_ws_bytes : 0;
   if (a->ldc != a->N) p.splitk_ws = nullptr;                    // the slab epilogue assumes a dense C

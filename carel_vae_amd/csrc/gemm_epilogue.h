@@ -31,6 +31,7 @@ struct GemmParams {
   float* splitk_ws; size_t splitk_ws_bytes;   // optional workspace enabling the internal split-K path
   float* colsum_a;          // optional, TN form: [splits][M] sums of A over this K-slice (bias gradient)
   float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
+  int split_tile_factor;    // internal split-K heuristic: the caller runs this many equal GEMMs side by side (1 = just this one)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
 };
 

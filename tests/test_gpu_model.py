@@ -23,9 +23,34 @@ CASES = {
     "zh_full12": (O.EncoderConfig(), O.Opt(pair_bow_dim=1000, dropout=0.0)),
 }
 TERMS = ("mmd", "emo", "cau", "pair", "kl_e", "kl_c", "rec")
-# bf16 encoder vs fp32 reference: documented tolerances (relative to each term / tensor scale)
-TOL_TERM_BF16 = 2e-2
-TOL_LATENT_BF16 = 2e-2
+# bf16 encoder (fp32 accumulate, fp32 residual stream) vs the fp32 reference.  Measured on MI355X (tools/parity_report.py,
+# round 2): main loss terms <= 3.6e-4 relative, the two KL terms (weight 7e-6, sums of squares of the latents) <= 1.1e-3,
+# latents / pooler output 1.3e-3 .. 6.7e-3 of their norm (2 .. 12 layers), total loss 1.2e-4 .. 8.9e-4 relative wherever
+# the total is not a near-cancellation of its weighted terms, and <= 1.5e-4 of the terms' scale everywhere.
+# north_star: "ELBO matching to 1e-3 rel" -- asserted at the north-star configuration in
+# test_bench_configuration_elbo_within_1e_3_of_cpu_fp32 (measured 1.2e-4 / 1.5e-4) and, with the margin the 8-sample
+# golden needs (measured 8.9e-4), below.
+TOL_TERM_BF16 = 1e-3            # mmd, emo, cau, pair, rec
+TOL_KL_BF16 = 3e-3              # kl_e, kl_c
+TOL_LATENT_BF16 = 1e-2
+TOL_LOSS_BF16 = 1.5e-3          # |d loss| / |loss| when |loss| >= 10 % of sum |w_i t_i|
+TOL_LOSS_OVER_SCALE = 3e-4      # |d loss| / sum |w_i t_i|, every case
+WEIGHTS = dict(mmd=30.0, emo=10.0, cau=10.0, pair=30.0, kl_e=1.0, kl_c=1.0, rec=1.0)
+
+
+def check_fp32_parity(out, ref, loss_tol=TOL_LOSS_BF16):
+    """out: HIP forward_terms; ref: fp32 values (golden or CPU oracle) for TERMS, 'loss' and the latents."""
+    for k in ("pooled", "mu_e", "lv_e", "mu_c", "lv_c"):
+        assert relnorm(out[k], ref[k]) < TOL_LATENT_BF16, k
+    for k in TERMS:
+        r = float(ref[k])
+        tol = TOL_KL_BF16 if k.startswith("kl") else TOL_TERM_BF16
+        assert abs(float(out[k]) - r) <= tol * max(abs(r), 1e-3), (k, float(out[k]), r)
+    scale = sum(abs(WEIGHTS[k] * float(ref[k])) for k in TERMS)
+    dl, rl = abs(float(out["loss"]) - float(ref["loss"])), abs(float(ref["loss"]))
+    assert dl <= TOL_LOSS_OVER_SCALE * scale, (dl, scale)
+    if rl >= 0.1 * scale:
+        assert dl <= loss_tol * rl, (float(out["loss"]), float(ref["loss"]))
 
 
 def build(cfg, opt, wseed, train_dropout=False):
@@ -67,13 +92,12 @@ def test_forward_terms_vs_golden_and_bf16_oracle(golden_dir, name):
     eps_e, eps_c = torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"])
     model.set_noise(eps_e, eps_c)
     out = model.forward_terms(*call(model, batch, it0))
-    # (a) golden, fp32 reference
-    assert relnorm(out["pooled"], torch.from_numpy(z["pooled"])) < TOL_LATENT_BF16
-    for k in ("mu_e", "lv_e", "mu_c", "lv_c"):
-        assert relnorm(out[k], torch.from_numpy(z[k])) < TOL_LATENT_BF16, k
-    for k in TERMS:
-        ref = float(z["t_" + k])
-        assert abs(float(out[k]) - ref) <= TOL_TERM_BF16 * max(abs(ref), 1e-3), (k, float(out[k]), ref)
+    # (a) golden, fp32 reference: every term, the latents and the TOTAL (the reference's weighted sum, :256-261)
+    gold = {k: torch.from_numpy(z["t_" + k]) for k in TERMS}
+    gold.update({k: torch.from_numpy(z[k]) for k in ("pooled", "mu_e", "lv_e", "mu_c", "lv_c")})
+    gold["loss"] = sum(WEIGHTS[k] * float(z["t_" + k]) * (-1.0 if k == "mmd" else 1.0) for k in TERMS)
+    assert abs(gold["loss"] - float(z["losses"][0])) <= 2e-5 * max(1.0, abs(gold["loss"]))   # the reference forward()'s own step-0 value
+    check_fp32_parity(out, gold)
     # (b) oracle with bf16 rounding where the kernels store bf16: the kernels themselves must be ~exact
     ref = O.forward_terms(P, batch, it0, cfg, opt, eps_e, eps_c, quant=O.bf16_round)
     # the emulation rounds at the same places but not bit-identically (e.g. probabilities are rounded after
@@ -89,6 +113,26 @@ def test_forward_terms_vs_golden_and_bf16_oracle(golden_dir, name):
     scale = sum(abs(w * float(ref[k])) for w, k in ((opt.mmd_loss_weight, "mmd"), (opt.emo_mul_loss_weight, "emo"),
                                                    (opt.cau_mul_loss_weight, "cau"), (opt.pair_mul_loss_weight, "pair")))
     assert abs(float(out["loss"]) - float(ref["loss"])) <= tol * scale, (float(out["loss"]), float(ref["loss"]), scale)
+
+
+@pytest.mark.parametrize("shape", ["A", "B"])
+def test_bench_configuration_elbo_within_1e_3_of_cpu_fp32(shape):
+    """The north-star tolerance at the north-star configuration (BASELINE.json configs[1]): B = 64, S = 128, 12 layers,
+    vocabulary 21 128, V = 23 771, dropout off, dense (A) and ECPE-shaped (B, padding skipped) batches, against the CPU
+    fp32 oracle (held to the reference's own outputs by tests/test_oracle_golden.py): ELBO within 1e-3 relative."""
+    cfg, opt = O.EncoderConfig(), O.Opt(dropout=0.0)
+    assert (cfg.layers, cfg.vocab_size, opt.pair_bow_dim) == (12, 21128, 23771)
+    model, P = build(cfg, opt, 0)
+    model.train()
+    batch = O.synthetic_batch(64, 128, cfg, opt.pair_bow_dim, seed=1, shape=shape)
+    g = torch.Generator().manual_seed(3)
+    eps_e, eps_c = torch.randn(opt.ec_dim, generator=g), torch.randn(opt.ec_dim, generator=g)
+    model.set_noise(eps_e, eps_c)
+    out = model.forward_terms(*call(model, batch, 3))
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    ref = O.forward_terms(P, batch, 3, cfg, opt, eps_e, eps_c)
+    check_fp32_parity(out, ref, loss_tol=1e-3)
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"]))
 
 
 @pytest.mark.parametrize("name", ["zh_small", "zh_ragged", "en_small", "zh_s64"])
