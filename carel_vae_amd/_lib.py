@@ -221,6 +221,7 @@ SIGNATURES = {
     "carel_en_tail_losses": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p]),
     "carel_en_tail_backward": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p, C.c_void_p]),
     "carel_en_pair_logits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "carel_bow_expand": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_axpy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "carel_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),

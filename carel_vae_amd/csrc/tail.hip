@@ -813,6 +813,29 @@ extern "C" int carel_scale_f32(void* x, int64_t n, const void* scale_dev, void* 
   return check_launch("scale_inplace_kernel");
 }
 
+// Bag-of-words targets shipped as (row, column, value) triples (3-30 entries per clause pair against V = 23 771 columns:
+// ~10 KB instead of the 6 MB dense block `bow_reps` of ref :829) and expanded on the device.  `trip` = int32 [nnz] rows,
+// int32 [nnz] columns, f32 [nnz] values back to back; entries of one batch are distinct (ECPEDataset builds one entry per
+// vocabulary word of the pair), so plain stores suffice.
+__global__ void bow_scatter_kernel(const int* __restrict__ rows, const int* __restrict__ cols, const float* __restrict__ vals, int nnz,
+                                   float* __restrict__ out, int B, int V) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const int r = rows[i], c = cols[i];
+  if (r >= 0 && r < B && c >= 0 && c < V) out[(long)r * V + c] = vals[i];
+}
+extern "C" int carel_bow_expand(const void* trip, int32_t nnz, void* out, int32_t B, int32_t V, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!out || B < 1 || V < 1 || nnz < 0 || (nnz > 0 && !trip)) return set_error(CAREL_ERR_ARG, "carel_bow_expand: bad arguments");
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * V * 4, stream);
+  if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_bow_expand: memset: %s", hipGetErrorString(e));
+  if (nnz == 0) return CAREL_OK;
+  const int* rows = (const int*)trip;
+  hipLaunchKernelGGL(bow_scatter_kernel, dim3((nnz + 255) / 256), dim3(256), 0, stream, rows, rows + nnz, (const float*)(rows + 2 * (long)nnz), nnz,
+                     (float*)out, B, V);
+  return check_launch("bow_scatter_kernel");
+}
+
 extern "C" int64_t carel_tail_pair_dead_offset(int32_t batch, int32_t ec_dim, int32_t bow_dim) {
   TailWork w = carve((float*)nullptr + 1, batch, ec_dim, bow_dim);   // offsets relative to a fake base
   return (int64_t)(w.pair_dead - ((float*)nullptr + 1));

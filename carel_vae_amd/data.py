@@ -338,3 +338,193 @@ def synthetic_ecpe_batch(B, S, vocab_size, V, seed=1, shape="A", pad_id=0, first
         rs2 = np.random.RandomState(seed + 7919)
         out["emo_labels"] = t((rs2.uniform(size=(B, 1)) < 0.5).astype(np.float32))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# PrefetchLoader: the seven `.to(device)` copies of every step (ref :823-830) taken off the step's critical path
+# ----------------------------------------------------------------------------------------------
+class PrefetchLoader:
+    """Wraps a loader of dict batches (BatchLoader or a stock DataLoader over ECPEDataset) and yields the same batches with
+    every tensor ALREADY ON THE DEVICE:
+
+      * a background thread pulls batches ahead of the training loop (`depth` batches, default 3) and packs each into ONE
+        page-locked staging block -- ids / mask / token types / labels, and the bag-of-words targets as (row, column, value)
+        triples (a pair has 3-30 vocabulary words of V = 23 771: ~10 KB instead of 6 MB dense);
+      * one async H2D copy per batch on a dedicated copy stream into a preallocated device slot; the training stream only
+        waits for that copy's event and expands the triples on the device (`carel_bow_expand`);
+      * slots are recycled without a host sync: before slot s is overwritten the copy stream waits for the event the
+        consumer recorded when it asked for the batch AFTER the one in s (all work on s is enqueued before that).
+
+    The reference's loop body is unchanged: `batch[k].to(device, ...)` of a tensor that is already there is a no-op.
+    `seq_lengths` (host list) is added like BatchLoader does, so the model can skip padding without a device read-back.
+    Values are bit-identical to the wrapped loader's (tests/test_gpu_training.py)."""
+
+    _INT_KEYS = ("input_ids", "attention_masks", "token_type_ids")
+
+    def __init__(self, loader, device="cuda", depth=3, max_nnz_per_row=64):
+        import threading
+        self.loader, self.device, self.depth = loader, torch.device(device), max(2, int(depth))
+        self.max_nnz_per_row = int(max_nnz_per_row)
+        self._threading = threading
+        self._slots = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    # ---- packing (host, producer thread) ------------------------------------------------------
+    @staticmethod
+    def pack_layout(B, S, emo_is_float, nnz_cap):
+        """word offsets (4-byte units) of the fields inside one staging block"""
+        o, lay = 0, {}
+
+        def take(name, n):
+            nonlocal o
+            lay[name] = (o, n)
+            o = (o + n + 1) & ~1                              # every field starts 8-byte aligned (int64 views)
+        for k in PrefetchLoader._INT_KEYS:
+            take(k, B * S * 2)                                # int64 as two words
+        take("labels", B)
+        take("cau_labels", B)
+        take("emo_labels", B if emo_is_float else 2 * B)
+        take("trip", 3 * nnz_cap)
+        return lay, o
+
+    @staticmethod
+    def sparsify(bow):
+        """dense [B, V] f32 -> (rows i32, cols i32, vals f32) of its non-zeros, row-major order"""
+        nz = bow.nonzero(as_tuple=False)
+        rows, cols = nz[:, 0].to(torch.int32), nz[:, 1].to(torch.int32)
+        return rows, cols, bow[nz[:, 0], nz[:, 1]].contiguous()
+
+    def _make_slots(self, batch):
+        B, S = batch["input_ids"].shape
+        V = batch["bow_reps"].shape[1]
+        emo_f = batch["emo_labels"].dtype.is_floating_point
+        cap = B * self.max_nnz_per_row
+        lay, words = self.pack_layout(B, S, emo_f, cap)
+        slots = []
+        for _ in range(self.depth):
+            slots.append(dict(host=torch.empty(words, dtype=torch.int32).pin_memory(), dev=torch.empty(words, dtype=torch.int32, device=self.device),
+                              bow=torch.empty((B, V), dtype=torch.float32, device=self.device),
+                              copied=torch.cuda.Event(), released=None))
+        self._geom = (B, S, V, emo_f, cap, lay, words)
+        self._slots = slots
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+
+    def _pack(self, batch, slot):
+        B, S, V, emo_f, cap, lay, words = self._geom
+        h = slot["host"]
+        for k in self._INT_KEYS:
+            o, n = lay[k]
+            h[o:o + n].view(torch.int64).view(B, S).copy_(batch[k])
+        for k in ("labels", "cau_labels"):
+            o, n = lay[k]
+            h[o:o + n].view(torch.float32).copy_(batch[k].reshape(-1).to(torch.float32))
+        o, n = lay["emo_labels"]
+        if emo_f:
+            h[o:o + n].view(torch.float32).copy_(batch["emo_labels"].reshape(-1).to(torch.float32))
+        else:
+            h[o:o + n].view(torch.int64).copy_(batch["emo_labels"].reshape(-1))
+        rows, cols, vals = self.sparsify(batch["bow_reps"])
+        nnz = int(rows.numel())
+        if nnz > cap:
+            raise ValueError("PrefetchLoader: %d bag-of-words entries in one batch exceed the staging capacity %d (raise max_nnz_per_row)" % (nnz, cap))
+        o, _ = lay["trip"]
+        h[o:o + nnz].copy_(rows)
+        h[o + nnz:o + 2 * nnz].copy_(cols)
+        h[o + 2 * nnz:o + 3 * nnz].view(torch.float32).copy_(vals)
+        return nnz
+
+    # ---- iteration ----------------------------------------------------------------------------
+    def __iter__(self):
+        import queue
+        q = queue.Queue(maxsize=self.depth - 1)        # at most depth - 1 batches ahead of the consumer + the one it holds
+        stop = self._threading.Event()
+        state = {"n": 0}
+
+        def producer():
+            try:
+                nt = torch.get_num_threads()
+                for batch in self.loader:
+                    if stop.is_set():
+                        return
+                    Bb, Sb = batch["input_ids"].shape
+                    Vb = batch["bow_reps"].shape[1]
+                    fits = self._slots is not None and (Sb, Vb) == (self._geom[1], self._geom[2]) and Bb <= self._geom[0]
+                    if not fits:
+                        self._make_slots(batch)
+                    i = state["n"] % self.depth
+                    slot = self._slots[i]
+                    slot["copied"].synchronize()               # the previous H2D out of this staging block is done (host wait, this thread only)
+                    torch.set_num_threads(1)                   # see BatchLoader: a spinning OpenMP pool starves the HIP runtime threads
+                    full = Bb == self._geom[0]
+                    if not full:                               # short last batch (once per epoch): plain copies
+                        item = dict(kind="plain", batch=batch)
+                    else:
+                        nnz = self._pack(batch, slot)
+                        with torch.cuda.stream(self._copy_stream):
+                            if slot["released"] is not None:
+                                self._copy_stream.wait_event(slot["released"])      # everything that used this device slot is enqueued-and-ordered before
+                            slot["dev"].copy_(slot["host"], non_blocking=True)
+                            slot["copied"].record(self._copy_stream)
+                        item = dict(kind="slot", slot=i, nnz=nnz, lengths=batch.get("seq_lengths"), att_host=None if "seq_lengths" in batch else batch["attention_masks"])
+                    torch.set_num_threads(nt)
+                    state["n"] += 1
+                    q.put(item)
+            except BaseException as e:                          # surface loader errors in the consumer
+                q.put(e)
+                return
+            q.put(None)
+
+        th = self._threading.Thread(target=producer, daemon=True)
+        th.start()
+        prev = None
+        try:
+            while True:
+                item = q.get()
+                if prev is not None:                            # all work on the previous batch has been enqueued by now
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    self._slots[prev]["released"] = ev
+                    prev = None
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                if item["kind"] == "plain":                     # short last batch: plain copies (once per epoch)
+                    b = item["batch"]
+                    out = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+                    if "seq_lengths" not in out:
+                        out["seq_lengths"] = b["attention_masks"].sum(1).tolist()
+                    yield out
+                    continue
+                yield self._unpack(item)
+                prev = item["slot"]
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except Exception:
+                    th.join(timeout=0.05)
+
+    def _unpack(self, item):
+        from . import ops
+        B, S, V, emo_f, cap, lay, words = self._geom
+        slot = self._slots[item["slot"]]
+        torch.cuda.current_stream(self.device).wait_event(slot["copied"])
+        d = slot["dev"]
+        out = {}
+        for k in self._INT_KEYS:
+            o, n = lay[k]
+            out[k] = d[o:o + n].view(torch.int64).view(B, S)
+        for k in ("labels", "cau_labels"):
+            o, n = lay[k]
+            out[k] = d[o:o + n].view(torch.float32).view(B, 1)
+        o, n = lay["emo_labels"]
+        out["emo_labels"] = d[o:o + n].view(torch.float32).view(B, 1) if emo_f else d[o:o + n].view(torch.int64).view(B, 1)
+        o, _ = lay["trip"]
+        nnz = item["nnz"]
+        out["bow_reps"] = ops.bow_expand(d[o:o + 3 * nnz] if nnz else d[o:o], nnz, slot["bow"])
+        out["seq_lengths"] = item["lengths"] if item["lengths"] is not None else item["att_host"].sum(1).tolist()
+        return out

@@ -250,6 +250,13 @@ def vi_upper(z, net, perm):
     return loss, dz
 
 
+def bow_expand(trip, nnz, out):
+    """trip: device int32 [3 * nnz] (rows, cols, f32 value bits); out: device f32 [B, V] (overwritten)."""
+    L.check(L.load().carel_bow_expand(trip.data_ptr() if nnz else None, int(nnz), out.data_ptr(), out.shape[0], out.shape[1], L.current_stream()),
+            "carel_bow_expand")
+    return out
+
+
 def scale_(x, scale_dev):
     L.check(L.load().carel_scale_f32(x.data_ptr(), x.numel(), scale_dev.data_ptr(), L.current_stream()), "carel_scale_f32")
 

@@ -345,6 +345,10 @@ int carel_tail_backward(const carel_tail_args* args, const void* grad_out_dev_f3
 /* same, plus an additional upstream gradient on the sampled embeddings z (f32 [B, 2*ec_dim], NOT scaled by grad_out):
  * lets further loss terms defined on z_e / z_c (e.g. the CLUB bound of the VI ablation) reach the encoder */
 int carel_tail_backward_dz(const carel_tail_args* args, const void* grad_out_dev_f32, const void* dz_extra_f32, void* stream);
+/* Host->device feeding of the bag-of-words targets (`bow_reps.to(device)`, ref :829, 6 MB per batch when dense): the batch's
+ * non-zeros as triples -- trip = int32 rows[nnz], int32 cols[nnz], f32 vals[nnz], contiguous, distinct (row, col) -- are
+ * expanded into the dense f32 [B, V] block the loss kernels read (zero fill + scatter, stream-ordered). */
+int carel_bow_expand(const void* trip, int32_t nnz, void* out_f32, int32_t B, int32_t V, void* stream);
 /* x[i] *= *scale_dev  (device scalar; used to apply loss.backward()'s grad_output without a host sync) */
 int carel_scale_f32(void* x_f32, int64_t n, const void* scale_dev_f32, void* stream);
 /* offset (in floats, inside `work`) of the flag carel_tail_losses sets to 1.0 when the pair loss was

@@ -93,3 +93,34 @@ def test_train_driver_english_adversarial(tmp_path):
     assert sum("f1 socre" in str(l) for l in logs) == 2
     df = T.generate_self_train_data(sizes, test_df, test_loader, model, "extreme")
     assert set(df["label"]) <= {0, 1}
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_prefetch_loader_yields_the_wrapped_loaders_batches_on_the_device(depth):
+    """PrefetchLoader (pinned ring, one async H2D per batch on a copy stream, bag-of-words as triples expanded by
+    carel_bow_expand): every field bit-identical to the wrapped loader's batch, over two epochs (slots recycled several
+    times, GPU kept busy between batches so a too-early slot reuse would show), odd batch size, short last batch."""
+    from carel_vae_amd.data import PrefetchLoader, synthetic_ecpe_batch
+    batches = [synthetic_ecpe_batch(15, 32, 100, 700, seed=10 + i, shape="B") for i in range(7)]
+    batches.append(synthetic_ecpe_batch(5, 32, 100, 700, seed=99, shape="B"))
+    pl = PrefetchLoader(batches, "cuda", depth=depth)
+    assert len(pl) == 8
+    busy = torch.zeros(1 << 22, device="cuda")
+    for epoch in range(2):
+        seen = 0
+        kept = []
+        for got, want in zip(pl, batches):
+            assert got["seq_lengths"] == want["attention_masks"].sum(1).tolist()
+            kept.append(({k: v for k, v in got.items() if torch.is_tensor(v)}, want))
+            for _ in range(20):
+                busy.add_(1.0)                         # work that is still running when the next batch is requested
+            for k, v in want.items():
+                assert got[k].is_cuda and got[k].dtype == v.dtype and got[k].shape == v.shape, k
+                assert torch.equal(got[k].cpu(), v), (epoch, seen, k)
+            seen += 1
+        assert seen == len(batches)
+    # binary float emotion labels (the `_en` dataset) take the float slot layout
+    fb = [synthetic_ecpe_batch(8, 16, 50, 90, seed=3 + i, shape="A", binary_emotion=True) for i in range(3)]
+    for got, want in zip(PrefetchLoader(fb, "cuda"), fb):
+        assert got["emo_labels"].dtype == torch.float32 and torch.equal(got["emo_labels"].cpu(), want["emo_labels"])
+        assert torch.equal(got["bow_reps"].cpu(), want["bow_reps"])
