@@ -257,6 +257,28 @@ class BatchLoader:
         }
         self.lengths = att.sum(1).tolist()
         self.pin = bool(pin_memory) and torch.cuda.is_available()
+        self._sparse = None
+
+    def enable_sparse_bow(self):
+        """Yield the bag-of-words targets as padded per-sample entry lists -- `bow_cols` int32 [B, M] (-1 = padding) and
+        `bow_vals` f32 [B, M], M = the largest entry count of the dataset -- INSTEAD of the dense `bow_reps` rows (95 KB per
+        sample at V = 23 771).  For PrefetchLoader, which ships the entries and expands them on the device."""
+        if self._sparse is None:
+            bow = self.fields["bow_reps"]
+            n, V = bow.shape
+            counts = (bow != 0).sum(1)
+            M = max(1, int(counts.max()) if n else 1)
+            M = (M + 7) & ~7
+            cols = torch.full((n, M), -1, dtype=torch.int32)
+            vals = torch.zeros((n, M), dtype=torch.float32)
+            nz = bow.nonzero(as_tuple=False)                      # row-major: entries of a row are consecutive
+            if nz.numel():
+                start = torch.cumsum(counts, 0) - counts
+                pos = torch.arange(nz.shape[0]) - start[nz[:, 0]]
+                cols[nz[:, 0], pos] = nz[:, 1].to(torch.int32)
+                vals[nz[:, 0], pos] = bow[nz[:, 0], nz[:, 1]]
+            self._sparse = (cols, vals, V)
+        return self
 
     def __len__(self):
         n = len(self.dataset)
@@ -290,6 +312,11 @@ class BatchLoader:
             torch.set_num_threads(1)
             try:
                 for k, t in self.fields.items():
+                    if k == "bow_reps" and self._sparse is not None:
+                        batch["bow_cols"] = self._sparse[0].index_select(0, idx)
+                        batch["bow_vals"] = self._sparse[1].index_select(0, idx)
+                        batch["bow_dim"] = self._sparse[2]
+                        continue
                     out = t.index_select(0, idx)      # (the out= form of index_select is ~60x slower on CPU)
                     batch[k] = out.pin_memory() if self.pin else out
             finally:
@@ -356,6 +383,8 @@ class PrefetchLoader:
         consumer recorded when it asked for the batch AFTER the one in s (all work on s is enqueued before that).
 
     The reference's loop body is unchanged: `batch[k].to(device, ...)` of a tensor that is already there is a no-op.
+    A batch's tensors are views of a recycled device slot: they are valid until the NEXT batch is requested (what a training
+    loop needs; clone what must live longer).
     `seq_lengths` (host list) is added like BatchLoader does, so the model can skip padding without a device read-back.
     Values are bit-identical to the wrapped loader's (tests/test_gpu_training.py)."""
 
@@ -367,6 +396,8 @@ class PrefetchLoader:
         self.max_nnz_per_row = int(max_nnz_per_row)
         self._threading = threading
         self._slots = None
+        if isinstance(loader, BatchLoader):
+            loader.enable_sparse_bow()             # entries straight from the dataset: no dense 6 MB gather, no non-zero scan
 
     def __len__(self):
         return len(self.loader)
@@ -391,16 +422,21 @@ class PrefetchLoader:
 
     @staticmethod
     def sparsify(bow):
-        """dense [B, V] f32 -> (rows i32, cols i32, vals f32) of its non-zeros, row-major order"""
+        """dense [B, V] f32 -> (rows i32, cols i32, vals f32) of its non-zeros, row-major order (slow path: a scan of the dense
+        block; loaders that know their entries -- BatchLoader -- hand them over instead)"""
         nz = bow.nonzero(as_tuple=False)
         rows, cols = nz[:, 0].to(torch.int32), nz[:, 1].to(torch.int32)
         return rows, cols, bow[nz[:, 0], nz[:, 1]].contiguous()
 
+    @staticmethod
+    def _bow_dim(batch):
+        return int(batch["bow_dim"]) if "bow_cols" in batch else batch["bow_reps"].shape[1]
+
     def _make_slots(self, batch):
         B, S = batch["input_ids"].shape
-        V = batch["bow_reps"].shape[1]
+        V = self._bow_dim(batch)
         emo_f = batch["emo_labels"].dtype.is_floating_point
-        cap = B * self.max_nnz_per_row
+        cap = B * (batch["bow_cols"].shape[1] if "bow_cols" in batch else self.max_nnz_per_row)
         lay, words = self.pack_layout(B, S, emo_f, cap)
         slots = []
         for _ in range(self.depth):
@@ -425,11 +461,18 @@ class PrefetchLoader:
             h[o:o + n].view(torch.float32).copy_(batch["emo_labels"].reshape(-1).to(torch.float32))
         else:
             h[o:o + n].view(torch.int64).copy_(batch["emo_labels"].reshape(-1))
+        o, _ = lay["trip"]
+        if "bow_cols" in batch:                    # padded entry lists: rows are implied, padding columns are -1 (skipped on the device)
+            M = batch["bow_cols"].shape[1]
+            nnz = B * M
+            h[o:o + nnz].view(B, M).copy_(torch.arange(B, dtype=torch.int32).view(B, 1).expand(B, M))
+            h[o + nnz:o + 2 * nnz].view(B, M).copy_(batch["bow_cols"])
+            h[o + 2 * nnz:o + 3 * nnz].view(torch.float32).view(B, M).copy_(batch["bow_vals"])
+            return nnz
         rows, cols, vals = self.sparsify(batch["bow_reps"])
         nnz = int(rows.numel())
         if nnz > cap:
             raise ValueError("PrefetchLoader: %d bag-of-words entries in one batch exceed the staging capacity %d (raise max_nnz_per_row)" % (nnz, cap))
-        o, _ = lay["trip"]
         h[o:o + nnz].copy_(rows)
         h[o + nnz:o + 2 * nnz].copy_(cols)
         h[o + 2 * nnz:o + 3 * nnz].view(torch.float32).copy_(vals)
@@ -438,39 +481,44 @@ class PrefetchLoader:
     # ---- iteration ----------------------------------------------------------------------------
     def __iter__(self):
         import queue
-        q = queue.Queue(maxsize=self.depth - 1)        # at most depth - 1 batches ahead of the consumer + the one it holds
+        q = queue.Queue()
+        free = self._threading.Semaphore(self.depth - 1)     # slots the producer may fill while the consumer holds one
         stop = self._threading.Event()
-        state = {"n": 0}
 
         def producer():
+            n = 0
             try:
                 nt = torch.get_num_threads()
                 for batch in self.loader:
+                    # a slot is written only after the consumer has handed it back (host handshake); its device half additionally
+                    # waits, stream-side, for the event the consumer recorded at that moment
+                    while not free.acquire(timeout=0.05):
+                        if stop.is_set():
+                            return
                     if stop.is_set():
                         return
                     Bb, Sb = batch["input_ids"].shape
-                    Vb = batch["bow_reps"].shape[1]
+                    Vb = self._bow_dim(batch)
                     fits = self._slots is not None and (Sb, Vb) == (self._geom[1], self._geom[2]) and Bb <= self._geom[0]
                     if not fits:
                         self._make_slots(batch)
-                    i = state["n"] % self.depth
+                    if Bb != self._geom[0]:                    # short last batch (once per epoch): plain copies by the consumer
+                        q.put(dict(kind="plain", batch=batch))
+                        continue
+                    i = n % self.depth
+                    n += 1
                     slot = self._slots[i]
                     slot["copied"].synchronize()               # the previous H2D out of this staging block is done (host wait, this thread only)
                     torch.set_num_threads(1)                   # see BatchLoader: a spinning OpenMP pool starves the HIP runtime threads
-                    full = Bb == self._geom[0]
-                    if not full:                               # short last batch (once per epoch): plain copies
-                        item = dict(kind="plain", batch=batch)
-                    else:
-                        nnz = self._pack(batch, slot)
-                        with torch.cuda.stream(self._copy_stream):
-                            if slot["released"] is not None:
-                                self._copy_stream.wait_event(slot["released"])      # everything that used this device slot is enqueued-and-ordered before
-                            slot["dev"].copy_(slot["host"], non_blocking=True)
-                            slot["copied"].record(self._copy_stream)
-                        item = dict(kind="slot", slot=i, nnz=nnz, lengths=batch.get("seq_lengths"), att_host=None if "seq_lengths" in batch else batch["attention_masks"])
+                    nnz = self._pack(batch, slot)
                     torch.set_num_threads(nt)
-                    state["n"] += 1
-                    q.put(item)
+                    with torch.cuda.stream(self._copy_stream):
+                        if slot["released"] is not None:
+                            self._copy_stream.wait_event(slot["released"])
+                        slot["dev"].copy_(slot["host"], non_blocking=True)
+                        slot["copied"].record(self._copy_stream)
+                    q.put(dict(kind="slot", slot=i, nnz=nnz, lengths=batch.get("seq_lengths"),
+                               att_host=None if "seq_lengths" in batch else batch["attention_masks"]))
             except BaseException as e:                          # surface loader errors in the consumer
                 q.put(e)
                 return
@@ -478,35 +526,42 @@ class PrefetchLoader:
 
         th = self._threading.Thread(target=producer, daemon=True)
         th.start()
-        prev = None
+        held = None
         try:
             while True:
                 item = q.get()
-                if prev is not None:                            # all work on the previous batch has been enqueued by now
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(self.device))
-                    self._slots[prev]["released"] = ev
-                    prev = None
+                if held is not None:                            # all work on the previous batch has been enqueued by now
+                    if held >= 0:
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.device))
+                        self._slots[held]["released"] = ev
+                    free.release()
+                    held = None
                 if item is None:
                     return
                 if isinstance(item, BaseException):
                     raise item
-                if item["kind"] == "plain":                     # short last batch: plain copies (once per epoch)
+                if item["kind"] == "plain":
                     b = item["batch"]
                     out = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+                    if "bow_cols" in out:                       # entry lists -> dense targets (not slot-backed)
+                        from . import ops
+                        Bb, M = b["bow_cols"].shape
+                        trip = torch.cat((torch.arange(Bb, dtype=torch.int32).view(Bb, 1).expand(Bb, M).reshape(-1), b["bow_cols"].reshape(-1),
+                                          b["bow_vals"].reshape(-1).view(torch.int32))).to(self.device)
+                        out["bow_reps"] = ops.bow_expand(trip, Bb * M, torch.empty((Bb, int(b["bow_dim"])), dtype=torch.float32, device=self.device))
+                        for k in ("bow_cols", "bow_vals", "bow_dim"):
+                            del out[k]
                     if "seq_lengths" not in out:
                         out["seq_lengths"] = b["attention_masks"].sum(1).tolist()
+                    held = -1
                     yield out
                     continue
+                held = item["slot"]
                 yield self._unpack(item)
-                prev = item["slot"]
         finally:
             stop.set()
-            while th.is_alive():
-                try:
-                    q.get_nowait()
-                except Exception:
-                    th.join(timeout=0.05)
+            th.join(timeout=2.0)
 
     def _unpack(self, item):
         from . import ops

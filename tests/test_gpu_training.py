@@ -108,10 +108,8 @@ def test_prefetch_loader_yields_the_wrapped_loaders_batches_on_the_device(depth)
     busy = torch.zeros(1 << 22, device="cuda")
     for epoch in range(2):
         seen = 0
-        kept = []
         for got, want in zip(pl, batches):
             assert got["seq_lengths"] == want["attention_masks"].sum(1).tolist()
-            kept.append(({k: v for k, v in got.items() if torch.is_tensor(v)}, want))
             for _ in range(20):
                 busy.add_(1.0)                         # work that is still running when the next batch is requested
             for k, v in want.items():
@@ -124,3 +122,30 @@ def test_prefetch_loader_yields_the_wrapped_loaders_batches_on_the_device(depth)
     for got, want in zip(PrefetchLoader(fb, "cuda"), fb):
         assert got["emo_labels"].dtype == torch.float32 and torch.equal(got["emo_labels"].cpu(), want["emo_labels"])
         assert torch.equal(got["bow_reps"].cpu(), want["bow_reps"])
+
+
+def test_prefetch_loader_around_batch_loader_ships_entry_lists():
+    """PrefetchLoader(BatchLoader): the bag-of-words targets travel as the dataset's padded entry lists (no dense gather, no
+    non-zero scan) and come out as the same dense rows a plain BatchLoader yields; short last batch included."""
+    import pandas as pd
+
+    class SynthDataset(D.ECPEDataset):
+        def __init__(self, n, V, seed):
+            b = D.synthetic_ecpe_batch(n, 32, 100, V, seed=seed, shape="B")
+            self.pairs = pd.Series(["x"] * n)
+            self.labels = b["labels"].view(-1).numpy(); self.emo_labels = b["emo_labels"].view(-1).numpy(); self.cau_labels = self.labels
+            self.max_len, self.bow_features, self.tokenizer = 32, [None] * V, object()
+            self.bow_representations = list(b["bow_reps"].numpy())
+            self._cache = (b["input_ids"], b["attention_masks"], b["token_type_ids"])
+    ds = SynthDataset(77, 900, 4)
+    want = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()} for b in D.BatchLoader(ds, batch_size=16)]
+    pl = D.PrefetchLoader(D.BatchLoader(ds, batch_size=16), "cuda", depth=3)
+    n = 0
+    for got, w in zip(pl, want):
+        assert set(got) == set(w), (set(got) ^ set(w))
+        assert got["seq_lengths"] == w["seq_lengths"]
+        for k, v in w.items():
+            if torch.is_tensor(v):
+                assert got[k].is_cuda and torch.equal(got[k].cpu(), v), (n, k)
+        n += 1
+    assert n == len(want) == 5
