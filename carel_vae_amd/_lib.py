@@ -121,6 +121,15 @@ class EncoderArgs(C.Structure):
                 ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p)]
 
 
+class HostPackArgs(C.Structure):
+    _fields_ = [("input_ids", C.c_void_p), ("attention_masks", C.c_void_p), ("token_type_ids", C.c_void_p), ("labels", C.c_void_p),
+                ("cau_labels", C.c_void_p), ("emo_labels", C.c_void_p), ("bow_cols", C.c_void_p), ("bow_vals", C.c_void_p),
+                ("idx", C.c_void_p), ("dst", C.c_void_p), ("n_samples", C.c_int64), ("batch", C.c_int32), ("seq_len", C.c_int32),
+                ("bow_entries", C.c_int32), ("emo_is_float", C.c_int32), ("off_input_ids", C.c_int64), ("off_attention_masks", C.c_int64),
+                ("off_token_type_ids", C.c_int64), ("off_labels", C.c_int64), ("off_cau_labels", C.c_int64), ("off_emo_labels", C.c_int64),
+                ("off_trip", C.c_int64)]
+
+
 class HsicArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("ldx", C.c_int64), ("ldy", C.c_int64), ("m", C.c_int32), ("d", C.c_int32),
                 ("s_x", C.c_float), ("s_y", C.c_float), ("hsic_out", C.c_void_p), ("grad_hsic", C.c_void_p),
@@ -221,6 +230,7 @@ SIGNATURES = {
     "carel_en_tail_losses": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p]),
     "carel_en_tail_backward": (C.c_int, [C.POINTER(EnTailArgs), C.c_void_p, C.c_void_p]),
     "carel_en_pair_logits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "carel_host_pack_batch": (C.c_int, [C.POINTER(HostPackArgs)]),
     "carel_bow_expand": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_axpy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "carel_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,

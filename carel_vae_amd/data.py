@@ -482,43 +482,96 @@ class PrefetchLoader:
     def __iter__(self):
         import queue
         q = queue.Queue()
-        free = self._threading.Semaphore(self.depth - 1)     # slots the producer may fill while the consumer holds one
+        free = self._threading.Semaphore(self.depth)         # free slots; the consumer hands its slot back when it asks for the next batch
         stop = self._threading.Event()
 
-        def producer():
+        def acquire_slot():
+            # a slot is written only after the consumer has handed it back (host handshake); its device half additionally
+            # waits, stream-side, for the event the consumer recorded at that moment
+            while not free.acquire(timeout=0.05):
+                if stop.is_set():
+                    return False
+            return not stop.is_set()
+
+        def ship(slot, i, nnz, lengths, att_host):
+            with torch.cuda.stream(self._copy_stream):
+                if slot["released"] is not None:
+                    self._copy_stream.wait_event(slot["released"])
+                slot["dev"].copy_(slot["host"], non_blocking=True)
+                slot["copied"].record(self._copy_stream)
+            q.put(dict(kind="slot", slot=i, nnz=nnz, lengths=lengths, att_host=att_host))
+
+        def producer_native():
+            """BatchLoader underneath: the batch is gathered from the dataset's stacked arrays by ONE C call (GIL released)."""
+            from . import _lib as L
+            import ctypes as C
+            bl = self.loader
+            f, (cols, vals, V) = bl.fields, bl._sparse
+            n_all, S = f["input_ids"].shape
+            B, M = bl.batch_size, cols.shape[1]
+            emo = f["emo_labels"].reshape(-1).contiguous()
+            lab, cau = f["labels"].reshape(-1).contiguous(), f["cau_labels"].reshape(-1).contiguous()
+            keep = (emo, lab, cau)                               # noqa: F841  (the C call reads these buffers)
+            order = bl._order().to(torch.int64).contiguous()
+            lib = L.load()
             n = 0
-            try:
-                nt = torch.get_num_threads()
-                for batch in self.loader:
-                    # a slot is written only after the consumer has handed it back (host handshake); its device half additionally
-                    # waits, stream-side, for the event the consumer recorded at that moment
-                    while not free.acquire(timeout=0.05):
-                        if stop.is_set():
-                            return
-                    if stop.is_set():
+            for s0 in range(0, n_all, B):
+                idx = order[s0:s0 + B].contiguous()
+                if idx.numel() < B:
+                    if bl.drop_last:
+                        break
+                    if not acquire_slot():
                         return
-                    Bb, Sb = batch["input_ids"].shape
-                    Vb = self._bow_dim(batch)
-                    fits = self._slots is not None and (Sb, Vb) == (self._geom[1], self._geom[2]) and Bb <= self._geom[0]
-                    if not fits:
-                        self._make_slots(batch)
-                    if Bb != self._geom[0]:                    # short last batch (once per epoch): plain copies by the consumer
-                        q.put(dict(kind="plain", batch=batch))
-                        continue
-                    i = n % self.depth
-                    n += 1
-                    slot = self._slots[i]
-                    slot["copied"].synchronize()               # the previous H2D out of this staging block is done (host wait, this thread only)
-                    torch.set_num_threads(1)                   # see BatchLoader: a spinning OpenMP pool starves the HIP runtime threads
-                    nnz = self._pack(batch, slot)
-                    torch.set_num_threads(nt)
-                    with torch.cuda.stream(self._copy_stream):
-                        if slot["released"] is not None:
-                            self._copy_stream.wait_event(slot["released"])
-                        slot["dev"].copy_(slot["host"], non_blocking=True)
-                        slot["copied"].record(self._copy_stream)
-                    q.put(dict(kind="slot", slot=i, nnz=nnz, lengths=batch.get("seq_lengths"),
-                               att_host=None if "seq_lengths" in batch else batch["attention_masks"]))
+                    b = {k: t.index_select(0, idx) for k, t in f.items() if k != "bow_reps"}
+                    b.update(bow_cols=cols.index_select(0, idx), bow_vals=vals.index_select(0, idx), bow_dim=V,
+                             seq_lengths=[bl.lengths[i] for i in idx.tolist()])
+                    q.put(dict(kind="plain", batch=b))
+                    continue
+                if not acquire_slot():
+                    return
+                if self._slots is None or self._geom[:3] != (B, S, V) or self._geom[4] != B * M:
+                    self._make_slots(dict(input_ids=f["input_ids"][:B], emo_labels=f["emo_labels"][:B], bow_cols=cols[:B], bow_dim=V))
+                i = n % self.depth
+                n += 1
+                slot = self._slots[i]
+                slot["copied"].synchronize()
+                lay = self._geom[5]
+                a = L.HostPackArgs()
+                a.input_ids, a.attention_masks, a.token_type_ids = f["input_ids"].data_ptr(), f["attention_masks"].data_ptr(), f["token_type_ids"].data_ptr()
+                a.labels, a.cau_labels, a.emo_labels = lab.data_ptr(), cau.data_ptr(), emo.data_ptr()
+                a.bow_cols, a.bow_vals, a.idx, a.dst = cols.data_ptr(), vals.data_ptr(), idx.data_ptr(), slot["host"].data_ptr()
+                a.n_samples, a.batch, a.seq_len, a.bow_entries, a.emo_is_float = n_all, B, S, M, int(emo.dtype.is_floating_point)
+                a.off_input_ids, a.off_attention_masks, a.off_token_type_ids = lay["input_ids"][0], lay["attention_masks"][0], lay["token_type_ids"][0]
+                a.off_labels, a.off_cau_labels, a.off_emo_labels, a.off_trip = lay["labels"][0], lay["cau_labels"][0], lay["emo_labels"][0], lay["trip"][0]
+                L.check(lib.carel_host_pack_batch(C.byref(a)), "carel_host_pack_batch")
+                ship(slot, i, B * M, [bl.lengths[j] for j in idx.tolist()], None)
+
+        def producer_generic():
+            n = 0
+            nt = torch.get_num_threads()
+            for batch in self.loader:
+                if not acquire_slot():
+                    return
+                Bb, Sb = batch["input_ids"].shape
+                Vb = self._bow_dim(batch)
+                fits = self._slots is not None and (Sb, Vb) == (self._geom[1], self._geom[2]) and Bb <= self._geom[0]
+                if not fits:
+                    self._make_slots(batch)
+                if Bb != self._geom[0]:                    # short last batch (once per epoch): plain copies by the consumer
+                    q.put(dict(kind="plain", batch=batch))
+                    continue
+                i = n % self.depth
+                n += 1
+                slot = self._slots[i]
+                slot["copied"].synchronize()               # the previous H2D out of this staging block is done (host wait, this thread only)
+                torch.set_num_threads(1)                   # see BatchLoader: a spinning OpenMP pool starves the HIP runtime threads
+                nnz = self._pack(batch, slot)
+                torch.set_num_threads(nt)
+                ship(slot, i, nnz, batch.get("seq_lengths"), None if "seq_lengths" in batch else batch["attention_masks"])
+
+        def producer():
+            try:
+                (producer_native if isinstance(self.loader, BatchLoader) and self.loader._sparse is not None else producer_generic)()
             except BaseException as e:                          # surface loader errors in the consumer
                 q.put(e)
                 return
@@ -527,9 +580,11 @@ class PrefetchLoader:
         th = self._threading.Thread(target=producer, daemon=True)
         th.start()
         held = None
+        import sys
+        switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(switch, 2e-4))                # the two threads hand the interpreter lock over quickly
         try:
             while True:
-                item = q.get()
                 if held is not None:                            # all work on the previous batch has been enqueued by now
                     if held >= 0:
                         ev = torch.cuda.Event()
@@ -537,6 +592,7 @@ class PrefetchLoader:
                         self._slots[held]["released"] = ev
                     free.release()
                     held = None
+                item = q.get()
                 if item is None:
                     return
                 if isinstance(item, BaseException):
@@ -560,6 +616,7 @@ class PrefetchLoader:
                 held = item["slot"]
                 yield self._unpack(item)
         finally:
+            sys.setswitchinterval(switch)
             stop.set()
             th.join(timeout=2.0)
 

@@ -349,6 +349,22 @@ int carel_tail_backward_dz(const carel_tail_args* args, const void* grad_out_dev
  * non-zeros as triples -- trip = int32 rows[nnz], int32 cols[nnz], f32 vals[nnz], contiguous, distinct (row, col) -- are
  * expanded into the dense f32 [B, V] block the loss kernels read (zero fill + scatter, stream-ordered). */
 int carel_bow_expand(const void* trip, int32_t nnz, void* out_f32, int32_t B, int32_t V, void* stream);
+/* HOST function (no HIP call, no GIL when reached through ctypes): gather the dataset rows idx[0..batch) into one staging
+ * block of 4-byte words -- the seven tensors of a batch (ref :136-144, :823-830) back to back at the given word offsets
+ * (int64 fields 8-byte aligned), the bag-of-words targets as rows[B*M], cols[B*M] (-1 = padding), vals[B*M] at off_trip.
+ * Every source pointer is a HOST array stacked over the n_samples of the dataset. */
+typedef struct carel_host_pack_args {
+  const void* input_ids; const void* attention_masks; const void* token_type_ids;   /* int64 [n, S] */
+  const void* labels; const void* cau_labels;                                     /* f32 [n] */
+  const void* emo_labels;                                                         /* int64 [n] or f32 [n] (emo_is_float) */
+  const void* bow_cols; const void* bow_vals;                                     /* int32 / f32 [n, M] */
+  const int64_t* idx;                                                             /* [batch] sample indices */
+  void* dst;                                                                      /* staging block (page-locked) */
+  int64_t n_samples;
+  int32_t batch, seq_len, bow_entries, emo_is_float;
+  int64_t off_input_ids, off_attention_masks, off_token_type_ids, off_labels, off_cau_labels, off_emo_labels, off_trip;
+} carel_host_pack_args;
+int carel_host_pack_batch(const carel_host_pack_args* args);
 /* x[i] *= *scale_dev  (device scalar; used to apply loss.backward()'s grad_output without a host sync) */
 int carel_scale_f32(void* x_f32, int64_t n, const void* scale_dev_f32, void* stream);
 /* offset (in floats, inside `work`) of the flag carel_tail_losses sets to 1.0 when the pair loss was

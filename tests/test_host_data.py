@@ -146,3 +146,57 @@ def test_english_script_reader_and_dataset(name):
     assert item["emo_labels"].dtype == torch.float32 and float(item["emo_labels"]) == 1.0
     assert item["labels"].dtype == torch.float32 and item["input_ids"].shape == (32,)
     assert set(item) == {"input_ids", "attention_masks", "token_type_ids", "labels", "emo_labels", "cau_labels", "bow_reps"}
+
+
+def test_native_host_batch_packer_matches_the_stacked_arrays():
+    """carel_host_pack_batch (the GIL-free gather PrefetchLoader's background thread calls): every field of the staging block
+    equals the row gather of the dataset's stacked arrays; bag-of-words entry lists with -1 padding; repeated indices."""
+    import ctypes as C
+    import pandas as pd
+    from carel_vae_amd import _lib as L
+
+    class SynthDataset(D.ECPEDataset):
+        def __init__(self, n, V, seed):
+            b = D.synthetic_ecpe_batch(n, 16, 100, V, seed=seed, shape="B")
+            self.pairs = pd.Series(["x"] * n)
+            self.labels = b["labels"].view(-1).numpy(); self.emo_labels = b["emo_labels"].view(-1).numpy(); self.cau_labels = self.labels
+            self.max_len, self.bow_features, self.tokenizer = 16, [None] * V, object()
+            self.bow_representations = list(b["bow_reps"].numpy())
+            self._cache = (b["input_ids"], b["attention_masks"], b["token_type_ids"])
+    bl = D.BatchLoader(SynthDataset(50, 300, 1), batch_size=8).enable_sparse_bow()
+    f, (cols, vals, V) = bl.fields, bl._sparse
+    B, S, M = 8, 16, cols.shape[1]
+    # the entry lists reproduce the dense rows
+    dense = torch.zeros(50, V)
+    for r in range(50):
+        for m in range(M):
+            if int(cols[r, m]) >= 0:
+                dense[r, int(cols[r, m])] = vals[r, m]
+    assert torch.equal(dense, f["bow_reps"])
+    lay, words = D.PrefetchLoader.pack_layout(B, S, False, B * M)
+    assert all(o % 2 == 0 for o, _ in lay.values())               # int64 views need 8-byte alignment
+    dst = torch.full((words,), -7, dtype=torch.int32)
+    idx = torch.tensor([3, 49, 0, 7, 7, 12, 30, 41])
+    emo, lab, cau = (f[k].reshape(-1).contiguous() for k in ("emo_labels", "labels", "cau_labels"))
+    a = L.HostPackArgs()
+    a.input_ids, a.attention_masks, a.token_type_ids = (f[k].data_ptr() for k in ("input_ids", "attention_masks", "token_type_ids"))
+    a.labels, a.cau_labels, a.emo_labels = lab.data_ptr(), cau.data_ptr(), emo.data_ptr()
+    a.bow_cols, a.bow_vals, a.idx, a.dst = cols.data_ptr(), vals.data_ptr(), idx.data_ptr(), dst.data_ptr()
+    a.n_samples, a.batch, a.seq_len, a.bow_entries, a.emo_is_float = 50, B, S, M, 0
+    a.off_input_ids, a.off_attention_masks, a.off_token_type_ids = lay["input_ids"][0], lay["attention_masks"][0], lay["token_type_ids"][0]
+    a.off_labels, a.off_cau_labels, a.off_emo_labels, a.off_trip = lay["labels"][0], lay["cau_labels"][0], lay["emo_labels"][0], lay["trip"][0]
+    L.check(L.load().carel_host_pack_batch(C.byref(a)))
+    for k in ("input_ids", "attention_masks", "token_type_ids"):
+        o, n = lay[k]
+        assert torch.equal(dst[o:o + n].view(torch.int64).view(B, S), f[k][idx]), k
+    o, n = lay["emo_labels"]
+    assert torch.equal(dst[o:o + n].view(torch.int64), emo[idx])
+    o, n = lay["labels"]
+    assert torch.equal(dst[o:o + n].view(torch.float32), lab[idx])
+    o, _ = lay["trip"]
+    nn = B * M
+    assert torch.equal(dst[o:o + nn].view(B, M), torch.arange(B, dtype=torch.int32).view(B, 1).expand(B, M))
+    assert torch.equal(dst[o + nn:o + 2 * nn].view(B, M), cols[idx])
+    assert torch.equal(dst[o + 2 * nn:o + 3 * nn].view(torch.float32).view(B, M), vals[idx])
+    idx[0] = 50
+    assert L.load().carel_host_pack_batch(C.byref(a)) != 0        # out-of-range index is refused, not read
