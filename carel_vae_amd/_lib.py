@@ -127,7 +127,8 @@ class HostPackArgs(C.Structure):
                 ("idx", C.c_void_p), ("dst", C.c_void_p), ("n_samples", C.c_int64), ("batch", C.c_int32), ("seq_len", C.c_int32),
                 ("bow_entries", C.c_int32), ("emo_is_float", C.c_int32), ("off_input_ids", C.c_int64), ("off_attention_masks", C.c_int64),
                 ("off_token_type_ids", C.c_int64), ("off_labels", C.c_int64), ("off_cau_labels", C.c_int64), ("off_emo_labels", C.c_int64),
-                ("off_trip", C.c_int64)]
+                ("off_trip", C.c_int64), ("lengths", C.c_void_p), ("batch_padded", C.c_int32), ("off_cu", C.c_int64), ("off_tok", C.c_int64),
+                ("t_eff", C.c_int64), ("t_pad", C.c_int64)]
 
 
 class HsicArgs(C.Structure):

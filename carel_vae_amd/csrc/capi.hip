@@ -44,7 +44,7 @@ extern "C" int carel_init(int device) {
 // through ctypes, i.e. WITHOUT the Python GIL, from the loader's background thread -- a Python-level gather there would
 // fight the training thread for the interpreter lock.
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" int carel_host_pack_batch(const carel_host_pack_args* a) {
+extern "C" int carel_host_pack_batch(carel_host_pack_args* a) {
   if (!a || !a->idx || !a->dst || !a->input_ids || !a->attention_masks || !a->token_type_ids || !a->labels || !a->cau_labels || !a->emo_labels ||
       !a->bow_cols || !a->bow_vals)
     return set_error(CAREL_ERR_ARG, "carel_host_pack_batch: null pointer");
@@ -72,6 +72,27 @@ extern "C" int carel_host_pack_batch(const carel_host_pack_args* a) {
     for (int m = 0; m < M; ++m) rows[(size_t)b * M + m] = b;
     memcpy(cols + (size_t)b * M, (const int32_t*)a->bow_cols + (size_t)i * M, (size_t)M * 4);
     memcpy(vals + (size_t)b * M, (const float*)a->bow_vals + (size_t)i * M, (size_t)M * 4);
+  }
+  a->t_eff = 0; a->t_pad = 0;
+  if (a->lengths) {
+    // token packing of the batch (DrlClassifier._pack_info): cu[b] = first packed row of sample b (samples past B repeat
+    // the total), tok[t] = original row b*S + s of packed row t, -1 for the filler rows up to the next multiple of 128
+    if (a->batch_padded < B) return set_error(CAREL_ERR_ARG, "carel_host_pack_batch: batch_padded < batch");
+    int32_t* cu = w + a->off_cu;
+    int32_t* tok = w + a->off_tok;
+    long t = 0;
+    for (int b = 0; b < B; ++b) {
+      long len = ((const int32_t*)a->lengths)[a->idx[b]];
+      if (len < 0) len = 0;
+      if (len > S) len = S;
+      cu[b] = (int32_t)t;
+      for (long sidx = 0; sidx < len; ++sidx) tok[t + sidx] = (int32_t)((long)b * S + sidx);
+      t += len;
+    }
+    for (int b = B; b <= a->batch_padded; ++b) cu[b] = (int32_t)t;
+    const long tp = (t + 127) / 128 * 128;
+    for (long x = t; x < tp; ++x) tok[x] = -1;                  // the region holds roundup128(B * S) entries
+    a->t_eff = t; a->t_pad = tp;
   }
   return CAREL_OK;
 }

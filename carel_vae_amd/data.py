@@ -370,6 +370,13 @@ def synthetic_ecpe_batch(B, S, vocab_size, V, seed=1, shape="A", pad_id=0, first
 # ----------------------------------------------------------------------------------------------
 # PrefetchLoader: the seven `.to(device)` copies of every step (ref :823-830) taken off the step's critical path
 # ----------------------------------------------------------------------------------------------
+class PackedLengths(list):
+    """The host list of attended lengths (what `seq_lengths=` takes) that ALSO carries the batch's token-packing arrays already
+    on the device (`cu`, `tok_row`, `n_tokens`, `t_eff`), so that the model has nothing to copy per step."""
+    cu = tok_row = None
+    n_tokens = t_eff = 0
+
+
 class PrefetchLoader:
     """Wraps a loader of dict batches (BatchLoader or a stock DataLoader over ECPEDataset) and yields the same batches with
     every tensor ALREADY ON THE DEVICE:
@@ -379,8 +386,8 @@ class PrefetchLoader:
         triples (a pair has 3-30 vocabulary words of V = 23 771: ~10 KB instead of 6 MB dense);
       * one async H2D copy per batch on a dedicated copy stream into a preallocated device slot; the training stream only
         waits for that copy's event and expands the triples on the device (`carel_bow_expand`);
-      * slots are recycled without a host sync: before slot s is overwritten the copy stream waits for the event the
-        consumer recorded when it asked for the batch AFTER the one in s (all work on s is enqueued before that).
+      * a slot is refilled only when the GPU is done with it (two event queries on the host; with `depth` slots the host may
+        run `depth` batches ahead of the GPU before that ever waits).
 
     The reference's loop body is unchanged: `batch[k].to(device, ...)` of a tensor that is already there is a no-op.
     A batch's tensors are views of a recycled device slot: they are valid until the NEXT batch is requested (what a training
@@ -418,6 +425,11 @@ class PrefetchLoader:
         take("cau_labels", B)
         take("emo_labels", B if emo_is_float else 2 * B)
         take("trip", 3 * nnz_cap)
+        Bp = B
+        while (Bp * S) % 128:
+            Bp += 1
+        take("cu", Bp + 1)                                    # token packing (filled by the native packer only)
+        take("tok", (B * S + 127) // 128 * 128)
         return lay, o
 
     @staticmethod
@@ -480,71 +492,75 @@ class PrefetchLoader:
 
     # ---- iteration ----------------------------------------------------------------------------
     def __iter__(self):
+        """Who does what (measured, tools/bench_train_epoch.py, one ECPE-sized epoch: 0.29 s with a plain BatchLoader):
+          * BatchLoader underneath: NO thread.  The batch is assembled by one C call (~30 us) in the consuming thread, one
+            batch ahead of use, and copied by the copy stream while the current step runs: 0.28 s.
+          * any other loader (a stock DataLoader's Python collate takes ~1.2 ms per batch): a background thread runs the
+            wrapped loader and packs; it does CPU work only.  EVERY HIP call (the async copy, the events) is still issued by
+            the consuming thread: a second thread calling into the HIP runtime while the training thread launches ~450
+            kernels per step made the epoch 1.8x slower (0.53 s), with a short or the default GIL switch interval, with
+            hipEventSynchronize or with polling; a CPU-only thread costs ~10 % (0.33 s) in interpreter-lock hand-overs."""
+        import collections
         import queue
         q = queue.Queue()
-        free = self._threading.Semaphore(self.depth)         # free slots; the consumer hands its slot back when it asks for the next batch
+        free = self._threading.Semaphore(self.depth)          # staging blocks the producer may fill
         stop = self._threading.Event()
 
         def acquire_slot():
-            # a slot is written only after the consumer has handed it back (host handshake); its device half additionally
-            # waits, stream-side, for the event the consumer recorded at that moment
             while not free.acquire(timeout=0.05):
                 if stop.is_set():
                     return False
             return not stop.is_set()
 
-        def ship(slot, i, nnz, lengths, att_host):
-            with torch.cuda.stream(self._copy_stream):
-                if slot["released"] is not None:
-                    self._copy_stream.wait_event(slot["released"])
-                slot["dev"].copy_(slot["host"], non_blocking=True)
-                slot["copied"].record(self._copy_stream)
-            q.put(dict(kind="slot", slot=i, nnz=nnz, lengths=lengths, att_host=att_host))
-
-        def producer_native():
-            """BatchLoader underneath: the batch is gathered from the dataset's stacked arrays by ONE C call (GIL released)."""
+        def native_items():
+            """BatchLoader underneath: the batch is gathered from the dataset's stacked arrays by ONE C call."""
             from . import _lib as L
             import ctypes as C
+            import time
             bl = self.loader
             f, (cols, vals, V) = bl.fields, bl._sparse
             n_all, S = f["input_ids"].shape
             B, M = bl.batch_size, cols.shape[1]
             emo = f["emo_labels"].reshape(-1).contiguous()
             lab, cau = f["labels"].reshape(-1).contiguous(), f["cau_labels"].reshape(-1).contiguous()
-            keep = (emo, lab, cau)                               # noqa: F841  (the C call reads these buffers)
             order = bl._order().to(torch.int64).contiguous()
             lib = L.load()
+            lay = self._geom[5] if self._slots is not None else None
+            a = L.HostPackArgs()
+            a.input_ids, a.attention_masks, a.token_type_ids = f["input_ids"].data_ptr(), f["attention_masks"].data_ptr(), f["token_type_ids"].data_ptr()
+            a.labels, a.cau_labels, a.emo_labels = lab.data_ptr(), cau.data_ptr(), emo.data_ptr()
+            a.bow_cols, a.bow_vals = cols.data_ptr(), vals.data_ptr()
+            a.n_samples, a.batch, a.seq_len, a.bow_entries, a.emo_is_float = n_all, B, S, M, int(emo.dtype.is_floating_point)
+            lens32 = torch.as_tensor(bl.lengths, dtype=torch.int32)
+            Bp = B
+            while (Bp * S) % 128:
+                Bp += 1
+            a.lengths, a.batch_padded = lens32.data_ptr(), Bp
+            if lay is not None:
+                a.off_cu, a.off_tok = lay["cu"][0], lay["tok"][0]
+                a.off_input_ids, a.off_attention_masks, a.off_token_type_ids = lay["input_ids"][0], lay["attention_masks"][0], lay["token_type_ids"][0]
+                a.off_labels, a.off_cau_labels, a.off_emo_labels, a.off_trip = lay["labels"][0], lay["cau_labels"][0], lay["emo_labels"][0], lay["trip"][0]
             n = 0
             for s0 in range(0, n_all, B):
                 idx = order[s0:s0 + B].contiguous()
                 if idx.numel() < B:
                     if bl.drop_last:
-                        break
-                    if not acquire_slot():
                         return
                     b = {k: t.index_select(0, idx) for k, t in f.items() if k != "bow_reps"}
                     b.update(bow_cols=cols.index_select(0, idx), bow_vals=vals.index_select(0, idx), bow_dim=V,
                              seq_lengths=[bl.lengths[i] for i in idx.tolist()])
-                    q.put(dict(kind="plain", batch=b))
+                    yield dict(kind="plain", batch=b)
                     continue
-                if not acquire_slot():
-                    return
-                if self._slots is None or self._geom[:3] != (B, S, V) or self._geom[4] != B * M:
-                    self._make_slots(dict(input_ids=f["input_ids"][:B], emo_labels=f["emo_labels"][:B], bow_cols=cols[:B], bow_dim=V))
                 i = n % self.depth
                 n += 1
                 slot = self._slots[i]
-                slot["copied"].synchronize()
-                lay = self._geom[5]
-                a = L.HostPackArgs()
-                a.input_ids, a.attention_masks, a.token_type_ids = f["input_ids"].data_ptr(), f["attention_masks"].data_ptr(), f["token_type_ids"].data_ptr()
-                a.labels, a.cau_labels, a.emo_labels = lab.data_ptr(), cau.data_ptr(), emo.data_ptr()
-                a.bow_cols, a.bow_vals, a.idx, a.dst = cols.data_ptr(), vals.data_ptr(), idx.data_ptr(), slot["host"].data_ptr()
-                a.n_samples, a.batch, a.seq_len, a.bow_entries, a.emo_is_float = n_all, B, S, M, int(emo.dtype.is_floating_point)
-                a.off_input_ids, a.off_attention_masks, a.off_token_type_ids = lay["input_ids"][0], lay["attention_masks"][0], lay["token_type_ids"][0]
-                a.off_labels, a.off_cau_labels, a.off_emo_labels, a.off_trip = lay["labels"][0], lay["cau_labels"][0], lay["emo_labels"][0], lay["trip"][0]
+                while not self._slot_idle(slot):               # the host is `depth` batches ahead of the GPU: let it catch up
+                    time.sleep(1e-4)
+                a.idx, a.dst = idx.data_ptr(), slot["host"].data_ptr()
                 L.check(lib.carel_host_pack_batch(C.byref(a)), "carel_host_pack_batch")
-                ship(slot, i, B * M, [bl.lengths[j] for j in idx.tolist()], None)
+                lens = PackedLengths(bl.lengths[j] for j in idx.tolist())
+                lens.t_eff, lens.n_tokens = int(a.t_eff), int(a.t_pad)
+                yield dict(kind="slot", slot=i, nnz=B * M, lengths=lens, att_host=None)
 
         def producer_generic():
             n = 0
@@ -552,49 +568,106 @@ class PrefetchLoader:
             for batch in self.loader:
                 if not acquire_slot():
                     return
-                Bb, Sb = batch["input_ids"].shape
-                Vb = self._bow_dim(batch)
-                fits = self._slots is not None and (Sb, Vb) == (self._geom[1], self._geom[2]) and Bb <= self._geom[0]
-                if not fits:
-                    self._make_slots(batch)
+                Bb = batch["input_ids"].shape[0]
                 if Bb != self._geom[0]:                    # short last batch (once per epoch): plain copies by the consumer
                     q.put(dict(kind="plain", batch=batch))
                     continue
                 i = n % self.depth
                 n += 1
-                slot = self._slots[i]
-                slot["copied"].synchronize()               # the previous H2D out of this staging block is done (host wait, this thread only)
                 torch.set_num_threads(1)                   # see BatchLoader: a spinning OpenMP pool starves the HIP runtime threads
-                nnz = self._pack(batch, slot)
+                nnz = self._pack(batch, self._slots[i])
                 torch.set_num_threads(nt)
-                ship(slot, i, nnz, batch.get("seq_lengths"), None if "seq_lengths" in batch else batch["attention_masks"])
+                q.put(dict(kind="slot", slot=i, nnz=nnz, lengths=batch.get("seq_lengths"),
+                           att_host=None if "seq_lengths" in batch else batch["attention_masks"]))
+
+        native = isinstance(self.loader, BatchLoader) and self.loader._sparse is not None
 
         def producer():
             try:
-                (producer_native if isinstance(self.loader, BatchLoader) and self.loader._sparse is not None else producer_generic)()
+                producer_generic()
             except BaseException as e:                          # surface loader errors in the consumer
                 q.put(e)
                 return
             q.put(None)
 
-        th = self._threading.Thread(target=producer, daemon=True)
-        th.start()
-        held = None
-        import sys
-        switch = sys.getswitchinterval()
-        sys.setswitchinterval(min(switch, 2e-4))                # the two threads hand the interpreter lock over quickly
+        # the slots exist before the thread starts (device allocations and page-locking belong to the consuming thread)
+        if native:
+            bl = self.loader
+            f, (cols, vals, V) = bl.fields, bl._sparse
+            B, S, M = bl.batch_size, f["input_ids"].shape[1], cols.shape[1]
+            if len(bl.dataset) >= B and (self._slots is None or self._geom[:3] != (B, S, V) or self._geom[4] != B * M):
+                self._make_slots(dict(input_ids=f["input_ids"][:B], emo_labels=f["emo_labels"][:B], bow_cols=cols[:B], bow_dim=V))
+        else:
+            it = iter(self.loader)
+            try:
+                first = next(it)
+            except StopIteration:
+                return
+            if self._slots is None or (first["input_ids"].shape[1], self._bow_dim(first)) != (self._geom[1], self._geom[2]) or first["input_ids"].shape[0] > self._geom[0]:
+                self._make_slots(first)
+            del it, first                                        # (re-iterated by the producer: loaders here are re-iterable)
+        th = None
+        if native:
+            src = native_items()
+        else:
+            th = self._threading.Thread(target=producer, daemon=True)
+            th.start()
+        issued = collections.deque()        # items whose H2D copy has been enqueued (consumed in order)
+        parked = []                         # staging blocks handed back by the training loop that their copy may still be reading
+        held, done = None, False
+        main = torch.cuda.current_stream(self.device)
+
+        def poll_parked():
+            freed = [x for x in parked if self._slot_idle(self._slots[x])]
+            for sl in freed:
+                parked.remove(sl)
+                free.release()
+            return bool(freed)
+
+        def next_item(block):
+            """-> an item, None at the end of the epoch, or queue.Empty (class) when nothing is ready and block is False"""
+            if native:
+                return next(src, None)
+            while True:
+                try:
+                    return q.get(timeout=1e-3) if block else q.get_nowait()
+                except queue.Empty:
+                    if not block:
+                        return queue.Empty
+                    poll_parked()                               # the producer may be waiting for a staging block
+
+        def issue(item):
+            if isinstance(item, dict) and item["kind"] == "slot":
+                slot = self._slots[item["slot"]]
+                with torch.cuda.stream(self._copy_stream):        # (the slot is idle: _slot_idle was true before it was packed)
+                    slot["dev"].copy_(slot["host"], non_blocking=True)
+                    slot["copied"].record(self._copy_stream)
+            issued.append(item)
+
         try:
             while True:
                 if held is not None:                            # all work on the previous batch has been enqueued by now
                     if held >= 0:
                         ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream(self.device))
+                        ev.record(main)
                         self._slots[held]["released"] = ev
-                    free.release()
+                        if not native:
+                            parked.append(held)
+                    elif not native:
+                        free.release()
                     held = None
-                item = q.get()
-                if item is None:
+                poll_parked()
+                while not done and len(issued) < 2:             # keep one batch's copy in flight behind the one being consumed
+                    item = next_item(block=not issued)
+                    if item is queue.Empty:
+                        break
+                    if item is None:
+                        done = True
+                    else:
+                        issue(item)
+                if not issued:
                     return
+                item = issued.popleft()
                 if isinstance(item, BaseException):
                     raise item
                 if item["kind"] == "plain":
@@ -616,9 +689,19 @@ class PrefetchLoader:
                 held = item["slot"]
                 yield self._unpack(item)
         finally:
-            sys.setswitchinterval(switch)
             stop.set()
-            th.join(timeout=2.0)
+            if th is not None:
+                th.join(timeout=2.0)
+
+    @staticmethod
+    def _slot_idle(slot):
+        """True when the GPU is done with both halves of a slot: the copy out of its staging block and every kernel that read
+        its device block (`released`, recorded when the training loop asked for the following batch).  Checked on the HOST
+        before the slot is refilled.  A stream-side wait instead (copy stream waits for `released`) was measured to make
+        the epoch 1.9x slower once the host runs ahead of the GPU: HIP multiplexes streams onto 4 hardware queues, and the
+        barrier packet parks whatever shares the copy stream's queue -- here the weight-gradient side stream -- until a step
+        from several steps ago has finished."""
+        return slot["copied"].query() and (slot["released"] is None or slot["released"].query())
 
     def _unpack(self, item):
         from . import ops
@@ -639,4 +722,10 @@ class PrefetchLoader:
         nnz = item["nnz"]
         out["bow_reps"] = ops.bow_expand(d[o:o + 3 * nnz] if nnz else d[o:o], nnz, slot["bow"])
         out["seq_lengths"] = item["lengths"] if item["lengths"] is not None else item["att_host"].sum(1).tolist()
+        if isinstance(out["seq_lengths"], PackedLengths) and out["seq_lengths"].n_tokens:
+            pl = out["seq_lengths"]
+            o, n = lay["cu"]
+            pl.cu = d[o:o + n]
+            o, _ = lay["tok"]
+            pl.tok_row = d[o:o + pl.n_tokens]
         return out

@@ -612,6 +612,9 @@ class DrlClassifier(nn.Module):
         t_eff = sum(lens_l)
         if t_eff == B * S:
             return None
+        if getattr(seq_lengths, "cu", None) is not None and seq_lengths.t_eff == t_eff and seq_lengths.cu.numel() == Bp + 1:
+            # carel_vae_amd.data.PrefetchLoader shipped the packing arrays with the batch: nothing to build or copy here
+            return SimpleNamespace(n_tokens=seq_lengths.n_tokens, t_eff=t_eff, cu=seq_lengths.cu, tok_row=seq_lengths.tok_row)
         t_pad = (t_eff + 127) // 128 * 128
         lens_a = np.asarray(lens_l, dtype=np.int64)
         cu = np.zeros(Bp + 1, dtype=np.int32)

@@ -363,8 +363,15 @@ typedef struct carel_host_pack_args {
   int64_t n_samples;
   int32_t batch, seq_len, bow_entries, emo_is_float;
   int64_t off_input_ids, off_attention_masks, off_token_type_ids, off_labels, off_cau_labels, off_emo_labels, off_trip;
+  /* optional token packing (padding skipped, carel_encoder_args.tok_row / cu_seqlens): lengths = int32 [n] attended
+   * length of every sample; writes cu_seqlens int32 [batch_padded + 1] at off_cu and tok_row int32 [<= batch*seq_len rounded up to 128] at
+   * off_tok, returns the attended-token count and its round-up to 128 in t_eff / t_pad.  lengths = NULL: skipped. */
+  const void* lengths;
+  int32_t batch_padded;
+  int64_t off_cu, off_tok;
+  int64_t t_eff, t_pad;                                                           /* out */
 } carel_host_pack_args;
-int carel_host_pack_batch(const carel_host_pack_args* args);
+int carel_host_pack_batch(carel_host_pack_args* args);
 /* x[i] *= *scale_dev  (device scalar; used to apply loss.backward()'s grad_output without a host sync) */
 int carel_scale_f32(void* x_f32, int64_t n, const void* scale_dev_f32, void* stream);
 /* offset (in floats, inside `work`) of the flag carel_tail_losses sets to 1.0 when the pair loss was

@@ -149,3 +149,33 @@ def test_prefetch_loader_around_batch_loader_ships_entry_lists():
                 assert got[k].is_cuda and torch.equal(got[k].cpu(), v), (n, k)
         n += 1
     assert n == len(want) == 5
+
+
+def test_train_driver_with_prefetch_loader_reproduces_the_batch_loader_run():
+    """The reference's driver loop fed by PrefetchLoader (device-resident batches, packing arrays shipped with the batch) gives
+    the same weights as the same loop fed by the BatchLoader it wraps: same batches, same packed-token path, same bits."""
+    import pandas as pd
+
+    class SynthDataset(D.ECPEDataset):
+        def __init__(self, n, V, seed):
+            b = D.synthetic_ecpe_batch(n, 32, 300, V, seed=seed, shape="B")
+            self.pairs = pd.Series(["x"] * n)
+            self.labels = b["labels"].view(-1).numpy(); self.emo_labels = b["emo_labels"].view(-1).numpy(); self.cau_labels = self.labels
+            self.max_len, self.bow_features, self.tokenizer = 32, [None] * V, object()
+            self.bow_representations = list(b["bow_reps"].numpy())
+            self._cache = (b["input_ids"], b["attention_masks"], b["token_type_ids"])
+    V = 257
+    tr_ds, te_ds = SynthDataset(72, V, 11), SynthDataset(24, V, 12)
+    outs = []
+    for wrap in (False, True):
+        opt = M.make_opt(epochs=1, pair_bow_dim=V, best_model_path="/tmp/carel_ckpt_pf", model_id="pf", dropout=0.0)
+        model = M.DrlClassifier(opt, M.encoder_config("zh", vocab_size=300, layers=2, hidden_dropout=0.0, attn_dropout=0.0), seed=3).to("cuda")
+        optim = M.FusedAdam(model, lr=1e-3)
+        tr = D.BatchLoader(tr_ds, batch_size=16, shuffle=False)
+        if wrap:
+            tr = D.PrefetchLoader(tr, "cuda", depth=2)
+        torch.manual_seed(5)                                   # the reparameterisation noise stream
+        T.train(tr, D.BatchLoader(te_ds, batch_size=24), model, [optim], "cuda", num_unpred_pairs=0, opt=opt, log=lambda *_: None)
+        outs.append({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

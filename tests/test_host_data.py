@@ -198,5 +198,17 @@ def test_native_host_batch_packer_matches_the_stacked_arrays():
     assert torch.equal(dst[o:o + nn].view(B, M), torch.arange(B, dtype=torch.int32).view(B, 1).expand(B, M))
     assert torch.equal(dst[o + nn:o + 2 * nn].view(B, M), cols[idx])
     assert torch.equal(dst[o + 2 * nn:o + 3 * nn].view(torch.float32).view(B, M), vals[idx])
+    # token packing arrays: the same cu / tok_row DrlClassifier._pack_info builds from the length list
+    lens = torch.as_tensor(bl.lengths, dtype=torch.int32)
+    a.lengths, a.batch_padded, a.off_cu, a.off_tok = lens.data_ptr(), 8, lay["cu"][0], lay["tok"][0]
+    L.check(L.load().carel_host_pack_batch(C.byref(a)))
+    ll = [bl.lengths[i] for i in idx.tolist()]
+    t_eff = sum(ll)
+    assert a.t_eff == t_eff and a.t_pad == (t_eff + 127) // 128 * 128
+    cu = dst[lay["cu"][0]:lay["cu"][0] + 9]
+    assert cu.tolist() == [sum(ll[:b]) for b in range(8)] + [t_eff]
+    tok = dst[lay["tok"][0]:lay["tok"][0] + min(int(a.t_pad), B * S)]
+    want = [b * S + s_ for b in range(8) for s_ in range(ll[b])]
+    assert tok[:t_eff].tolist() == want and (tok[t_eff:] == -1).all()
     idx[0] = 50
     assert L.load().carel_host_pack_batch(C.byref(a)) != 0        # out-of-range index is refused, not read

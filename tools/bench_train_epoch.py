@@ -29,7 +29,8 @@ def main():
     opt = cv.make_opt(epochs=1, pair_bow_dim=V, best_model_path="/tmp/carel_ckpt", model_id="epoch")
     cv.training.save_ckp = lambda *a, **k: None          # the 400 MB checkpoint write (when F1 improves) is not what is measured
     train_ds, test_ds = SynthDataset(n_train, V, 1), SynthDataset(n_test, V, 2)
-    for name in ("DataLoader", "BatchLoader", "PrefetchLoader"):
+    names = os.environ.get("CAREL_LOADERS", "DataLoader,BatchLoader,PrefetchLoader").split(",")
+    for name in names:
         torch.manual_seed(0)
         model = cv.DrlClassifier(opt, cv.encoder_config("zh"), seed=0).to("cuda")
         optim = cv.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=True)
@@ -40,7 +41,7 @@ def main():
             tr = D.BatchLoader(train_ds, batch_size=64, shuffle=True)
             te = D.BatchLoader(test_ds, batch_size=len(test_ds), shuffle=False)
         else:       # pinned ring + copy stream + sparse bag-of-words around the same BatchLoader
-            tr = D.PrefetchLoader(D.BatchLoader(train_ds, batch_size=64, shuffle=True), "cuda", depth=3)
+            tr = D.PrefetchLoader(D.BatchLoader(train_ds, batch_size=64, shuffle=True), "cuda", depth=int(os.environ.get("CAREL_PREFETCH_DEPTH", "3")))
             te = D.BatchLoader(test_ds, batch_size=len(test_ds), shuffle=False)
         t0 = time.perf_counter()
         nb = sum(1 for _ in tr)
