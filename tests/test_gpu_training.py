@@ -153,7 +153,8 @@ def test_prefetch_loader_around_batch_loader_ships_entry_lists():
 
 def test_train_driver_with_prefetch_loader_reproduces_the_batch_loader_run():
     """The reference's driver loop fed by PrefetchLoader (device-resident batches, packing arrays shipped with the batch) gives
-    the same weights as the same loop fed by the BatchLoader it wraps: same batches, same packed-token path, same bits."""
+    the same weights as the same loop fed by the BatchLoader it wraps: same batches, same packed-token path (the embedding
+    backward accumulates with float atomics, so two runs of EITHER loader agree to fp32 summation order, not bit for bit)."""
     import pandas as pd
 
     class SynthDataset(D.ECPEDataset):
@@ -178,4 +179,5 @@ def test_train_driver_with_prefetch_loader_reproduces_the_batch_loader_run():
         T.train(tr, D.BatchLoader(te_ds, batch_size=24), model, [optim], "cuda", num_unpred_pairs=0, opt=opt, log=lambda *_: None)
         outs.append({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
     for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), k
+        a, b = outs[0][k].double(), outs[1][k].double()
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), k
