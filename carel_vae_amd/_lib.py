@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcarel_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CarelError(RuntimeError):
@@ -90,7 +90,8 @@ class AdamArgs(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("shadow_bf16", C.c_void_p), ("n", C.c_int64), ("step", C.c_int64),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("grad_scale", C.c_float), ("skip_lo", C.c_int64), ("skip_hi", C.c_int64), ("skip_flag", C.c_void_p)]
+                ("grad_scale", C.c_float), ("skip_lo", C.c_int64), ("skip_hi", C.c_int64), ("skip_flag", C.c_void_p),
+                ("grad_scale_dev", C.c_void_p), ("weight_decay", C.c_float), ("decay_segments", C.c_void_p), ("n_decay_segments", C.c_int32)]
 
 
 class LayerParams(C.Structure):
@@ -184,6 +185,10 @@ SIGNATURES = {
     "carel_profile_gemm": (C.c_int, [C.c_int32, C.c_int32]),
     "carel_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "carel_mean_pool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "carel_mean_pool_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "carel_triplet_semihard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_grad_norm_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_pdist_fwd": (C.c_int, [C.POINTER(PdistArgs), C.c_void_p]),

@@ -11,7 +11,16 @@ struct AdamArgs {
   long n;
   float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, grad_scale;
   long skip_lo, skip_hi; const float* skip_flag;     // [skip_lo, skip_hi) untouched when *skip_flag != 0
+  const float* grad_scale_dev;                       // optional device scalar multiplied into the gradient (clip coefficient)
+  float decay;                                       // AdamW: p *= decay (= 1 - lr * weight_decay) first, inside the decay segments
+  const long* seg; int nseg;                         // sorted [start, end) pairs (elements, multiples of 4) that take the decay
 };
+// is element i (a multiple of 4) inside one of the sorted decay segments?
+__device__ __forceinline__ bool adam_decays(const AdamArgs& a, long i) {
+  int lo = 0, hi = a.nseg;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.seg[2 * mid + 1] <= i) lo = mid + 1; else hi = mid; }
+  return lo < a.nseg && a.seg[2 * lo] <= i;
+}
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a) {
   g *= a.grad_scale;
@@ -23,11 +32,13 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   const bool skipping = a.skip_flag && a.skip_flag[0] != 0.f;
+  if (a.grad_scale_dev) a.grad_scale *= a.grad_scale_dev[0];
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (; i < a.n; i += stride) {
     if (i + 4 <= a.n) {
       float4 p = *(float4*)(a.p + i);
+      if (a.nseg > 0 && adam_decays(a, i)) { p.x *= a.decay; p.y *= a.decay; p.z *= a.decay; p.w *= a.decay; }   // param.mul_(1 - lr * weight_decay)
       const float4 g = *(const float4*)(a.g + i);
       float4 m = *(float4*)(a.m + i), v = *(float4*)(a.v + i);
       const bool s0 = skipping && i + 0 >= a.skip_lo && i + 0 < a.skip_hi, s1 = skipping && i + 1 >= a.skip_lo && i + 1 < a.skip_hi;
@@ -42,6 +53,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
       for (long j = i; j < a.n; ++j) {
         if (skipping && j >= a.skip_lo && j < a.skip_hi) continue;
         float p = a.p[j], m = a.m[j], v = a.v[j];
+        if (a.nseg > 0 && adam_decays(a, j & ~3L)) p *= a.decay;
         adam1(p, a.g[j], m, v, a);
         a.p[j] = p; a.m[j] = m; a.v[j] = v;
         if (a.shadow) a.shadow[j] = f2bf(p);
@@ -100,6 +112,10 @@ extern "C" int carel_adam_step(const carel_adam_args* a, void* stream_) {
   k.lr_over_bc1 = (float)((double)a->lr / bc1); k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   k.b1 = a->beta1; k.b2 = a->beta2; k.eps = a->eps; k.grad_scale = a->grad_scale == 0.f ? 1.f : a->grad_scale;
   k.skip_lo = a->skip_lo; k.skip_hi = a->skip_hi; k.skip_flag = (const float*)a->skip_flag;
+  k.grad_scale_dev = (const float*)a->grad_scale_dev;
+  k.decay = (float)(1.0 - (double)a->lr * (double)a->weight_decay);
+  k.seg = (const long*)a->decay_segments; k.nseg = a->decay_segments ? a->n_decay_segments : 0;
+  if (a->weight_decay != 0.f && !a->decay_segments) return set_error(CAREL_ERR_ARG, "carel_adam_step: weight_decay needs decay_segments");
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(k.n)), dim3(256), 0, stream, k);
   return check_launch("adam_kernel");
 }

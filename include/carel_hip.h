@@ -29,7 +29,7 @@ extern "C" {
 #define CAREL_ERR_HIP (-3)    /* a HIP runtime call or launch failed    */
 
 /* ABI version of this header; carel_abi_version() must return the same number. */
-#define CAREL_ABI_VERSION 1
+#define CAREL_ABI_VERSION 2
 
 int carel_abi_version(void);
 /* Checks that `device` is a gfx950 part and records nothing else.  ref: `model.to(device)` :932 */
@@ -394,12 +394,36 @@ typedef struct carel_adam_args {
   float lr, beta1, beta2, eps;
   float grad_scale;                   /* multiplies the gradient first (0 = 1.0) */
   int64_t skip_lo, skip_hi; const void* skip_flag;
+  /* AdamW / clipping (the sentence-transformer fine-tune, fit(): AdamW weight_decay 0.01 on weight matrices only,
+   * max_grad_norm 1): all optional, zero / NULL = plain Adam */
+  const void* grad_scale_dev;         /* device f32 scalar multiplied into the gradient as well (carel_grad_norm_clip's coefficient) */
+  float weight_decay;                 /* decoupled: param *= 1 - lr * weight_decay before the update, inside decay_segments */
+  const void* decay_segments;         /* device int64 [n_decay_segments][2]: sorted [start, end) element ranges relative to
+                                         `param` (multiples of 4) */
+  int32_t n_decay_segments;
 } carel_adam_args;
 int carel_adam_step(const carel_adam_args* args, void* stream);
 int carel_cast_f32_to_bf16(const void* src_f32, void* dst_bf16, int64_t n, void* stream);
 /* torch.optim.RMSprop(params, lr).step() with torch's defaults (alpha 0.99, eps 1e-8, no momentum, not centered): the
  * optimiser of the five discriminators of drl_classifier_en.py (:1056-1060).  fp32 only (the discriminators have no bf16 copy). */
 int carel_rmsprop_step(void* param_f32, const void* grad_f32, void* square_avg_f32, int64_t n, float lr, float alpha, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sentence-embedding fine-tuning (chi_ec_sentence_transformer.py / en_ec_sentence_transformer.py :22, :78, :84-87; the
+ * arithmetic is in the third-party `sentence_transformers`, absent here: parity unpinned, oracle/carel_oracle_st.py restates
+ * the published algorithm).  fp32.
+ *   carel_mean_pool_*: Pooling(mode "mean") over the attended tokens of the last hidden states x f32 [rows, hidden]:
+ *     sample b owns rows row0[b] .. row0[b] + len[b] (prefix-form masks); backward writes EVERY row of dx (zeros outside).
+ *   carel_triplet_semihard: losses.BatchSemiHardTripletLoss(model, margin), Euclidean distance, forward and (demb != NULL)
+ *     the gradient w.r.t. the embeddings for upstream gradient 1; batch <= 64; labels int32.
+ *   carel_grad_norm_clip: out2 = {||grad||_2, min(1, max_norm / (norm + 1e-6))} (torch.nn.utils.clip_grad_norm_);
+ *     scratch = 1024 floats; pass out2 + 1 as carel_adam_args.grad_scale_dev.
+ * ---------------------------------------------------------------------------------------------- */
+int carel_mean_pool_fwd(const void* x_f32, const void* row0_i32, const void* len_i32, int32_t batch, int32_t hidden, void* out_f32, void* stream);
+int carel_mean_pool_bwd(const void* g_f32, const void* row_sample_i32, const void* len_i32, int64_t rows, int32_t hidden, void* dx_f32, void* stream);
+int carel_triplet_semihard(const void* emb_f32, const void* labels_i32, int32_t batch, int32_t hidden, float margin, void* loss_out_f32,
+                           void* demb_f32, void* stream);
+int carel_grad_norm_clip(const void* grad_f32, int64_t n, float max_norm, void* scratch_f32, void* out2_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RBF-MMD statistic.  Replaces MMDStatistic.__call__ (ref :547-569) + pdist (ref :580-589) and

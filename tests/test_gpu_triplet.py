@@ -1,0 +1,195 @@
+"""Sentence-embedding fine-tune (chi_ec_sentence_transformer.py :22, :78, :84-87) on the GPU against the restatement of the
+`sentence_transformers` package's published algorithm in oracle/carel_oracle_st.py.  PARITY UNPINNED: the package is absent
+here and the reference holds no outputs for this path; tolerances: fp32 kernels 1e-5..1e-4, bf16 encoder as in test_gpu_model."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from carel_vae_amd import _lib as L
+from carel_vae_amd import drl_classifier as M
+from carel_vae_amd import sentence_transformer as S
+from oracle import carel_oracle as O
+from oracle import carel_oracle_st as ST
+
+pytestmark = pytest.mark.gpu
+
+
+def relnorm(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+@pytest.mark.parametrize("B,classes,scale", [(16, 7, 1.0), (16, 2, 3.0), (5, 3, 0.2), (64, 8, 1.0), (12, 1, 1.0)])
+def test_triplet_kernel_loss_and_gradient(B, classes, scale):
+    g = torch.Generator().manual_seed(B * 10 + classes)
+    emb = torch.randn((B, 768), generator=g) * scale
+    labels = torch.randint(0, classes, (B,), generator=g)
+    for margin in (0.5, 4.45, 60.0):
+        e = emb.clone().requires_grad_(True)
+        want = ST.batch_semi_hard_triplet_loss(labels, e, margin)
+        if not torch.isfinite(want):           # no positive pair at all: 0/0 in the package; the kernel reports 0
+            continue
+        want.backward()
+        eg = emb.cuda().requires_grad_(True)
+        got = S._TripletFn.apply(eg, labels.to(torch.int32).cuda(), margin)
+        assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (margin, got.item(), want.item())
+        (2.5 * got).backward()
+        assert relnorm(eg.grad, 2.5 * e.grad) < 2e-4, margin
+
+
+def test_mean_pool_and_clip_and_adamw_kernels():
+    lib = L.load()
+    g = torch.Generator().manual_seed(1)
+    # mean pooling over ragged rows (packed layout: samples back to back, then filler rows)
+    lens = [5, 1, 32, 17]
+    rows = 128
+    x = torch.randn((rows, 768), generator=g).cuda()
+    row0 = torch.tensor(np.cumsum([0] + lens[:-1]), dtype=torch.int32).cuda()
+    ln = torch.tensor(lens, dtype=torch.int32).cuda()
+    out = torch.empty((4, 768), device="cuda")
+    L.check(lib.carel_mean_pool_fwd(x.data_ptr(), row0.data_ptr(), ln.data_ptr(), 4, 768, out.data_ptr(), L.current_stream()))
+    o = 0
+    for b, n in enumerate(lens):
+        assert torch.allclose(out[b], x[o:o + n].mean(0), rtol=1e-5, atol=1e-6)
+        o += n
+    rs = torch.full((rows,), -1, dtype=torch.int32)
+    o = 0
+    for b, n in enumerate(lens):
+        rs[o:o + n] = b
+        o += n
+    gout = torch.randn((4, 768), generator=g).cuda()
+    dx = torch.full((rows, 768), 7.0, device="cuda")
+    L.check(lib.carel_mean_pool_bwd(gout.data_ptr(), rs.cuda().data_ptr(), ln.data_ptr(), rows, 768, dx.data_ptr(), L.current_stream()))
+    o = 0
+    for b, n in enumerate(lens):
+        assert torch.allclose(dx[o:o + n], (gout[b] / n).expand(n, 768), rtol=1e-6, atol=0)
+        o += n
+    assert (dx[o:] == 0).all()
+    # clip coefficient
+    n = 1_000_003 // 4 * 4
+    grad = (torch.randn(n, generator=g) * 0.01).cuda()
+    scratch, out2 = torch.empty(1024, device="cuda"), torch.empty(2, device="cuda")
+    L.check(lib.carel_grad_norm_clip(grad.data_ptr(), n, 1.0, scratch.data_ptr(), out2.data_ptr(), L.current_stream()))
+    norm = float(grad.double().norm())
+    assert abs(out2[0].item() - norm) < 1e-5 * norm and abs(out2[1].item() - min(1.0, 1.0 / (norm + 1e-6))) < 1e-5
+    # AdamW with decay segments + device clip coefficient vs torch.optim.AdamW on the same two groups
+    n = 4096
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    segs = torch.tensor([[0, 1024], [2048, 3072]], dtype=torch.int64)
+    pd, pn = torch.nn.Parameter(torch.cat((p0[0:1024], p0[2048:3072]))), torch.nn.Parameter(torch.cat((p0[1024:2048], p0[3072:])))
+    ref = torch.optim.AdamW([{"params": [pd], "weight_decay": 0.01}, {"params": [pn], "weight_decay": 0.0}], lr=1e-2)
+    p, m_, v_ = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    coef = torch.tensor([0.0, 0.37], device="cuda")
+    for step in range(1, 4):
+        gs = g0 * step
+        pd.grad, pn.grad = torch.cat((gs[0:1024], gs[2048:3072])) * 0.37, torch.cat((gs[1024:2048], gs[3072:])) * 0.37
+        ref.step()
+        a = L.AdamArgs()
+        gd = gs.cuda()
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.n, a.step = p.data_ptr(), gd.data_ptr(), m_.data_ptr(), v_.data_ptr(), n, step
+        a.lr, a.beta1, a.beta2, a.eps, a.grad_scale = 1e-2, 0.9, 0.999, 1e-8, 1.0
+        a.grad_scale_dev, a.weight_decay, a.decay_segments, a.n_decay_segments = coef.data_ptr() + 4, 0.01, segs.cuda().data_ptr(), 2
+        L.check(lib.carel_adam_step(C.byref(a), L.current_stream()))
+        torch.cuda.synchronize()
+    want = torch.empty(n)
+    want[0:1024], want[2048:3072], want[1024:2048], want[3072:] = pd.data[:1024], pd.data[1024:], pn.data[:1024], pn.data[1024:]
+    assert torch.allclose(p.cpu(), want, rtol=2e-6, atol=2e-7)
+
+
+class CharTokenizer:
+    """HF encode_plus interface: [CLS]=101, one id per character, [SEP]=102, pad 0."""
+
+    def encode_plus(self, text, text_pair=None, add_special_tokens=True, max_length=32, padding="max_length", return_token_type_ids=True,
+                    truncation=True, return_attention_mask=True, return_tensors="pt"):
+        ids = [101] + [ord(c) % 150 + 120 for c in text][:max_length - 2] + [102]
+        att = [1] * len(ids) + [0] * (max_length - len(ids))
+        ids = ids + [0] * (max_length - len(ids))
+        t = lambda v: torch.tensor([v])
+        return {"input_ids": t(ids), "attention_mask": t(att), "token_type_ids": t([0] * max_length)}
+
+
+def _setup(dropout=0.0):
+    cfg = O.EncoderConfig(layers=2, vocab_size=300)
+    opt = O.Opt(pair_bow_dim=8)
+    P = O.init_params(cfg, opt, seed=5)
+    mcfg = M.encoder_config("zh", vocab_size=300, layers=2, hidden_dropout=dropout, attn_dropout=dropout)
+    model = S.SentenceTransformer(mcfg, tokenizer=CharTokenizer(), max_seq_length=32)
+    model.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")})
+    model.to("cuda")
+    rs = np.random.RandomState(3)
+    sents = ["".join(chr(0x4E00 + int(c)) for c in rs.randint(0, 200, size=rs.randint(2, 29))) for _ in range(48)]
+    labels = rs.randint(0, 4, size=48).tolist()
+    return cfg, P, model, sents, labels
+
+
+def test_embeddings_and_three_fit_steps_against_the_restatement():
+    cfg, P, model, sents, labels = _setup()
+    feats = model.tokenize(sents[:16])
+    b = dict(input_ids=feats["input_ids"], attention_masks=feats["attention_mask"], token_type_ids=feats["token_type_ids"])
+    want = ST.encode(P, b["input_ids"], b["attention_masks"], b["token_type_ids"], cfg)
+    got = torch.from_numpy(model.encode(sents[:16], batch_size=16))
+    assert relnorm(got, want) < 1e-2                                   # bf16 encoder vs fp32 (2 layers: ~2e-3 measured on the VAE path)
+    want_q = ST.encode(P, b["input_ids"], b["attention_masks"], b["token_type_ids"], cfg, quant=O.bf16_round)
+    assert relnorm(got, want_q) < 4e-3                                 # vs the bf16-emulating oracle: the kernels themselves
+    # padding is skipped (packed rows) with identical embeddings
+    model._m.varlen = False
+    dense = torch.from_numpy(model.encode(sents[:16], batch_size=16))
+    model._m.varlen = True
+    assert relnorm(got, dense) < 1e-6
+    # three steps of fit(): loss values, gradient norm of the first step, direction and size of the weight update
+    examples = [S.InputExample(texts=[s], label=l) for s, l in zip(sents, labels)]
+    loader = torch.utils.data.DataLoader(examples, shuffle=False, batch_size=16)
+    loss = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45)
+    model.fit(train_objectives=[(loader, loss)], epochs=1, warmup_steps=1, optimizer_params={"lr": 1e-3}, output_path=None)
+    batches = []
+    for s in range(0, 48, 16):
+        f = model.tokenize(sents[s:s + 16])
+        batches.append(dict(input_ids=f["input_ids"], attention_masks=f["attention_mask"], token_type_ids=f["token_type_ids"],
+                            labels=torch.tensor(labels[s:s + 16])))
+    ref_losses, ref_norms, W = ST.fit_steps(P, batches, cfg, margin=4.45, lr=1e-3, warmup_steps=1, total_steps=3)
+    got_losses = model.last_fit.losses
+    assert abs(got_losses[0] - ref_losses[0]) <= 2e-3 * abs(ref_losses[0]), (got_losses, ref_losses)
+    for a_, b_ in zip(got_losses, ref_losses):                         # steps 2, 3 see weights that moved by bf16-noisy Adam updates
+        assert abs(a_ - b_) <= 2e-2 * abs(b_), (got_losses, ref_losses)
+    sd = model.state_dict()
+    moved = 0
+    for k in ("encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight", "embeddings.position_embeddings.weight",
+              "encoder.layer.1.output.LayerNorm.weight", "encoder.layer.0.intermediate.dense.bias"):
+        d_ref = W["encoder." + k] - P["encoder." + k]
+        d_got = sd[k].cpu() - P["encoder." + k]
+        assert float(d_ref.norm()) > 0
+        cos = float((d_ref.flatten() @ d_got.flatten()) / (d_ref.norm() * d_got.norm()))
+        assert cos > 0.9 and 0.8 < float(d_got.norm() / d_ref.norm()) < 1.25, (k, cos, float(d_got.norm() / d_ref.norm()))
+        moved += 1
+    assert moved == 5
+    # the pooler is not part of the sentence model's parameters and did not move
+    assert torch.equal(sd["pooler.dense.weight"].cpu(), P["encoder.pooler.dense.weight"])
+    assert "pooler.dense.weight" not in dict(model.named_parameters())
+
+
+def test_first_step_gradients_and_clip_norm_against_the_restatement():
+    cfg, P, model, sents, labels = _setup()
+    f = model.tokenize(sents[:16])
+    lab = torch.tensor(labels[:16])
+    model.train(True)
+    loss_mod = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45)
+    loss = loss_mod([f], lab)
+    loss.backward()
+    keys = ST.encoder_keys(P)
+    Wr = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in P.items()}
+    ref = ST.batch_semi_hard_triplet_loss(lab, ST.encode(Wr, f["input_ids"], f["attention_mask"], f["token_type_ids"], cfg), 4.45)
+    ref.backward()
+    named = dict(model.named_parameters())
+    worst = {}
+    for k in keys:
+        gr = Wr[k].grad
+        if gr is None or float(gr.norm()) < 1e-7:
+            continue
+        worst[k] = relnorm(named[k[len("encoder."):]].grad, gr)
+    assert max(worst.values()) < 6e-2 and float(np.median(list(worst.values()))) < 2e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    opt = S.FusedAdamW(model, lr=1e-3)
+    opt.step()
+    total = float(torch.sqrt(sum((Wr[k].grad.double() ** 2).sum() for k in keys if Wr[k].grad is not None)))
+    assert abs(opt.last_grad_norm().item() - total) <= 2e-2 * total
