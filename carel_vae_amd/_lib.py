@@ -91,7 +91,8 @@ class AdamArgs(C.Structure):
                 ("shadow_bf16", C.c_void_p), ("n", C.c_int64), ("step", C.c_int64),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("grad_scale", C.c_float), ("skip_lo", C.c_int64), ("skip_hi", C.c_int64), ("skip_flag", C.c_void_p),
-                ("grad_scale_dev", C.c_void_p), ("weight_decay", C.c_float), ("decay_segments", C.c_void_p), ("n_decay_segments", C.c_int32)]
+                ("grad_scale_dev", C.c_void_p), ("weight_decay", C.c_float), ("decay_segments", C.c_void_p), ("n_decay_segments", C.c_int32),
+                ("skip_count", C.c_void_p)]
 
 
 class LayerParams(C.Structure):

@@ -11,6 +11,8 @@ struct AdamArgs {
   long n;
   float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, grad_scale;
   long skip_lo, skip_hi; const float* skip_flag;     // [skip_lo, skip_hi) untouched when *skip_flag != 0
+  const float* skip_count;                           // optional device scalar: steps the skip range has been frozen so far
+  float lr, step;                                    //   -> its bias corrections use (step - *skip_count), like torch's per-parameter step
   const float* grad_scale_dev;                       // optional device scalar multiplied into the gradient (clip coefficient)
   float decay;                                       // AdamW: p *= decay (= 1 - lr * weight_decay) first, inside the decay segments
   const long* seg; int nseg;                         // sorted [start, end) pairs (elements, multiples of 4) that take the decay
@@ -30,9 +32,24 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
   p = p - a.lr_over_bc1 * (m / denom);                   // param.addcdiv_(exp_avg, denom, value=-lr/bc1)
 }
 
+// torch.optim.Adam keeps one step counter PER PARAMETER and does not advance it when the parameter's grad is None: the range
+// that can be frozen (the pair head) therefore has its own bias corrections once it has been frozen at least once
+__device__ __forceinline__ AdamArgs adam_range_args(const AdamArgs& a) {
+  AdamArgs r = a;
+  const float own = a.step - a.skip_count[0];
+  r.lr_over_bc1 = a.lr / (1.0f - powf(a.b1, own));
+  r.inv_sqrt_bc2 = 1.0f / sqrtf(1.0f - powf(a.b2, own));
+  return r;
+}
+
+__global__ void adam_skip_bump_kernel(const float* __restrict__ flag, float* __restrict__ count) {
+  if (flag[0] != 0.f) count[0] += 1.0f;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   const bool skipping = a.skip_flag && a.skip_flag[0] != 0.f;
   if (a.grad_scale_dev) a.grad_scale *= a.grad_scale_dev[0];
+  const bool own_steps = a.skip_count && a.skip_count[0] != 0.f && a.skip_hi > a.skip_lo;
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (; i < a.n; i += stride) {
@@ -43,10 +60,20 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
       float4 m = *(float4*)(a.m + i), v = *(float4*)(a.v + i);
       const bool s0 = skipping && i + 0 >= a.skip_lo && i + 0 < a.skip_hi, s1 = skipping && i + 1 >= a.skip_lo && i + 1 < a.skip_hi;
       const bool s2 = skipping && i + 2 >= a.skip_lo && i + 2 < a.skip_hi, s3 = skipping && i + 3 >= a.skip_lo && i + 3 < a.skip_hi;
-      if (!s0) adam1(p.x, g.x, m.x, v.x, a);
-      if (!s1) adam1(p.y, g.y, m.y, v.y, a);
-      if (!s2) adam1(p.z, g.z, m.z, v.z, a);
-      if (!s3) adam1(p.w, g.w, m.w, v.w, a);
+      if (own_steps && i + 3 >= a.skip_lo && i < a.skip_hi) {       // (rare: the few float4 groups that touch the pair head)
+        const AdamArgs r = adam_range_args(a);
+        const bool r0 = i + 0 >= a.skip_lo && i + 0 < a.skip_hi, r1 = i + 1 >= a.skip_lo && i + 1 < a.skip_hi;
+        const bool r2 = i + 2 >= a.skip_lo && i + 2 < a.skip_hi, r3 = i + 3 >= a.skip_lo && i + 3 < a.skip_hi;
+        if (!s0) adam1(p.x, g.x, m.x, v.x, r0 ? r : a);
+        if (!s1) adam1(p.y, g.y, m.y, v.y, r1 ? r : a);
+        if (!s2) adam1(p.z, g.z, m.z, v.z, r2 ? r : a);
+        if (!s3) adam1(p.w, g.w, m.w, v.w, r3 ? r : a);
+      } else {
+        if (!s0) adam1(p.x, g.x, m.x, v.x, a);
+        if (!s1) adam1(p.y, g.y, m.y, v.y, a);
+        if (!s2) adam1(p.z, g.z, m.z, v.z, a);
+        if (!s3) adam1(p.w, g.w, m.w, v.w, a);
+      }
       *(float4*)(a.p + i) = p; *(float4*)(a.m + i) = m; *(float4*)(a.v + i) = v;
       if (a.shadow) { uint2 o = {pack2bf(p.x, p.y), pack2bf(p.z, p.w)}; *(uint2*)(a.shadow + i) = o; }
     } else {
@@ -54,7 +81,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         if (skipping && j >= a.skip_lo && j < a.skip_hi) continue;
         float p = a.p[j], m = a.m[j], v = a.v[j];
         if (a.nseg > 0 && adam_decays(a, j & ~3L)) p *= a.decay;
-        adam1(p, a.g[j], m, v, a);
+        if (own_steps && j >= a.skip_lo && j < a.skip_hi) adam1(p, a.g[j], m, v, adam_range_args(a));
+        else adam1(p, a.g[j], m, v, a);
         a.p[j] = p; a.m[j] = m; a.v[j] = v;
         if (a.shadow) a.shadow[j] = f2bf(p);
       }
@@ -112,11 +140,14 @@ extern "C" int carel_adam_step(const carel_adam_args* a, void* stream_) {
   k.lr_over_bc1 = (float)((double)a->lr / bc1); k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   k.b1 = a->beta1; k.b2 = a->beta2; k.eps = a->eps; k.grad_scale = a->grad_scale == 0.f ? 1.f : a->grad_scale;
   k.skip_lo = a->skip_lo; k.skip_hi = a->skip_hi; k.skip_flag = (const float*)a->skip_flag;
+  k.skip_count = (const float*)a->skip_count; k.lr = a->lr; k.step = (float)a->step;
   k.grad_scale_dev = (const float*)a->grad_scale_dev;
   k.decay = (float)(1.0 - (double)a->lr * (double)a->weight_decay);
   k.seg = (const long*)a->decay_segments; k.nseg = a->decay_segments ? a->n_decay_segments : 0;
   if (a->weight_decay != 0.f && !a->decay_segments) return set_error(CAREL_ERR_ARG, "carel_adam_step: weight_decay needs decay_segments");
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(k.n)), dim3(256), 0, stream, k);
+  if (a->skip_count && a->skip_flag)       // after the update: one more frozen step on the range's record if this one was frozen
+    hipLaunchKernelGGL(adam_skip_bump_kernel, dim3(1), dim3(1), 0, stream, (const float*)a->skip_flag, (float*)a->skip_count);
   return check_launch("adam_kernel");
 }
 

@@ -334,7 +334,8 @@ class DrlClassifier(nn.Module):
         self.forward_chains = True           # dense batches: the two halves of the batch as two forward chains (results identical)
         self._fwd_count = 0
         self._noise = None
-        self._ws = {}
+        self._ws = {}                        # small per-shape buffers (tail, [CLS] index arrays)
+        self._enc_ws = {}                    # encoder activation / scratch workspaces, LRU-bounded (see _workspace)
         self._dp = None                     # set by carel_vae_amd.dp.DataParallel
         self._adam_hook = None              # set by FusedAdam(fuse_into_backward=True)
         self._flat = None
@@ -511,10 +512,14 @@ class DrlClassifier(nn.Module):
 
     def _workspace(self, B, S, inference):
         key = (B, S, bool(inference))
-        ws = self._ws.get(key)
+        ws = self._enc_ws.get(key)
+        if ws is not None:
+            self._enc_ws[key] = self._enc_ws.pop(key)             # most recently used last
         if ws is None:
-            if len(self._ws) >= 3:
-                self._ws.clear()
+            # encoder activations / scratch are GBs at B = 64: keep the four most recent (batch, seq, mode) shapes -- e.g. the
+            # training batch, the odd last batch and the evaluation chunk -- and drop only the least recently used one
+            while len(self._enc_ws) >= 4:
+                self._enc_ws.pop(next(iter(self._enc_ws)))
             lib = L.load()
             dev = self._flat.device
             ws = SimpleNamespace()
@@ -522,7 +527,7 @@ class DrlClassifier(nn.Module):
             # 0 * NaN from never-written memory would poison the MFMA sums; everything written later is finite
             ws.act = torch.zeros(lib.carel_encoder_act_bytes(B, S, self.cfg.layers, int(inference)), device=dev, dtype=torch.uint8)
             ws.scratch = torch.zeros(lib.carel_encoder_scratch_bytes(B, S), device=dev, dtype=torch.uint8)
-            self._ws[key] = ws
+            self._enc_ws[key] = ws
         return ws
 
     def _cls_info(self, B, Bp, S, pack, dev):
@@ -891,6 +896,7 @@ class FusedAdam:
         self.grad_scale = 1.0
         self.param_groups = [dict(params=self._params, lr=lr, betas=betas, eps=eps)]
         self._done = []                  # [lo, hi) ranges already updated for the coming step()
+        self._skip_count = None
         self._aux = None
         if fuse_into_backward:
             ptr = L.load().carel_side_stream(1)
@@ -924,6 +930,9 @@ class FusedAdam:
             a.skip_lo, a.skip_hi = m._pair_lo - lo, m._pair_hi - lo
             off = L.load().carel_tail_pair_dead_offset(call.B, m.opt.ec_dim, m.opt.pair_bow_dim)
             a.skip_flag = call.buf.work.data_ptr() + off * 4
+            if self._skip_count is None:       # frozen steps of the pair head so far (torch: that parameter's own step counter lags)
+                self._skip_count = torch.zeros(1, device=m._flat.device, dtype=torch.float32)
+            a.skip_count = self._skip_count.data_ptr()
         L.check(L.load().carel_adam_step(C.byref(a), stream), "carel_adam_step")
 
     def _layer_ready(self, layer, after=None):
@@ -958,9 +967,12 @@ class FusedAdam:
         m.mark_shadow_fresh()
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr)
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr,
+                    pair_head_frozen_steps=None if self._skip_count is None else self._skip_count.clone())
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        fr = sd.get("pair_head_frozen_steps")
+        self._skip_count = None if fr is None else fr.to(self.exp_avg.device, torch.float32).reshape(1).clone()

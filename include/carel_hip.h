@@ -401,6 +401,10 @@ typedef struct carel_adam_args {
   const void* decay_segments;         /* device int64 [n_decay_segments][2]: sorted [start, end) element ranges relative to
                                          `param` (multiples of 4) */
   int32_t n_decay_segments;
+  /* optional device f32 scalar owned by the caller (zero it once): how many steps [skip_lo, skip_hi) has been frozen so far.
+   * The range's bias corrections then use step - *skip_count (torch.optim.Adam advances a parameter's step counter only
+   * when it has a gradient), and the call adds 1 to it when *skip_flag != 0. */
+  void* skip_count;
 } carel_adam_args;
 int carel_adam_step(const carel_adam_args* args, void* stream);
 int carel_cast_f32_to_bf16(const void* src_f32, void* dst_bf16, int64_t n, void* stream);

@@ -130,7 +130,7 @@ SLICE_KEYS = [
 
 
 def run_case(name, cfg, opt, B, S, wseed, bseed, shape="A", steps=3, iteration0=3, all_negative=False,
-             grads=True):
+             grads=True, neg_steps=()):
     ns, model, P = build_reference_model(cfg, opt, wseed)
     batch = O.synthetic_batch(B, S, cfg, opt.pair_bow_dim, seed=bseed, shape=shape)
     if all_negative:
@@ -144,8 +144,14 @@ def run_case(name, cfg, opt, B, S, wseed, bseed, shape="A", steps=3, iteration0=
                versions=np.array(f"torch={torch.__version__};transformers={__import__('transformers').__version__}"))
     for k, v in batch.items():
         rec["in_" + k] = v.numpy()
+    # steps listed in neg_steps run the same batch with every pair label 0: the pair loss is replaced by the int 0 (:510-511),
+    # pair_classifier.grad stays None and torch.optim.Adam skips that parameter (its own step counter does not advance)
+    rec["neg_steps"] = np.array(list(neg_steps), dtype=np.int64)
+    batch_pos = batch
+    batch_neg = dict(batch, labels=torch.zeros_like(batch["labels"]), cau_labels=torch.zeros_like(batch["cau_labels"]))
     losses = []
     for s in range(steps):
+        batch = batch_neg if s in neg_steps else batch_pos
         torch.manual_seed(1000 + s)
         eps_e = torch.randn(opt.ec_dim)
         eps_c = torch.randn(opt.ec_dim)
@@ -246,8 +252,12 @@ def run_statistics():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    run_statistics()
     nodrop = dict(dropout=0.0)
+    if len(sys.argv) > 1 and sys.argv[1] == "zh_negmid":       # round-2 addition; the other fixtures are unchanged
+        run_case("zh_negmid", O.EncoderConfig(layers=1, vocab_size=500), O.Opt(pair_bow_dim=130, **nodrop),
+                 B=8, S=64, wseed=17, bseed=27, steps=4, neg_steps=(1,))
+        sys.exit(0)
+    run_statistics()
     run_case("zh_small", O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=257, **nodrop),
              B=8, S=128, wseed=11, bseed=21)
     run_case("zh_ragged", O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=513, **nodrop),

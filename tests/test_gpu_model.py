@@ -213,6 +213,45 @@ def test_three_step_adam_trajectory(golden_dir):
         assert torch.equal(sd[n].cpu(), P0[n])
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_adam_trajectory_with_an_all_negative_step_in_the_middle(golden_dir, fused):
+    """tests/golden/zh_negmid.npz: the reference's class for four steps, step 1 with every pair label 0 -- its pair loss is
+    the int 0 (:510-511), pair_classifier.grad is None and torch.optim.Adam skips that parameter WITHOUT advancing its own
+    step counter, so from step 2 on the pair head's bias corrections lag the other parameters' by one.  FusedAdam keeps
+    that count on the device (carel_adam_args.skip_count); with one global step count the pair head's two later updates
+    come out ~14 % short (2.5e-6 of a 1e-5 move), which the 8e-7 bound below catches.  Stock torch.optim.Adam on the same
+    model must agree too (the model leaves .grad None for the frozen head)."""
+    cfg, opt = O.EncoderConfig(layers=1, vocab_size=500), O.Opt(pair_bow_dim=130, dropout=0.0)
+    z, batch = load(golden_dir, "zh_negmid")
+    B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
+    neg = set(z["neg_steps"].tolist())
+    assert steps == 4 and neg == {1}
+    model, P = build(cfg, opt, wseed)
+    model.train()
+    optim = M.FusedAdam(model, lr=opt.vae_lr) if fused else torch.optim.Adam(model.get_params(), lr=opt.vae_lr)
+    batch_neg = dict(batch, labels=torch.zeros_like(batch["labels"]), cau_labels=torch.zeros_like(batch["cau_labels"]))
+    losses = []
+    for s in range(steps):
+        model.set_noise(torch.from_numpy(z[f"eps_e_{s}"]), torch.from_numpy(z[f"eps_c_{s}"]))
+        loss = model(*call(model, batch_neg if s in neg else batch, it0 + s))
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        losses.append(float(loss))
+    scale = 30 * 1.6 + 10 * 2.0 + 10 * 0.75 + 30 * 1.05
+    assert np.abs(np.array(losses) - z["losses"]).max() < 6e-3 * scale, (losses, z["losses"])
+    sd = model.state_dict()
+    for pk in ("pair_classifier.weight", "pair_classifier.bias"):
+        f = sd[pk].detach().cpu().reshape(-1)
+        n = 64
+        step = max(1, f.numel() // n)
+        got = torch.cat((f[:n], f[-n:], f[::step][:n])).numpy()
+        d = np.abs(got - z["w_" + pk])
+        assert np.median(d) <= 3e-7 and (d <= 8e-7).mean() >= 0.9, (pk, float(np.median(d)), float(d.max()))
+    if fused:
+        assert float(optim._skip_count) == 1.0
+
+
 def test_torch_adam_drop_in_and_dropout_parity(golden_dir):
     """torch.optim.Adam(model.get_params()) works unchanged; with dropout ON the HIP step equals the oracle
     fed the same counter-based masks."""

@@ -10,6 +10,7 @@ from oracle import carel_oracle as O
 
 CASES = {
     "zh_small": (O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=257, dropout=0.0)),
+    "zh_negmid": (O.EncoderConfig(layers=1, vocab_size=500), O.Opt(pair_bow_dim=130, dropout=0.0)),   # 4 steps, step 1 all-negative
     "zh_ragged": (O.EncoderConfig(layers=2, vocab_size=1000), O.Opt(pair_bow_dim=513, dropout=0.0)),
     "zh_allneg": (O.EncoderConfig(layers=1, vocab_size=500), O.Opt(pair_bow_dim=130, dropout=0.0)),
     "zh_s64": (O.EncoderConfig(layers=2, vocab_size=800), O.Opt(pair_bow_dim=300, dropout=0.0)),
@@ -42,9 +43,11 @@ def test_forward_terms_and_training_steps(golden_dir, name):
     P = O.init_params(cfg, opt, seed=wseed)
     st = O.AdamState()
     losses = []
+    neg = set(z["neg_steps"].tolist()) if "neg_steps" in z.files else set()
+    batch_neg = dict(batch, labels=torch.zeros_like(batch["labels"]), cau_labels=torch.zeros_like(batch["cau_labels"]))
     for s in range(steps):
         eps_e, eps_c = torch.from_numpy(z[f"eps_e_{s}"]), torch.from_numpy(z[f"eps_c_{s}"])
-        P, out, grads = O.train_step(P, batch, it0 + s, cfg, opt, st, eps_e, eps_c)
+        P, out, grads = O.train_step(P, batch_neg if s in neg else batch, it0 + s, cfg, opt, st, eps_e, eps_c)
         losses.append(float(out["loss"]))
         if s == 0:
             np.testing.assert_allclose(out["pooled"].numpy(), z["pooled"], atol=2e-5, rtol=1e-4)
