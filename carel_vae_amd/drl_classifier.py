@@ -322,6 +322,7 @@ class DrlClassifier(nn.Module):
         self.encoder = CarelEncoder(self.cfg)
         self._aprx_names = []
         self._has_pair_skip = True          # the pair head is frozen for a step whose pair loss was replaced by 0 (ref :510-511)
+        self.strict_pair_skip = False       # True: also leave its .grad None on such a step (for stock torch optimisers; one host read per step)
         self._build_heads(opt)
         gen = None
         if seed is not None:
@@ -415,6 +416,7 @@ class DrlClassifier(nn.Module):
         self._grad_views = None
         self._layer_structs = None
         self._ws = {}
+        self._enc_ws = {}
         self._pair_lo = offs[self._pair_range_names[0]]
         self._pair_hi = offs[self._pair_range_names[1]] + named[self._pair_range_names[1]].numel()
 
@@ -743,6 +745,14 @@ class DrlClassifier(nn.Module):
         if accumulate:
             self._flat_grad.add_(prev)
         self._bind_grads()
+        if self.strict_pair_skip and self._has_pair_skip and not accumulate:
+            # stock optimisers: leave pair_classifier.grad None when the pair loss was replaced by 0, exactly as the reference
+            # does (:510-511) -- torch.optim.Adam then skips the parameter.  One device->host read per step (the reference's
+            # own `if torch.isinf(...).any()` is such a read too); FusedAdam needs no read (carel_adam_args.skip_flag).
+            off = L.load().carel_tail_pair_dead_offset(c.B, self.opt.ec_dim, self.opt.pair_bow_dim)
+            if float(c.buf.work[off]) != 0.0:
+                for k in self._pair_range_names:
+                    self._named[k].grad = None
 
     def _backward_encoder(self, ea, accumulate):
         """Encoder layers 11..0 and the embeddings, given ea.dx = d loss / d (last hidden states)."""
