@@ -184,4 +184,4 @@ def test_train_driver_with_prefetch_loader_reproduces_the_batch_loader_run():
         d = (outs[0][k].double() - outs[1][k].double()).abs()
         assert float(d.max()) <= 2 * 5 * 1e-3 * 1.01, k
         if not k.endswith("key.bias"):                 # analytically zero gradient (softmax shift invariance): pure rounding noise
-            assert float((d <= 2e-5).double().mean()) >= 0.9, (k, float((d <= 2e-5).double().mean()))
+            assert float((d <= 2e-4).double().mean()) >= 0.9, (k, float((d <= 2e-4).double().mean()))   # 20 % of one lr-sized move
