@@ -196,6 +196,82 @@ def launch_ranks(a):
     print(line, flush=True)
 
 
+def input_pipeline_leg(dev, model, optim, batch_size):
+    """SURVEY 8(d)'s full step -- host batch assembly + H2D copy + forward + backward + Adam + the reference's loss logging --
+    through the reference's own driver loop (carel_vae_amd.training.train = ref :802-922): one epoch over a society_num-sized
+    synthetic dataset (2 587 ECPE-shaped pairs, 41 steps) + the evaluation pass over 1 938 pairs, fed by PrefetchLoader."""
+    from carel_vae_amd import data as D
+    from carel_vae_amd import training as T
+    V = model.opt.pair_bow_dim
+    tr_ds, te_ds = D.SyntheticECPEDataset(2587, V, 1), D.SyntheticECPEDataset(1938, V, 2)
+    saved = T.save_ckp
+    T.save_ckp = lambda *a_, **k_: None            # the 400 MB checkpoint write on an F1 improvement is not what is measured
+    opt = model.opt
+    ep, opt.epochs = opt.epochs, 1
+    out = {}
+    try:
+        for name in ("BatchLoader", "PrefetchLoader"):
+            tr = D.BatchLoader(tr_ds, batch_size=batch_size, shuffle=True)
+            if name == "PrefetchLoader":
+                tr = D.PrefetchLoader(tr, dev, depth=3)
+            te = D.BatchLoader(te_ds, batch_size=len(te_ds), shuffle=False)
+            T.train(tr, te, model, [optim], dev, num_unpred_pairs=22, opt=opt, log=lambda *_: None)       # warm-up epoch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            T.train(tr, te, model, [optim], dev, num_unpred_pairs=22, opt=opt, log=lambda *_: None)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = {"epoch_s": dt, "training_pairs_per_s": 2587 / dt}
+            log("input pipeline leg, %s: %.3f s per epoch" % (name, dt))
+    finally:
+        T.save_ckp = saved
+        opt.epochs = ep
+    out["note"] = ("training.train (ref :802-922) for one epoch: 41 steps of %d ECPE-shaped pairs incl. batch assembly and H2D, running-loss read-back "
+                   "every 10 steps, then get_pair_preds over 1938 test pairs; checkpoint write excluded" % batch_size)
+    return out
+
+
+def sentence_transformer_leg(dev, steps):
+    """chi_ec_sentence_transformer.py's fit() step (:84-87): 16 sentences, BERT-base (vocab 21128), mean pooling, batch-semi-hard
+    triplet loss (margin 4.45), gradient-norm clip + AdamW; S = 128 dense and ECPE-like sentence lengths."""
+    from carel_vae_amd import drl_classifier as M
+    from carel_vae_amd import sentence_transformer as S
+    from carel_vae_amd.data import synthetic_ecpe_batch
+    model = S.SentenceTransformer(M.encoder_config("zh"), seed=0).to(dev)
+    model.train(True)
+    loss_mod = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45)
+    optim = S.FusedAdamW(model, lr=2e-5)
+    out = {}
+    for shape in ("A", "B"):
+        feats = []
+        for i in range(4):
+            b = synthetic_ecpe_batch(16, 128, 21128, 8, seed=500 + i, shape=shape)
+            feats.append(({"input_ids": b["input_ids"].to(dev), "attention_mask": b["attention_masks"].to(dev), "token_type_ids": b["token_type_ids"].to(dev),
+                           "seq_lengths": b["attention_masks"].sum(1).tolist()}, (b["emo_labels"].view(-1) % 4).to(dev)))
+
+        def step(i):
+            f, lab = feats[i % 4]
+            loss = loss_mod([f], lab)
+            loss.backward()
+            optim.step()
+            optim.zero_grad()
+            return loss
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["dense" if shape == "A" else "ecpe_shaped"] = {"ms_per_step": 1e3 * dt / steps, "sentences_per_s": 16 * steps / dt, "final_loss": float(loss.detach())}
+        log("sentence-transformer leg, shape %s: %.3f ms/step" % (shape, 1e3 * dt / steps))
+    out["note"] = "fit() step of chi_ec_sentence_transformer.py: B=16, S=128, BERT-base vocab 21128, dropout on, triplet margin 4.45, clip 1.0 + AdamW; one GPU; parity unpinned (see DESIGN.md)"
+    del model, optim
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -361,8 +437,11 @@ def main():
 
     # ---- config 4: the English three-space adversarial model (drl_classifier_en.py), one GPU ----
     english = None
+    pipeline = sentence = None
     if not a.no_ecpe and rank == 0 and world == 1:
+        pipeline = input_pipeline_leg(dev, model, optim, a.batch)
         english = english_leg(dev, a.batch, max(5, a.steps // 2))
+        sentence = sentence_transformer_leg(dev, max(5, a.steps // 2))
 
     # ---- roofline of the dominant kernel family ----
     roof = None
@@ -406,7 +485,8 @@ def main():
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
                       "wgrad_side_stream": bool(model.overlap_wgrad), "forward_chains": bool(model.overlap_wgrad and model.forward_chains),
                       "adam_in_backward": bool(getattr(optim, "_aux", None) is not None)},
-           "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "english_adversarial": english, "final_loss": final_loss}
+           "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "english_adversarial": english, "input_pipeline": pipeline,
+           "sentence_transformer": sentence, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):
             m2 = M.DrlClassifier(M.make_opt(**vars(oopt)), M.encoder_config("zh", hidden_dropout=0.0, attn_dropout=0.0), seed=0)

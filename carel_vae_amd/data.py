@@ -370,6 +370,21 @@ def synthetic_ecpe_batch(B, S, vocab_size, V, seed=1, shape="A", pad_id=0, first
 # ----------------------------------------------------------------------------------------------
 # PrefetchLoader: the seven `.to(device)` copies of every step (ref :823-830) taken off the step's critical path
 # ----------------------------------------------------------------------------------------------
+class SyntheticECPEDataset(ECPEDataset):
+    """An ECPEDataset whose caches are filled from `synthetic_ecpe_batch` (no tokenizer / corpus vocabulary offline): n pairs of
+    ECPE-shaped lengths, bag-of-words width V.  Same `__getitem__` contract; works with DataLoader / BatchLoader / PrefetchLoader."""
+
+    def __init__(self, n, V, seed, max_len=128, vocab_size=21128, shape="B"):
+        b = synthetic_ecpe_batch(n, max_len, vocab_size, V, seed=seed, shape=shape)
+        self.pairs = pd.Series(["x"] * n)
+        self.labels = b["labels"].view(-1).numpy()
+        self.emo_labels = b["emo_labels"].view(-1).numpy()
+        self.cau_labels = self.labels
+        self.max_len, self.bow_features, self.tokenizer = max_len, [None] * V, object()
+        self.bow_representations = list(b["bow_reps"].numpy())
+        self._cache = (b["input_ids"], b["attention_masks"], b["token_type_ids"])
+
+
 class PackedLengths(list):
     """The host list of attended lengths (what `seq_lengths=` takes) that ALSO carries the batch's token-packing arrays already
     on the device (`cu`, `tok_row`, `n_tokens`, `t_eff`), so that the model has nothing to copy per step."""
