@@ -419,6 +419,10 @@ int gemm_pp_pick_tn(const GemmParams& p, int splits) {
 // workgroups of the wider tile, each with at least 8 K tiles, at most 16 slabs.  0 = shape not supported.
 int gemm_pp_wgrad_splits(int M, int N, long K) {
   if (M % 256 || N % 96 || K % 64 || K < 512) return 0;
+  // measured at K = 8192 (tools/bench_gemm_pp.py, GEMM + slab reduction): 768 x 3072 / 3072 x 768: 64 us vs 82 us with the 128x128
+  // kernel; 2304 x 768: 56.4 vs 53.9; 768 x 768: 33.5 vs 31.2 -- the small outputs need so many K slices to fill 256 CUs that the
+  // slab traffic eats the gain, so they stay on the 128x128 kernel
+  if ((long)M * N < 2000000L) return 0;
   const int npn = N % 192 == 0 ? 2 : 1;
   const long tiles = (long)(M / 256) * (N / (96 * npn));
   long s = 256 / tiles;
