@@ -207,3 +207,21 @@ def test_english_adversarial_two_ranks_equal_single_process():
         assert torch.equal(w0, w1), k
         step = 1e-2 if k.split(".")[0].endswith("disc") else 1e-3          # RMSprop: lr / sqrt(1 - alpha); Adam: lr
         assert float((w0 - weights[k]).abs().max()) <= 2.2 * step, k
+
+
+def test_bench_launches_two_ranks_by_itself_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher in the environment (it used to run ONE GPU and report n_gpus 1):
+    the parent starts the rank processes as a child before touching the GPU and relays rank 0's line; rehearsed on this one-GPU
+    box with both ranks on cuda:0 and gloo carrying the collectives (CAREL_REHEARSE_ONE_GPU=1)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CAREL_REHEARSE_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-ecpe"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
