@@ -610,7 +610,8 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }
   if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }
-  if (v == 80 || v == 81) { gemm_pp_loader_variant(v - 80); return CAREL_OK; }         // automatic use of the 256x192 tile off / on
+  if (v >= 80 && v <= 82) { gemm_pp_loader_variant(v - 80); return CAREL_OK; }         // automatic use of the 256x192 tile off / on
+  if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
   g_gemm_variant = v;
   return CAREL_OK;
 }

@@ -181,6 +181,7 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s);   
 // as possible -- the slices need not be equal, so any split factor works)
 void gemm_pp_force_npn(int n);
 void gemm_pp_loader_variant(int on);
+void gemm_pp_wide_variant(int on);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);

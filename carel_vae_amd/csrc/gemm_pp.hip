@@ -40,6 +40,9 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int PP_A_BYTES = 32768;
+#ifndef CAREL_PP_MPRIO
+#define CAREL_PP_MPRIO 1           // s_setprio level of the matrix segment (experiment: CAREL_EXTRA_FLAGS=-DCAREL_PP_MPRIO=0)
+#endif
 template <int NPN, bool BT> struct PPGeom {
   static constexpr int BPART = BT ? 16384 : 12288;
   static constexpr int STAGE = PP_A_BYTES + NPN * BPART;
@@ -48,11 +51,15 @@ template <int NPN, bool BT> struct PPGeom {
 
 // DBG (timing ablations, results wrong, only instantiated in a -DCAREL_GEMM_ABLATE build): 1 no DMA after the prologue,
 // 2 no MFMA, 3 no fragment reads after the first tile, 4 no epilogue, 5 the half-populated second B instruction dropped
-template <int NPN, bool AT, bool BT, int EPI, int DBG = 0>
+// WIDE: the schedule PPSchedW<NPN> -- one phase per B part with BOTH M halves (24 MFMAs per matrix segment instead of 12, half the
+// barriers per K tile; the A fragments of both halves are read in phase 0 and kept: +16 registers), every wave drains its LDS reads
+// before the barrier that ends its load segment (so a slot may be restaged ONE phase after its last read; tools/gemm_sched.py war = 1)
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   static_assert(!AT || BT, "the A^T form (weight gradient) has both operands K-strided");
-  using S = PPSched<NPN>;
+  using S = std::conditional_t<WIDE, PPSchedW<NPN>, PPSched<NPN>>;
   using G = PPGeom<NPN, BT>;
+  static_assert(S::STAGES == PPSched<NPN>::STAGES, "PPGeom sizes the LDS from the fine schedule's stage count");
   constexpr int NP = S::NP, ST = S::STAGES;
   constexpr int BN = 96 * NPN, WN = 48 * NPN, NF = 3 * NPN;
   constexpr int BPART = G::BPART, STAGE = G::STAGE;
@@ -142,10 +149,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       constexpr int j = u - 2;
       const char* g = bp + (long)d * b_step + j * b_part_step;
       char* pb = sb + PP_A_BYTES + j * BPART;
+      // A compiler fence after every lane-masked instruction: LLVM (ROCm 7.2) otherwise merges the masked copy of one piece with the
+      // unmasked copy of a neighbouring one into a single instruction whose LDS base is a per-lane select, and takes that base with
+      // v_readfirstlane -- the upper half-wave then lands on the lower half's destination (seen with three units in one phase).
       if (bact[0]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[0]), (CAREL_LDS void*)(pb + bdst[0]), 16, 0, 0);
+      asm volatile("" ::: "memory");
       if (bact[1] && DBG != 5) __builtin_amdgcn_global_load_lds((const void*)(g + boff[1]), (CAREL_LDS void*)(pb + bdst[1]), 16, 0, 0);
       if (DBG == 5) __builtin_amdgcn_global_load_lds((const void*)(g + boff[0]), (CAREL_LDS void*)(pb + bdst[0]), 16, 0, 0);   // keeps the vmcnt arithmetic
     }
+    asm volatile("" ::: "memory");     // and no instruction crosses a unit (vmcnt retires in issue order)
   };
 
   f32x4 acc[2][2][NF];
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[2][2], fb[3][2];                                   // [16-row block][k32 step], [16-column block][k32 step]
+  bf16x8 fa[WIDE ? 2 : 1][2][2], fb[3][2];                     // [M half (wide only)][16-row block][k32 step], [16-column block][k32 step]
   // A^T form, first tile column, group 0: sum_k A[k][m] through a ones-vector MFMA -> the bias gradient (colsum_a)
   const bool do_cs = AT && p.colsum_a != nullptr && tn == 0 && wc == 0;     // wave-uniform
   f32x4 acc1[2][2];
@@ -185,14 +197,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       constexpr int P = decltype(PP)::value;
       constexpr int h = S::phase_h[P], j = S::phase_j[P];
       // ---------------- load segment L(P): fragments of this phase, this phase's DMA units, counted wait -------------
-      const bool do_reads = DBG != 3 || first_tile;
-      if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
+      const bool do_reads = (DBG != 3 && DBG != 6 && DBG != 7 && DBG != 8) || first_tile;     // 6: DMA + barriers only, 7: barriers only, 8: MFMA + barriers only
+      if constexpr (WIDE) {
+        if constexpr (P == 0) {
+          if (do_reads)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks)
+                fa[hh][i][ks] = AT ? frag16_col(st + hh * 16384, wr * 32 + i * 16, ks * 32) : frag16_row(st, wr * 64 + hh * 32 + i * 16, ks * 32);
+        }
+      } else if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
         if (do_reads)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            fa[i][ks] = AT ? frag16_col(st + h * 16384, wr * 32 + i * 16, ks * 32) : frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
+            fa[0][i][ks] = AT ? frag16_col(st + h * 16384, wr * 32 + i * 16, ks * 32) : frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
       }
       if constexpr (P == 0 || S::phase_j[P] != S::phase_j[P == 0 ? 0 : P - 1]) {
         const char* pb = st + PP_A_BYTES + j * BPART;
@@ -206,33 +229,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       static_for<S::n_issue[P]>([&](auto E) {
         constexpr int e = decltype(E)::value;
         constexpr int u = S::issue_unit[P][e], d = S::issue_delta[P][e];
-        if constexpr ((R == 0 || d < R) && DBG != 1) {
+        if constexpr ((R == 0 || d < R) && DBG != 1 && DBG != 7 && DBG != 8) {
           int stg = sidx + d;
           if (stg >= ST) stg -= ST;
           issue(IC<u>{}, a_ptr, b_ptr, d, stg);
         }
       });
-      if constexpr (S::wait[R][P] >= 0 && DBG != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
+      if constexpr (S::wait[R][P] >= 0 && DBG != 1 && DBG != 7 && DBG != 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
+      if constexpr (WIDE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before the barrier: war = 1
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- matrix segment M(P) --------------------------------------------------------------------------
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(CAREL_PP_MPRIO);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int hh = (WIDE ? 0 : h); hh < (WIDE ? 2 : h + 1); ++hh)
 #pragma unroll
-          for (int jj = 0; jj < 3; ++jj) {
-            if (DBG == 2) asm volatile("" ::"v"(fb[jj][ks]), "v"(fa[i][ks]));
-            else acc[h][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[i][ks], acc[h][i][j * 3 + jj]);   // swapped: D[n][m]
-          }
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+              if (DBG == 2 || DBG == 6 || DBG == 7) asm volatile("" ::"v"(fb[jj][ks]), "v"(fa[WIDE ? hh : 0][i][ks]));
+              else acc[hh][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[WIDE ? hh : 0][i][ks], acc[hh][i][j * 3 + jj]);   // swapped: D[n][m]
+            }
       if constexpr (AT && j == 0) {
         if (do_cs) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc1[h][i] = mfma16(ones, fa[i][ks], acc1[h][i]);
+            for (int hh = (WIDE ? 0 : h); hh < (WIDE ? 2 : h + 1); ++hh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) acc1[hh][i] = mfma16(ones, fa[WIDE ? hh : 0][i][ks], acc1[hh][i]);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -355,10 +383,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 // tables of tools/gemm_sched.py hold unchanged.  M must be a multiple of 256 (no edge rows); grid = min(tiles, 256), a
 // multiple of 8 when there is more than one round (a workgroup's tiles then stay in one XCD chunk).
 // =====================================================================================================================
-template <int NPN, bool BT, int EPI>
-__global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
-  using S = PPSched<NPN>;
+// NLW loader waves (2 or 4; 4 = one per SIMD, each standing in for two compute waves: a wave's LDS-DMA instruction costs it about 60
+// cycles of issue, so two loaders alone cannot keep up with a 45-KiB K tile); WIDE as in gemm_pp_kernel.
+template <int NPN, bool BT, int EPI, int NLW, bool WIDE>
+__global__ __launch_bounds__(512 + 64 * NLW) void gemm_ppl_kernel(GemmParams p) {
+  using S = std::conditional_t<WIDE, PPSchedW<NPN>, PPSched<NPN>>;
   using G = PPGeom<NPN, BT>;
+  static_assert(S::STAGES == PPSched<NPN>::STAGES, "PPGeom sizes the LDS from the fine schedule's stage count");
+  constexpr int EMU = 8 / NLW;                                            // compute waves' pieces per loader wave
   constexpr int NP = S::NP, ST = S::STAGES;
   constexpr int BN = 96 * NPN, WN = 48 * NPN, NF = 3 * NPN;
   constexpr int BPART = G::BPART, STAGE = G::STAGE;
@@ -381,12 +413,12 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
   if (wave >= 8) {
     // ------------------------------------------------------------------------------------------------ loader waves
     const int lw = wave - 8;
-    uint32_t aoff[4][2][2], boff[4][2];
-    int adst[4][2][2], bdst[4][2];
-    bool bact[4][2];
+    uint32_t aoff[EMU][2][2], boff[EMU][2];
+    int adst[EMU][2][2], bdst[EMU][2];
+    bool bact[EMU][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int w = lw * 4 + i, wr = w & 3, wc = w >> 2;
+    for (int i = 0; i < EMU; ++i) {
+      const int w = lw * EMU + i, wr = w & 3, wc = w >> 2;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -432,7 +464,7 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
       constexpr int u = decltype(U)::value;
       char* sb = smem + stg * STAGE;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < EMU; ++i) {
         if constexpr (u < 2) {
           __builtin_amdgcn_global_load_lds((const void*)(va[d] + aoff[i][u][0]), (CAREL_LDS void*)(sb + adst[i][u][0]), 16, 0, 0);
           __builtin_amdgcn_global_load_lds((const void*)(va[d] + aoff[i][u][1]), (CAREL_LDS void*)(sb + adst[i][u][1]), 16, 0, 0);
@@ -441,15 +473,22 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
           const char* g = vb[d] + j * b_part_step;
           char* pb = sb + PP_A_BYTES + j * BPART;
           if (bact[i][0]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[i][0]), (CAREL_LDS void*)(pb + bdst[i][0]), 16, 0, 0);
+          // Compiler fence after EVERY masked instruction.  Without it LLVM (ROCm 7.2) merges the masked and unmasked copies of
+          // neighbouring pieces into one instruction whose LDS base is a per-lane select, and then takes that base with
+          // v_readfirstlane: the upper half-wave lands on the lower half's destination (seen as stale B rows, round 2).
+          asm volatile("" ::: "memory");
           if (bact[i][1]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[i][1]), (CAREL_LDS void*)(pb + bdst[i][1]), 16, 0, 0);
+          asm volatile("" ::: "memory");
         }
       }
+      // vmcnt retires in ISSUE order and the schedule's immediates count whole units: no instruction may move across a unit
+      asm volatile("" ::: "memory");
     };
     static_for<S::NPRO>([&](auto I) {
       constexpr int i = decltype(I)::value;
       issue(IC<S::pro_unit[i]>{}, S::pro_tile[i], S::pro_tile[i] % ST);
     });
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * S::PRO_WAIT) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EMU * S::PRO_WAIT) : "memory");
     __builtin_amdgcn_s_barrier();
     int sidx = 0, v = 0;
     auto tileL = [&](auto RR) {
@@ -465,7 +504,7 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
             issue(IC<u>{}, d, stg);
           }
         });
-        if constexpr (S::wait[R][P] >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * S::wait[R][P]) : "memory");
+        if constexpr (S::wait[R][P] >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EMU * S::wait[R][P]) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
       });
@@ -489,7 +528,7 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[2][2], fb[3][2];
+  bf16x8 fa[WIDE ? 2 : 1][2][2], fb[3][2];
   const int rho = lane >> 4;
   constexpr int NQ = NF / 2;
 
@@ -553,11 +592,20 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
     static_for<NP>([&](auto PP) {
       constexpr int P = decltype(PP)::value;
       constexpr int h = S::phase_h[P], j = S::phase_j[P];
-      if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
+      if constexpr (WIDE) {
+        if constexpr (P == 0) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks) fa[hh][i][ks] = frag16_row(st, wr * 64 + hh * 32 + i * 16, ks * 32);
+        }
+      } else if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fa[i][ks] = frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
+          for (int ks = 0; ks < 2; ++ks) fa[0][i][ks] = frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
       }
       if constexpr (P == 0 || S::phase_j[P] != S::phase_j[P == 0 ? 0 : P - 1]) {
         const char* pb = st + PP_A_BYTES + j * BPART;
@@ -567,16 +615,20 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
           for (int ks = 0; ks < 2; ++ks)
             fb[jj][ks] = BT ? frag16_col(pb, wc * 48 + jj * 16, ks * 32) : frag16_row(pb, wc * 48 + jj * 16, ks * 32);
       }
+      if constexpr (WIDE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before the barrier: war = 1
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(CAREL_PP_MPRIO);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int hh = (WIDE ? 0 : h); hh < (WIDE ? 2 : h + 1); ++hh)
 #pragma unroll
-          for (int jj = 0; jj < 3; ++jj) acc[h][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[i][ks], acc[h][i][j * 3 + jj]);
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+              acc[hh][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[WIDE ? hh : 0][i][ks], acc[hh][i][j * 3 + jj]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -592,12 +644,12 @@ __global__ __launch_bounds__(640, 3) void gemm_ppl_kernel(GemmParams p) {
   if (wc == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <int NPN, bool BT, int EPI>
+template <int NPN, bool BT, int EPI, int NLW, bool WIDE>
 int launch_ppl(GemmParams p, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_ppl_kernel<NPN, BT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_ppl_kernel<NPN, BT, EPI, NLW, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_ppl_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
@@ -607,34 +659,37 @@ int launch_ppl(GemmParams p, hipStream_t s) {
     hipError_t e = hipMemsetAsync(p.colsum_part, 0, (size_t)(p.M / 128) * p.N * 4, s);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_ppl_kernel: memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL((gemm_ppl_kernel<NPN, BT, EPI>), dim3(tiles < 256 ? tiles : 256), dim3(640), G::LDS, s, p);
+  hipLaunchKernelGGL((gemm_ppl_kernel<NPN, BT, EPI, NLW, WIDE>), dim3(tiles < 256 ? tiles : 256), dim3(512 + 64 * NLW), G::LDS, s, p);
   return check_launch("gemm_ppl_kernel");
 }
 
-template <int NPN, bool AT, bool BT, int EPI, int DBG = 0>
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
 int launch_pp(GemmParams p, int splits, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
   static bool attr = false;      // per process; setting it again is harmless if two threads race
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
-  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
   return check_launch("gemm_pp_kernel");
 }
 
+static int g_pp_wide = 0;        // tuning hook (carel_gemm_set_variant(90 / 91)): the wide-phase schedule where it is built (npn 2)
+
 template <bool BT, int EPI>
 int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
-  if (npn == 1) return launch_pp<1, false, BT, EPI>(p, 1, s);
-  if (npn == 2) return launch_pp<2, false, BT, EPI>(p, 1, s);
-  if constexpr (!BT) { if (npn == 3) return launch_pp<3, false, BT, EPI>(p, 1, s); }
+  if (npn == 1) return g_pp_wide ? launch_pp<1, false, BT, EPI, 0, true>(p, 1, s) : launch_pp<1, false, BT, EPI>(p, 1, s);
+  if (npn == 2) return g_pp_wide ? launch_pp<2, false, BT, EPI, 0, true>(p, 1, s) : launch_pp<2, false, BT, EPI>(p, 1, s);
+  if constexpr (!BT) { if (npn == 3) return g_pp_wide ? launch_pp<3, false, BT, EPI, 0, true>(p, 1, s) : launch_pp<3, false, BT, EPI>(p, 1, s); }
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch: npn = %d not built for this form", npn);
 }
 
 }  // namespace
 
+void gemm_pp_wide_variant(int on) { g_pp_wide = on ? 1 : 0; }
 static int g_pp_force_npn = 0;     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
 void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
 
@@ -702,27 +757,35 @@ int gemm_pp_wgrad_splits(int M, int N, long K) {
 }
 
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s) {
-  if (npn == 1) return launch_pp<1, true, true, EPI_SLAB_F32>(p, splits, s);
-  if (npn == 2) return launch_pp<2, true, true, EPI_SLAB_F32>(p, splits, s);
+  if (npn == 1) return g_pp_wide ? launch_pp<1, true, true, EPI_SLAB_F32, 0, true>(p, splits, s) : launch_pp<1, true, true, EPI_SLAB_F32>(p, splits, s);
+  if (npn == 2) return g_pp_wide ? launch_pp<2, true, true, EPI_SLAB_F32, 0, true>(p, splits, s) : launch_pp<2, true, true, EPI_SLAB_F32>(p, splits, s);
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_tn: npn = %d not built", npn);
 }
 
 #ifdef CAREL_GEMM_ABLATE
 int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s) {     // NT, bias -> bf16 epilogue only
-#define PPD(N, D) if (npn == N && dbg == D) return launch_pp<N, false, false, EPI_BIAS_BF16, D>(p, 1, s)
-  PPD(3, 1); PPD(3, 2); PPD(3, 3); PPD(3, 4); PPD(3, 5); PPD(1, 1); PPD(1, 2); PPD(1, 3); PPD(1, 4); PPD(1, 5);
+#define PPD(N, D) if (npn == N && dbg == D) return g_pp_wide ? launch_pp<N, false, false, EPI_BIAS_BF16, D, true>(p, 1, s) : launch_pp<N, false, false, EPI_BIAS_BF16, D>(p, 1, s)
+#define PPDN(N) PPD(N, 1); PPD(N, 2); PPD(N, 3); PPD(N, 4); PPD(N, 5); PPD(N, 6); PPD(N, 7); PPD(N, 8)
+  PPDN(1); PPDN(2); PPDN(3);
+#undef PPDN
 #undef PPD
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_dbg: (npn, dbg) = (%d, %d) not built", npn, dbg);
 }
 #endif
 
 static int g_pp_loader = 0;      // tuning hook (carel_gemm_set_variant(80 / 81)): the loader-wave persistent variant off / on
-void gemm_pp_loader_variant(int on) { g_pp_loader = on ? 1 : 0; }
+void gemm_pp_loader_variant(int on) { g_pp_loader = (on >= 0 && on <= 2) ? on : 0; }
 
+// mode 1: two loader waves, fine schedule (the first experiment); mode 2: four loader waves -- with the wide schedule for npn 1
+// (12 waves = 3 per SIMD leave 170 registers per wave: the wide npn-2 kernel's 190-200 do not fit), fine for npn 2
 template <bool BT, int EPI>
 static int launch_ppl_n(const GemmParams& p, int npn, hipStream_t s) {
-  if (npn == 1) return launch_ppl<1, BT, EPI>(p, s);
-  return launch_ppl<2, BT, EPI>(p, s);
+  if (g_pp_loader == 2) {
+    if (npn == 1) return launch_ppl<1, BT, EPI, 4, true>(p, s);
+    return launch_ppl<2, BT, EPI, 4, false>(p, s);
+  }
+  if (npn == 1) return launch_ppl<1, BT, EPI, 2, false>(p, s);
+  return launch_ppl<2, BT, EPI, 2, false>(p, s);
 }
 
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {

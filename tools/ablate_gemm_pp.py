@@ -15,8 +15,11 @@ def timed(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-names = {3: "full", 61: "no DMA after prologue", 62: "no MFMA", 63: "no fragment reads", 64: "no epilogue", 65: "no half-populated B instr"}
-for (M, N, K) in [(8192, 2304, 768), (8192, 768, 3072), (8192, 768, 768)]:
+names = {3: "full", 61: "no DMA", 62: "no MFMA", 63: "no reads", 64: "no epilogue", 66: "DMA+barriers only", 67: "barriers only", 68: "MFMA+barriers only"}
+WIDE = int(os.environ.get("WIDE", 0))
+L.check(lib.carel_gemm_set_variant(90 + WIDE))
+print("wide-phase schedule" if WIDE else "fine schedule")
+for (M, N, K) in [(8192, 2304, 768), (8192, 3072, 768), (4096, 3072, 768), (8192, 768, 3072), (8192, 768, 768)]:
     A, B = rnd(M, K), rnd(N, K)
     out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     bias = torch.zeros(N, device="cuda")
@@ -28,4 +31,4 @@ for (M, N, K) in [(8192, 2304, 768), (8192, 768, 3072), (8192, 768, 768)]:
             f(); t = timed(f)
             if r: res[v].append(t)
     print("M=%d N=%d K=%d: " % (M, N, K) + " | ".join("%s %.1f us" % (names[v], statistics.median(res[v])) for v in names), flush=True)
-L.check(lib.carel_gemm_set_variant(0))
+L.check(lib.carel_gemm_set_variant(0)); L.check(lib.carel_gemm_set_variant(90))

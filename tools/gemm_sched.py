@@ -27,8 +27,11 @@ tables with the constexpr copies in gemm_pp.hip.
 import sys
 
 
-def phases(npn):
-    """serpentine (h, j) order of a K tile"""
+def phases(npn, wide=False):
+    """(h, j) order of a K tile: serpentine over (M half, B part); wide: one phase per B part, both M halves (h = -1),
+    the A fragments of both halves read once in phase 0 and kept in registers"""
+    if wide:
+        return [(-1, j) for j in range(npn)]
     out = []
     h = 0
     for j in range(npn):
@@ -38,29 +41,38 @@ def phases(npn):
     return out
 
 
-def unit_span(npn):
+def phase_reads(npn, wide=False):
+    """the units whose LDS image phase p reads"""
+    if wide:
+        return [(["A0", "A1"] if j == 0 else []) + ["B%d" % j] for j in range(npn)]
+    return [["A%d" % h, "B%d" % j] for (h, j) in phases(npn)]
+
+
+def unit_span(npn, wide=False):
     """unit -> (first phase, last phase) inside a tile"""
-    ph = phases(npn)
     span = {}
-    for p, (h, j) in enumerate(ph):
-        for u in ("A%d" % h, "B%d" % j):
+    for p, us in enumerate(phase_reads(npn, wide)):
+        for u in us:
             f, l = span.get(u, (p, p))
             span[u] = (min(f, p), max(l, p))
     return span
 
 
-def make(npn, stages, max_lead=None):
-    NP = 2 * npn
-    span = unit_span(npn)
+def make(npn, stages, max_lead=None, wide=False, war=2):
+    """war: phases between a unit's last read and the issue that overwrites its slot.  2 for the fine schedule (group 1's
+    reads of phase q are only known complete at the start of its M(q), one barrier after group 0's L(q+1)); 1 when every
+    wave drains its LDS reads (lgkmcnt(0)) BEFORE the barrier that ends its load segment (the wide schedule does)."""
+    NP = len(phases(npn, wide))
+    span = unit_span(npn, wide)
     units = ["A0", "A1"] + ["B%d" % j for j in range(npn)]
     lead = {}
     for u in units:
         first, last = span[u]
-        d = stages * NP - last + first - 2           # WAR: n - d >= (t - S) * NP + last + 2
+        d = stages * NP - last + first - war         # WAR: n - d >= (t - S) * NP + last + war
         if max_lead is not None:
             d = min(d, max_lead)
         if d < 2:
-            raise ValueError("no legal issue phase for %s (npn=%d stages=%d)" % (u, npn, stages))
+            raise ValueError("no legal issue phase for %s (npn=%d stages=%d)" % (u, npn, stages))     # RAW needs one phase of flight
         lead[u] = d
     # issue[p] = [(unit, tile delta)], ordered by need phase
     issue = [[] for _ in range(NP)]
@@ -75,7 +87,7 @@ def make(npn, stages, max_lead=None):
     for p in range(NP):
         issue[p].sort(key=lambda x: (x[1] * NP + x[2], x[0]))
         issue[p] = [(u, d) for (u, d, _) in issue[p]]
-    return dict(npn=npn, stages=stages, NP=NP, span=span, units=units, lead=lead, issue=issue)
+    return dict(npn=npn, stages=stages, NP=NP, span=span, units=units, lead=lead, issue=issue, wide=wide, war=war)
 
 
 def program(s, nk):
@@ -94,13 +106,12 @@ def program(s, nk):
     pro.sort()
     for (_, _, u, tt) in pro:
         ev.append(("issue", u, tt))
-    ph = phases(s["npn"])
+    reads = phase_reads(s["npn"], s["wide"])
     for t in range(nk):
         for p in range(NP):
             q = t * NP + p
-            h, j = ph[p]
-            ev.append(("read", "A%d" % h, t, q))
-            ev.append(("read", "B%d" % j, t, q))
+            for u in reads[p]:
+                ev.append(("read", u, t, q))
             for (u, d) in s["issue"][p]:
                 if t + d < nk:
                     ev.append(("issue", u, t + d))
@@ -190,14 +201,14 @@ def check(s, nk):
     for (u, t), i in issue_phase.items():
         prev = (u, t - S)
         if prev in last_read:
-            assert i >= last_read[prev] + 2, ("WAR", (u, t), i, last_read[prev])
+            assert i >= last_read[prev] + s["war"], ("WAR", (u, t), i, last_read[prev])
     # in-flight bound: vmcnt is a 6-bit counter
     assert max([x for x in w.values() if x is not None] + [0]) <= 63
     return True
 
 
-def describe(npn, stages, max_lead=None):
-    s = make(npn, stages, max_lead)
+def describe(npn, stages, max_lead=None, wide=False, war=2):
+    s = make(npn, stages, max_lead, wide, war)
     for nk in (4, 5, 6, 7, 12, 13, 36, 48):
         check(s, nk)
     tabs, ntail = tables(s)
@@ -206,6 +217,7 @@ def describe(npn, stages, max_lead=None):
 
 CONFIGS = {1: 3, 2: 2, 3: 2}     # NPN -> LDS stages
 LEADS = {1: 4, 2: 4, 3: 5}       # NPN -> cap on the issue lead in phases (about 3-4 units = 45-60 KiB in flight per CU)
+WIDE_CONFIGS = {1: 3, 2: 2, 3: 2}             # wide phases (24 MFMAs each): NPN -> LDS stages; war = 1, leads uncapped
 UNIT_ID = {"A0": 0, "A1": 1, "B0": 2, "B1": 3, "B2": 4}
 
 
@@ -224,20 +236,23 @@ def header():
            "// Units: 0 = A0, 1 = A1, 2 + j = Bj.  wait[R][p]: vmcnt immediate at the end of L(p); R = 0 steady state,",
            "// R = r: r tiles remain including the current one; -1 = no wait.",
            "template <int NPN> struct PPSched;"]
-    for npn, st in CONFIGS.items():
-        s, tabs, ntail = describe(npn, st, LEADS[npn])
+    out.append("template <int NPN> struct PPSchedW;     // wide phases: phase_h = -1 (both M halves), A fragments read in phase 0 only")
+    todo = [("PPSched", npn, st, LEADS[npn], False, 2) for npn, st in CONFIGS.items()]
+    todo += [("PPSchedW", npn, st, None, True, 1) for npn, st in WIDE_CONFIGS.items()]
+    for (name, npn, st, cap, wide, war) in todo:
+        s, tabs, ntail = describe(npn, st, cap, wide, war)
         while ntail > 1 and tabs[ntail] == tabs[0]:
             ntail -= 1
         NP = s["NP"]
         maxi = max(1, max(len(x) for x in s["issue"]))
         pro, pro_wait = prologue_of(s)
-        ph = phases(npn)
+        ph = phases(npn, wide)
         def arr(rows):
             return "{" + ", ".join("{" + ", ".join(str(v) for v in r) + "}" for r in rows) + "}"
         iu = [[UNIT_ID[x[0]] for x in s["issue"][p]] + [-1] * (maxi - len(s["issue"][p])) for p in range(NP)]
         idl = [[x[1] for x in s["issue"][p]] + [0] * (maxi - len(s["issue"][p])) for p in range(NP)]
         wt = [[(-1 if v is None else v) for v in tabs[R]] for R in range(ntail + 1)]
-        out += ["template <> struct PPSched<%d> {" % npn,
+        out += ["template <> struct %s<%d> {" % (name, npn),
                 "  static constexpr int NP = %d, STAGES = %d, NTAIL = %d, MAXI = %d, NPRO = %d, PRO_WAIT = %d;" % (NP, st, ntail, maxi, len(pro), pro_wait),
                 "  static constexpr int phase_h[NP] = {%s};" % ", ".join(str(h) for h, _ in ph),
                 "  static constexpr int phase_j[NP] = {%s};" % ", ".join(str(j) for _, j in ph),
@@ -253,9 +268,10 @@ def header():
 
 def emit():
     out = []
-    for npn, st in CONFIGS.items():
-        s, tabs, ntail = describe(npn, st, LEADS[npn])
-        out.append("NPN=%d stages=%d phases=%s" % (npn, st, phases(npn)))
+    todo = [(npn, st, LEADS[npn], False, 2) for npn, st in CONFIGS.items()] + [(npn, st, None, True, 1) for npn, st in WIDE_CONFIGS.items()]
+    for (npn, st, cap, wide, war) in todo:
+        s, tabs, ntail = describe(npn, st, cap, wide, war)
+        out.append("NPN=%d stages=%d%s phases=%s" % (npn, st, " WIDE" if wide else "", phases(npn, wide)))
         out.append("  lead   %s" % s["lead"])
         for p in range(s["NP"]):
             out.append("  phase %d issue %s" % (p, s["issue"][p]))
