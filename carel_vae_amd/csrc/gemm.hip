@@ -610,7 +610,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }
   if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }
-  if (v >= 80 && v <= 82) { gemm_pp_loader_variant(v - 80); return CAREL_OK; }         // automatic use of the 256x192 tile off / on
+  if (v >= 100 && v <= 116) { gemm_pp_wgrad_force(v - 100); return CAREL_OK; }         // ping-pong weight gradient: split-K factor forced (0 = heuristic)
   if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
   g_gemm_variant = v;
   return CAREL_OK;
@@ -676,7 +676,8 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
         q.K = a->K;
         const int npn = gemm_pp_pick_tn(q, splits);
         const long wgs = npn ? (long)(q.M / 256) * (q.N / (96 * npn)) * splits : 0;
-        if (npn && (g_gemm_variant == 3 || wgs >= g_pp_min_tiles)) return gemm_pp_launch_tn(q, npn, splits, stream);
+        // (the same floor as gemm_pp_wgrad_splits: whatever carel_gemm_wgrad_splits proposes for this kernel must be taken by it)
+        if (npn && (g_gemm_variant == 3 || wgs >= 64)) return gemm_pp_launch_tn(q, npn, splits, stream);
       }
       if (a->K % (64 * splits) || !((a->M % 128 == 0 && a->N % 128 == 0) || (a->M % 256 == 0 && a->N % 192 == 0)))
         return set_error(CAREL_ERR_SHAPE, "carel_gemm_bf16: this (M,N,K,splits) fits neither weight-gradient kernel (M=%d N=%d K=%d splits=%d)", a->M, a->N, a->K, splits);
@@ -700,10 +701,7 @@ static int wgrad_splits_128(int M, int N, long T) {
 extern "C" int32_t carel_gemm_wgrad_splits(int32_t M, int32_t N, int64_t T) {
   if (g_gemm_variant != 1 && g_gemm_variant != 2) {
     const int s = gemm_pp_wgrad_splits(M, N, (long)T);
-    if (s > 0) {
-      const int npn = N % 192 == 0 ? 2 : 1;
-      if (g_gemm_variant == 3 || (long)(M / 256) * (N / (96 * npn)) * s >= g_pp_min_tiles) return s;
-    }
+    if (s > 0) return s;
   }
   return wgrad_splits_128(M, N, (long)T);
 }

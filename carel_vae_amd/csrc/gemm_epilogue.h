@@ -180,10 +180,10 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s);   
 // weight-gradient form (A^T B into fp32 slabs; p.K = the WHOLE contraction length, dealt to `splits` z slices as evenly
 // as possible -- the slices need not be equal, so any split factor works)
 void gemm_pp_force_npn(int n);
-void gemm_pp_loader_variant(int on);
 void gemm_pp_wide_variant(int on);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
+void gemm_pp_wgrad_force(int s);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
 
 }  // namespace carel

@@ -371,298 +371,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 }
 
-// =====================================================================================================================
-// Loader-wave variant (round 2, NT / NN forms, NPN 1-2): the same tile, phases and schedule, but the LDS-DMA is issued -- and its
-// counted vmcnt waits are executed -- by TWO EXTRA WAVES (8, 9; each stands in for four compute waves' pieces, 8 instructions
-// per unit, so every immediate of the schedule is x4), and the workgroup is PERSISTENT over its tiles on one continuous
-// stream of K tiles.  Why: vmcnt retires in issue order, so a wave that both stores an epilogue and waits for DMA cannot let
-// its stores drain behind the next tile's main loop (measured with the 8-wave persistent loop: nothing overlapped).  Here the
-// eight compute waves never wait on vmcnt in the main loop: they fire a tile's epilogue stores and go straight on with the
-// next tile, whose first K tiles the loader waves already have in flight; the store traffic (the HBM-bound part of a GEMM
-// launch) leaves L2 under the next main loop.  The loaders keep group 0's barrier cadence, so the RAW / WAR rules and the
-// tables of tools/gemm_sched.py hold unchanged.  M must be a multiple of 256 (no edge rows); grid = min(tiles, 256), a
-// multiple of 8 when there is more than one round (a workgroup's tiles then stay in one XCD chunk).
-// =====================================================================================================================
-// NLW loader waves (2 or 4; 4 = one per SIMD, each standing in for two compute waves: a wave's LDS-DMA instruction costs it about 60
-// cycles of issue, so two loaders alone cannot keep up with a 45-KiB K tile); WIDE as in gemm_pp_kernel.
-template <int NPN, bool BT, int EPI, int NLW, bool WIDE>
-__global__ __launch_bounds__(512 + 64 * NLW) void gemm_ppl_kernel(GemmParams p) {
-  using S = std::conditional_t<WIDE, PPSchedW<NPN>, PPSched<NPN>>;
-  using G = PPGeom<NPN, BT>;
-  static_assert(S::STAGES == PPSched<NPN>::STAGES, "PPGeom sizes the LDS from the fine schedule's stage count");
-  constexpr int EMU = 8 / NLW;                                            // compute waves' pieces per loader wave
-  constexpr int NP = S::NP, ST = S::STAGES;
-  constexpr int BN = 96 * NPN, WN = 48 * NPN, NF = 3 * NPN;
-  constexpr int BPART = G::BPART, STAGE = G::STAGE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0..7 compute, 8..9 loaders
-  const int nk = p.K >> 6;
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int nmine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int V = nmine * nk;                                               // K tiles of this workgroup's whole stream
-  auto tile_rc = [&](int j, int& tm, int& tn) {                           // j-th tile of this workgroup (XCD-chunked order)
-    const int bid = (int)blockIdx.x + j * (int)gridDim.x;
-    const int xcd = bid & 7, qq = ntiles >> 3, rr = ntiles & 7;
-    const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    tm = tid / p.tiles_n; tn = tid - tm * p.tiles_n;
-  };
-  const long a_step = 128, b_step = BT ? 64 * p.ldb * 2 : 128;
-  const long b_part_step = BT ? 48 * 2 : 48 * p.ldb * 2;
-
-  if (wave >= 8) {
-    // ------------------------------------------------------------------------------------------------ loader waves
-    const int lw = wave - 8;
-    uint32_t aoff[EMU][2][2], boff[EMU][2];
-    int adst[EMU][2][2], bdst[EMU][2];
-    bool bact[EMU][2];
-#pragma unroll
-    for (int i = 0; i < EMU; ++i) {
-      const int w = lw * EMU + i, wr = w & 3, wc = w >> 2;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int piece = wr * 8 + h * 4 + wc * 2 + k;
-          const int row = piece * 8 + (lane >> 3);
-          const int c = (lane & 7) ^ (lane >> 3);
-          aoff[i][h][k] = (uint32_t)(((long)row * p.lda + c * 8) * 2);
-          adst[i][h][k] = piece * 1024;
-        }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (!BT) {
-          const int base_row = k == 0 ? w * 8 : (8 + (w >> 1)) * 8 + (w & 1) * 4;
-          const int r = base_row + (lane >> 3);
-          const int c = (lane & 7) ^ (r & 7);
-          boff[i][k] = (uint32_t)((((long)(r / 48) * WN + r % 48) * p.ldb + c * 8) * 2);
-          bdst[i][k] = base_row * 128;
-          bact[i][k] = k == 0 || lane < 32;
-        } else {
-          const int q = w * 2 + k;
-          const int r = q * 4 + (lane >> 4);
-          const int c = (lane & 15) ^ swz_col(r);
-          boff[i][k] = (uint32_t)(((long)r * p.ldb + (c / 6) * WN + (c % 6) * 8) * 2);
-          bdst[i][k] = q * 1024;
-          bact[i][k] = c < 12;
-        }
-      }
-    }
-    // operand pointers of the virtual K tiles v, v+1, v+2 (slot d = tile v + d); refreshed as v advances
-    const char* va[3];
-    const char* vb[3];
-    auto locate = [&](int vv, const char*& a, const char*& b) {
-      if (vv >= V) { a = (const char*)p.A; b = (const char*)p.B; return; }      // never issued (tail tables)
-      const int j = vv / nk, kt = vv - j * nk;
-      int tm, tn;
-      tile_rc(j, tm, tn);
-      a = (const char*)(p.A + (long)tm * 256 * p.lda) + kt * a_step;
-      b = (const char*)(BT ? p.B + (long)tn * BN : p.B + (long)tn * BN * p.ldb) + kt * b_step;
-    };
-    locate(0, va[0], vb[0]); locate(1, va[1], vb[1]); locate(2, va[2], vb[2]);
-    auto issue = [&](auto U, int d, int stg) {
-      constexpr int u = decltype(U)::value;
-      char* sb = smem + stg * STAGE;
-#pragma unroll
-      for (int i = 0; i < EMU; ++i) {
-        if constexpr (u < 2) {
-          __builtin_amdgcn_global_load_lds((const void*)(va[d] + aoff[i][u][0]), (CAREL_LDS void*)(sb + adst[i][u][0]), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((const void*)(va[d] + aoff[i][u][1]), (CAREL_LDS void*)(sb + adst[i][u][1]), 16, 0, 0);
-        } else {
-          constexpr int j = u - 2;
-          const char* g = vb[d] + j * b_part_step;
-          char* pb = sb + PP_A_BYTES + j * BPART;
-          if (bact[i][0]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[i][0]), (CAREL_LDS void*)(pb + bdst[i][0]), 16, 0, 0);
-          // Compiler fence after EVERY masked instruction.  Without it LLVM (ROCm 7.2) merges the masked and unmasked copies of
-          // neighbouring pieces into one instruction whose LDS base is a per-lane select, and then takes that base with
-          // v_readfirstlane: the upper half-wave lands on the lower half's destination (seen as stale B rows, round 2).
-          asm volatile("" ::: "memory");
-          if (bact[i][1]) __builtin_amdgcn_global_load_lds((const void*)(g + boff[i][1]), (CAREL_LDS void*)(pb + bdst[i][1]), 16, 0, 0);
-          asm volatile("" ::: "memory");
-        }
-      }
-      // vmcnt retires in ISSUE order and the schedule's immediates count whole units: no instruction may move across a unit
-      asm volatile("" ::: "memory");
-    };
-    static_for<S::NPRO>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      issue(IC<S::pro_unit[i]>{}, S::pro_tile[i], S::pro_tile[i] % ST);
-    });
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EMU * S::PRO_WAIT) : "memory");
-    __builtin_amdgcn_s_barrier();
-    int sidx = 0, v = 0;
-    auto tileL = [&](auto RR) {
-      constexpr int R = decltype(RR)::value;
-      static_for<NP>([&](auto PP) {
-        constexpr int P = decltype(PP)::value;
-        static_for<S::n_issue[P]>([&](auto E) {
-          constexpr int e = decltype(E)::value;
-          constexpr int u = S::issue_unit[P][e], d = S::issue_delta[P][e];
-          if constexpr (R == 0 || d < R) {
-            int stg = sidx + d;
-            if (stg >= ST) stg -= ST;
-            issue(IC<u>{}, d, stg);
-          }
-        });
-        if constexpr (S::wait[R][P] >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EMU * S::wait[R][P]) : "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-      });
-      ++v;
-      va[0] = va[1]; vb[0] = vb[1]; va[1] = va[2]; vb[1] = vb[2];
-      locate(v + 2, va[2], vb[2]);
-      sidx = sidx + 1 == ST ? 0 : sidx + 1;
-    };
-    for (int t = 0; t < V - S::NTAIL; ++t) tileL(IC<0>{});
-    static_for<S::NTAIL>([&](auto I) { tileL(IC<S::NTAIL - decltype(I)::value>{}); });
-    __builtin_amdgcn_s_barrier();                                // group 0's cadence: one closing barrier
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------- compute waves
-  const int wr = wave & 3, wc = wave >> 2;                       // wc = ping-pong group
-  f32x4 acc[2][2][NF];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NF; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[WIDE ? 2 : 1][2][2], fb[3][2];
-  const int rho = lane >> 4;
-  constexpr int NQ = NF / 2;
-
-  auto epilogue = [&](int jtile) {
-    int tm, tn;
-    tile_rc(jtile, tm, tn);
-    const long m0 = (long)tm * 256, n0 = (long)tn * BN;
-    float cs[NQ > 0 ? NQ : 1][8];
-#pragma unroll
-    for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cs[q][e] = 0.f;
-    float bias8[NQ > 0 ? NQ : 1][8];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) epi_bias8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, bias8[q]);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int h = b >> 1, i = b & 1;
-      const long row = m0 + wr * 64 + h * 32 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        float v8[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[h][i][2 * q][e]), __float_as_uint(acc[h][i][2 * q + 1][e]), false, false);
-          v8[e] = __uint_as_float(r[0]); v8[4 + e] = __uint_as_float(r[1]);
-        }
-        const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
-        EpiIn8 in;
-        epi_in8<EPI>(p, row, col, in);
-        epi_out8<EPI>(p, v8, bias8[q], in, row, col);
-        if (EPI == EPI_DGELU_BF16) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) cs[q][e] += v8[e];
-        }
-      }
-      if constexpr (NF & 1) epi_store<EPI>(p, acc[h][i][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
-#pragma unroll
-      for (int j = 0; j < NF; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (EPI == EPI_DGELU_BF16 && p.colsum_part) {
-      // per-128-row column sums (the FFN1 bias gradient): 16 lanes -> 1 by shuffles, then the two wave rows of a half through
-      // float atomics into the zero-initialised output (two adders per address: order-independent up to one rounding)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = cs[q][e];
-          t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-          if ((lane & 15) == 0)
-            atomicAdd(p.colsum_part + ((long)tm * 2 + (wr >> 1)) * p.N + n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8 + e, t);
-        }
-    }
-  };
-
-  __builtin_amdgcn_s_barrier();                                  // the prologue's barrier (its DMA was the loaders')
-  if (wc == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one barrier behind group 0
-  int sidx = 0, kt = 0, jtile = 0;
-  auto tileC = [&]() {
-    const char* st = smem + sidx * STAGE;
-    static_for<NP>([&](auto PP) {
-      constexpr int P = decltype(PP)::value;
-      constexpr int h = S::phase_h[P], j = S::phase_j[P];
-      if constexpr (WIDE) {
-        if constexpr (P == 0) {
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks) fa[hh][i][ks] = frag16_row(st, wr * 64 + hh * 32 + i * 16, ks * 32);
-        }
-      } else if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fa[0][i][ks] = frag16_row(st, wr * 64 + h * 32 + i * 16, ks * 32);
-      }
-      if constexpr (P == 0 || S::phase_j[P] != S::phase_j[P == 0 ? 0 : P - 1]) {
-        const char* pb = st + PP_A_BYTES + j * BPART;
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-            fb[jj][ks] = BT ? frag16_col(pb, wc * 48 + jj * 16, ks * 32) : frag16_row(pb, wc * 48 + jj * 16, ks * 32);
-      }
-      if constexpr (WIDE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before the barrier: war = 1
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(CAREL_PP_MPRIO);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int hh = (WIDE ? 0 : h); hh < (WIDE ? 2 : h + 1); ++hh)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj)
-              acc[hh][i][j * 3 + jj] = mfma16(fb[jj][ks], fa[WIDE ? hh : 0][i][ks], acc[hh][i][j * 3 + jj]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    sidx = sidx + 1 == ST ? 0 : sidx + 1;
-    if (++kt == nk) {                                            // tile complete: fire its stores, go on with the next tile
-      epilogue(jtile);
-      kt = 0; ++jtile;
-    }
-  };
-  for (int t = 0; t < V; ++t) tileC();
-  if (wc == 0) __builtin_amdgcn_s_barrier();
-}
-
-template <int NPN, bool BT, int EPI, int NLW, bool WIDE>
-int launch_ppl(GemmParams p, hipStream_t s) {
-  using G = PPGeom<NPN, BT>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_ppl_kernel<NPN, BT, EPI, NLW, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_ppl_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr = true;
-  }
-  p.tiles_m = p.M / 256; p.tiles_n = p.N / (96 * NPN);
-  const int tiles = p.tiles_m * p.tiles_n;
-  if (EPI == EPI_DGELU_BF16 && p.colsum_part) {                  // accumulated with atomics in the epilogue
-    hipError_t e = hipMemsetAsync(p.colsum_part, 0, (size_t)(p.M / 128) * p.N * 4, s);
-    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_ppl_kernel: memset: %s", hipGetErrorString(e));
-  }
-  hipLaunchKernelGGL((gemm_ppl_kernel<NPN, BT, EPI, NLW, WIDE>), dim3(tiles < 256 ? tiles : 256), dim3(512 + 64 * NLW), G::LDS, s, p);
-  return check_launch("gemm_ppl_kernel");
-}
-
 template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
 int launch_pp(GemmParams p, int splits, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
@@ -677,7 +385,7 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
   return check_launch("gemm_pp_kernel");
 }
 
-static int g_pp_wide = 0;        // tuning hook (carel_gemm_set_variant(90 / 91)): the wide-phase schedule where it is built (npn 2)
+static int g_pp_wide = 1;        // tuning hook (carel_gemm_set_variant(90 / 91)): the fine (12-MFMA phases) / wide-phase schedule
 
 template <bool BT, int EPI>
 int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
@@ -740,19 +448,27 @@ int gemm_pp_pick_tn(const GemmParams& p, int splits) {
 
 // The split-K factor the ping-pong kernel wants for dW[M,N] = A^T B over K tokens: as many slices as keep <= 256
 // workgroups of the wider tile, each with at least 8 K tiles, at most 16 slabs.  0 = shape not supported.
+static int g_pp_wgrad_force = 0;   // tuning hook (carel_gemm_set_variant(100 + s)): this split-K factor for every supported weight gradient
+void gemm_pp_wgrad_force(int s) { g_pp_wgrad_force = (s >= 0 && s <= 16) ? s : 0; }
+
 int gemm_pp_wgrad_splits(int M, int N, long K) {
   if (M % 256 || N % 96 || K % 64 || K < 512) return 0;
-  // measured at K = 8192 (tools/bench_gemm_pp.py, GEMM + slab reduction): 768 x 3072 / 3072 x 768: 64 us vs 82 us with the 128x128
-  // kernel; 2304 x 768: 56.4 vs 53.9; 768 x 768: 33.5 vs 31.2 -- the small outputs need so many K slices to fill 256 CUs that the
-  // slab traffic eats the gain, so they stay on the 128x128 kernel
-  if ((long)M * N < 2000000L) return 0;
+  if (g_pp_wgrad_force) { const long m = (K >> 6) / 4; return (int)(g_pp_wgrad_force < m ? g_pp_wgrad_force : m); }
+  // Measured with the wide schedule (tools/bench_wgrad_splits.py, GEMM + slab reduction, T = 8192 / 4096, us; 128x128 kernel first):
+  //   768 x 768   (12 tiles): 32.0 | s4 32.2  s6 27.3  s8 25.1  s10 26.0  s12 31.9        / 23.7 | s8 19.9
+  //   2304 x 768  (36 tiles): 54.3 | s2 55.8  s3 45.4  s4 54.3  s5 50.0  s7 47.3  s8 67.8 / 35.0 | s3 30.7
+  //   768 x 3072  (48 tiles): 84.4 | s2 58.2  s3 66.3  s4 57.7  s5 54.7  s6 80.5          / 52.3 | s2 36.8  s5 39.7
+  // More than 256 workgroups is a second round (always worse).  A small output pays for every extra slab (written and read back: 2 x
+  // 4 M N bytes per slice), and the K tile of a slice runs faster while fewer CUs compete for L2: its optimum is near 100-110
+  // workgroups; the wide FFN outputs want the chip filled.
   const int npn = N % 192 == 0 ? 2 : 1;
   const long tiles = (long)(M / 256) * (N / (96 * npn));
-  long s = 256 / tiles;
+  long s = ((long)M * N < 2000000L ? 112 : 256) / tiles;
   const long nk = K >> 6;
   if (s > nk / 8) s = nk / 8;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
+  if (tiles * s < 64) return 0;      // short token counts: too few K tiles to slice -- the 128x128 kernel's finer tiles fill the chip better
   return (int)s;
 }
 
@@ -773,42 +489,7 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s) {  
 }
 #endif
 
-static int g_pp_loader = 0;      // tuning hook (carel_gemm_set_variant(80 / 81)): the loader-wave persistent variant off / on
-void gemm_pp_loader_variant(int on) { g_pp_loader = (on >= 0 && on <= 2) ? on : 0; }
-
-// mode 1: two loader waves, fine schedule (the first experiment); mode 2: four loader waves -- with the wide schedule for npn 1
-// (12 waves = 3 per SIMD leave 170 registers per wave: the wide npn-2 kernel's 190-200 do not fit), fine for npn 2
-template <bool BT, int EPI>
-static int launch_ppl_n(const GemmParams& p, int npn, hipStream_t s) {
-  if (g_pp_loader == 2) {
-    if (npn == 1) return launch_ppl<1, BT, EPI, 4, true>(p, s);
-    return launch_ppl<2, BT, EPI, 4, false>(p, s);
-  }
-  if (npn == 1) return launch_ppl<1, BT, EPI, 2, false>(p, s);
-  return launch_ppl<2, BT, EPI, 2, false>(p, s);
-}
-
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {
-  const int nk = p.K >> 6;
-  if (g_pp_loader && npn <= 2 && p.M % 256 == 0 && nk >= 4) {
-    const int tiles = (p.M / 256) * (p.N / (96 * npn));
-    if (tiles <= 256 || tiles % 8 == 0) {
-      if (!bt) {
-        switch (epi) {
-          case EPI_BIAS_BF16: return launch_ppl_n<false, EPI_BIAS_BF16>(p, npn, s);
-          case EPI_BIAS_GELU: return launch_ppl_n<false, EPI_BIAS_GELU>(p, npn, s);
-          case EPI_BIAS_DROP_RESID: return launch_ppl_n<false, EPI_BIAS_DROP_RESID>(p, npn, s);
-          case EPI_ADD_F32: return launch_ppl_n<false, EPI_ADD_F32>(p, npn, s);
-        }
-      } else {
-        switch (epi) {
-          case EPI_BIAS_BF16: return launch_ppl_n<true, EPI_BIAS_BF16>(p, npn, s);
-          case EPI_DGELU_BF16: return launch_ppl_n<true, EPI_DGELU_BF16>(p, npn, s);
-          case EPI_ADD_F32: return launch_ppl_n<true, EPI_ADD_F32>(p, npn, s);
-        }
-      }
-    }
-  }
   if (!bt) {
     switch (epi) {
       case EPI_BIAS_BF16: return launch_pp_n<false, EPI_BIAS_BF16>(p, npn, s);

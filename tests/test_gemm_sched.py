@@ -10,9 +10,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gemm_sched as G  # noqa: E402
 
 
+def _all_configs():
+    """(npn, stages, lead cap, wide, war): the fine schedules and the wide-phase ones the kernel runs by default"""
+    return [(npn, st, G.LEADS[npn], False, 2) for npn, st in G.CONFIGS.items()] + [(npn, st, None, True, 1) for npn, st in G.WIDE_CONFIGS.items()]
+
+
 def test_schedules_have_no_hazards_and_tables_reproduce_every_wait():
-    for npn, stages in G.CONFIGS.items():
-        s, tabs, ntail = G.describe(npn, stages, G.LEADS[npn])
+    for (npn, stages, cap, wide, war) in _all_configs():
+        s, tabs, ntail = G.describe(npn, stages, cap, wide, war)
         while ntail > 1 and tabs[ntail] == tabs[0]:
             ntail -= 1
         NP = s["NP"]
@@ -23,12 +28,23 @@ def test_schedules_have_no_hazards_and_tables_reproduce_every_wait():
             for t in range(nk):
                 R = nk - t
                 tab = tabs[R] if R <= ntail else tabs[0]
-                assert [w[t * NP + p] for p in range(NP)] == tab, (npn, nk, t)
+                assert [w[t * NP + p] for p in range(NP)] == tab, (npn, wide, nk, t)
             assert G.prologue_of(s, nk) == pro12
 
 
+def test_wide_schedule_restages_one_phase_after_the_last_read_and_keeps_a_k_tile_in_flight():
+    """war = 1 is only legal because the kernel drains lgkmcnt before the barrier that ends a load segment; the payoff is a
+    lead of S * NP - 1 phases, i.e. every unit is issued at least one whole K tile before the wait that retires it."""
+    for npn, stages in G.WIDE_CONFIGS.items():
+        s = G.make(npn, stages, None, True, 1)
+        assert s["NP"] == npn and all(d == stages * npn - 1 for d in s["lead"].values())
+        assert min(s["lead"].values()) - 1 >= npn            # flight (issue -> wait) of at least NP phases = one K tile
+        src = open(os.path.join(ROOT, "carel_vae_amd", "csrc", "gemm_pp.hip")).read()
+        assert 'if constexpr (WIDE) asm volatile("s_waitcnt lgkmcnt(0)"' in src
+
+
 def test_every_unit_is_two_dma_instructions_and_lds_fits():
-    for npn, stages in G.CONFIGS.items():
+    for npn, stages in list(G.CONFIGS.items()) + list(G.WIDE_CONFIGS.items()):
         for bpart in (12288, 16384):
             if npn == 3 and bpart == 16384:
                 continue                                   # NN form is built for npn 1, 2

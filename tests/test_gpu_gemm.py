@@ -194,14 +194,15 @@ def test_internal_split_k_with_workspace_matches_single_pass():
 # kernels add the K tiles in the same order with the same MFMA, so on shapes both accept they must agree BIT FOR BIT.
 # ---------------------------------------------------------------------------------------------------------------
 class _variant:
-    """v: kernel choice (1 = 128x128 only, 3 = ping-pong wherever possible); loader = 1: its loader-wave persistent variant"""
-    def __init__(self, v, loader=0): self.v, self.loader = v, loader
+    """v: kernel choice (1 = 128x128 only, 3 = ping-pong wherever possible); wide: the ping-pong kernel's schedule
+    (1 = wide phases, the default; 0 = the fine 12-MFMA phases)"""
+    def __init__(self, v, wide=1): self.v, self.wide = v, wide
     def __enter__(self):
         L.check(L.load().carel_gemm_set_variant(self.v))
-        L.check(L.load().carel_gemm_set_variant(80 + self.loader))
+        L.check(L.load().carel_gemm_set_variant(90 + self.wide))
     def __exit__(self, *a):
         L.check(L.load().carel_gemm_set_variant(0))
-        L.check(L.load().carel_gemm_set_variant(80))
+        L.check(L.load().carel_gemm_set_variant(91))
 
 
 def _ints(shape, seed, lo=-3, hi=4):
@@ -209,33 +210,33 @@ def _ints(shape, seed, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=g).float().cuda().bfloat16()
 
 
-@pytest.mark.parametrize("loader", [0, 1])
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("form", ["NT", "NN"])
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (8192, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 2304),
                                    (256, 96, 256), (2176, 192, 320), (1000, 288, 448), (3000, 576, 1024), (768, 192, 256), (2048, 960, 512)])
-def test_pp_exact_integers(form, M, N, K, loader):
+def test_pp_exact_integers(form, M, N, K, wide):
     """Exact small-integer data at the production shapes (M = 8192 x {768, 2304, 3072}) and at ragged M (edge rows are
     masked) / every npn: any stale LDS tile, wrong fragment map or missed k step shows as an integer difference."""
     A = _ints((M, K), 1)
     B = _ints((N, K), 2) if form == "NT" else _ints((K, N), 2)
     out = torch.full((M + 8, N), 7.0, device="cuda")          # 8 guard rows: nothing past row M may be written
-    with _variant(3, loader):
+    with _variant(3, wide):
         gemm(A, B, L.GEMM_NT if form == "NT" else L.GEMM_NN, L.EPI_ADD_F32, M, N, K, out_f32=out)
     ref = A.double() @ (B.double().t() if form == "NT" else B.double())
     assert torch.equal(out[:M].double(), ref), float((out[:M].double() - ref).abs().max())
     assert torch.equal(out[M:], torch.full((8, N), 7.0, device="cuda"))
 
 
-@pytest.mark.parametrize("loader", [0, 1])
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
-def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, loader):
+def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, wide):
     M = 1024
     A, W, b = _rand((M, K), 1, 41).bfloat16(), _rand((N, K), 0.05, 42).bfloat16(), _rand((N,), 0.1, 43)
     Wn = _rand((K, N), 0.05, 44).bfloat16()
     r, u = _rand((M, N), 1, 45), _rand((M, N), 1.5, 46).bfloat16()
     res = {}
     for v in (1, 3):
-        with _variant(v, loader if v == 3 else 0):
+        with _variant(v, wide):
             o = {}
             o["qkv"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
             gemm(A, W, L.GEMM_NT, L.EPI_BIAS_BF16, M, N, K, out_bf16=o["qkv"], bias=b)
@@ -258,14 +259,14 @@ def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, loader):
             assert torch.equal(res[3][k], res[1][k]), (k, float((res[3][k].float() - res[1][k].float()).abs().max()))
 
 
-@pytest.mark.parametrize("loader", [0, 1])
-def test_pp_race_screen_repeated_launches(loader):
+@pytest.mark.parametrize("wide", [1, 0])
+def test_pp_race_screen_repeated_launches(wide):
     """20 launches of each production shape on fresh random data, compared with the first launch bit for bit while a
     second stream keeps the memory system busy (uneven load is what exposes a too-early LDS read)."""
     M = 8192
     side = torch.cuda.Stream()
     junk = torch.empty(64 << 20, device="cuda")
-    with _variant(3, loader):
+    with _variant(3, wide):
         for (N, K, form) in [(2304, 768, "NT"), (3072, 768, "NT"), (768, 3072, "NT"), (3072, 768, "NN"), (768, 2304, "NN")]:
             A = _rand((M, K), 1, 51).bfloat16()
             B = (_rand((N, K), 0.05, 52) if form == "NT" else _rand((K, N), 0.05, 52)).bfloat16()
@@ -321,7 +322,7 @@ def test_pp_wgrad_equal_slices_bitwise_equal_128_tile():
 def test_wgrad_splits_helper_matches_what_the_kernels_accept():
     lib = L.load()
     for (M, N) in [(768, 3072), (3072, 768), (768, 768), (2304, 768)]:
-        for T in (8192, 4096, 1920, 1024):
+        for T in (8192, 4096, 1920, 1664, 1024, 640, 512, 128):          # packed batches give any multiple of 128 tokens
             for v in (0, 1, 3):
                 with _variant(v):
                     s = lib.carel_gemm_wgrad_splits(M, N, T)
@@ -329,5 +330,5 @@ def test_wgrad_splits_helper_matches_what_the_kernels_accept():
                     dY, X = _rand((T, M), 1, 65).bfloat16(), _rand((T, N), 1, 66).bfloat16()
                     slabs = torch.empty((s, M, N), device="cuda")
                     gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, M, N, T, splits=s, out_f32=slabs)
-                    if T == 1024 and v != 1:
+                    if T <= 1664 and v != 1:
                         assert rel_err(slabs.sum(0), dY.double().t() @ X.double()) < TOL

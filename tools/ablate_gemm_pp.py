@@ -19,7 +19,7 @@ names = {3: "full", 61: "no DMA", 62: "no MFMA", 63: "no reads", 64: "no epilogu
 WIDE = int(os.environ.get("WIDE", 0))
 L.check(lib.carel_gemm_set_variant(90 + WIDE))
 print("wide-phase schedule" if WIDE else "fine schedule")
-for (M, N, K) in [(8192, 2304, 768), (8192, 3072, 768), (4096, 3072, 768), (8192, 768, 3072), (8192, 768, 768)]:
+for (M, N, K) in [(8192, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 768)]:
     A, B = rnd(M, K), rnd(N, K)
     out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     bias = torch.zeros(N, device="cuda")
@@ -31,4 +31,4 @@ for (M, N, K) in [(8192, 2304, 768), (8192, 3072, 768), (4096, 3072, 768), (8192
             f(); t = timed(f)
             if r: res[v].append(t)
     print("M=%d N=%d K=%d: " % (M, N, K) + " | ".join("%s %.1f us" % (names[v], statistics.median(res[v])) for v in names), flush=True)
-L.check(lib.carel_gemm_set_variant(0)); L.check(lib.carel_gemm_set_variant(90))
+L.check(lib.carel_gemm_set_variant(0)); L.check(lib.carel_gemm_set_variant(91))

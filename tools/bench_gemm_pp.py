@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Encoder GEMM shapes at T = 8192 (random data): the 128x128 kernel (variant 1) vs the ping-pong kernel (variant 3),
+"""Encoder GEMM shapes at T = 8192 (random data): the 128x128 kernel (variant 1) vs the ping-pong kernel (variant 3; fine and wide schedule),
 interleaved rounds in one process (median of 5 rounds x 20 launches), plus the vendor BLAS (torch.mm, plain GEMM without
 epilogue) as the reference point.  Measurement only; the product never calls the vendor library."""
 import os, sys, statistics
@@ -27,7 +27,7 @@ def timed(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-tot = {1: 0.0, 3: 0.0, "ppl": 0.0, "ppw": 0.0, "ppl4": 0.0, "blas": 0.0}
+tot = {1: 0.0, 3: 0.0, "ppw": 0.0, "blas": 0.0}
 for name, form, epi, M, N, K in shapes:
     A = rnd(M, K)
     B = rnd(N, K) if form == L.GEMM_NT else rnd(K, N)
@@ -35,16 +35,15 @@ for name, form, epi, M, N, K in shapes:
               out_f32=torch.empty((M, N), device="cuda"), bias=torch.zeros(N, device="cuda"), resid=torch.zeros((M, N), device="cuda"),
               aux=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), drop=(1, 2, 0, 0.1))
     if epi == L.EPI_DGELU_BF16: kw["colsum_part"] = torch.empty((M // 128, N), device="cuda")
-    def run(v):                                     # "ppl": the ping-pong kernel's loader-wave persistent variant (hook 81)
-        L.check(lib.carel_gemm_set_variant(3 if v in ("ppl", "ppw", "ppl4") else v))
-        L.check(lib.carel_gemm_set_variant(81 if v == "ppl" else 82 if v == "ppl4" else 80))     # ppl4: four loader waves (hook 82)
-        L.check(lib.carel_gemm_set_variant(91 if v == "ppw" else 90))      # "ppw": the wide-phase schedule (hook 91)
+    def run(v):                                     # 3 ("pp"): the ping-pong kernel with the fine schedule (hook 90); "ppw": wide phases (91, default)
+        L.check(lib.carel_gemm_set_variant(3 if v == "ppw" else v))
+        L.check(lib.carel_gemm_set_variant(91 if v == "ppw" else 90))
         return lambda: gemm(A, B, form, epi, M, N, K, **kw)
     Bm = B.t() if form == L.GEMM_NT else B
     fns = {1: run, 3: run}
-    ts = {1: [], 3: [], "ppl": [], "ppw": [], "ppl4": [], "blas": []}
+    ts = {1: [], 3: [], "ppw": [], "blas": []}
     for rnd_i in range(6):
-        for v in (1, 3, "ppl", "ppw", "ppl4"):
+        for v in (1, 3, "ppw"):
             f = run(v); f(); t = timed(f)
             if rnd_i: ts[v].append(t)
         f = lambda: torch.mm(A, Bm); f(); t = timed(f)
@@ -52,11 +51,11 @@ for name, form, epi, M, N, K in shapes:
     med = {k: statistics.median(v) for k, v in ts.items()}
     fl = 2.0 * M * N * K
     for k in tot: tot[k] += med[k]
-    print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp %6.1f us %5.0f TF (min %6.1f) | ppl %6.1f us %5.0f TF (min %6.1f) | ppw %6.1f us %5.0f TF | ppl4 %6.1f us %5.0f TF | blas %6.1f us %5.0f TF" % (
-        name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, min(ts[3]), med["ppl"], fl / med["ppl"] / 1e6, min(ts["ppl"]), med["ppw"], fl / med["ppw"] / 1e6, med["ppl4"], fl / med["ppl4"] / 1e6,
+    print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp %6.1f us %5.0f TF | ppw %6.1f us %5.0f TF (min %6.1f) | blas %6.1f us %5.0f TF" % (
+        name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, med["ppw"], fl / med["ppw"] / 1e6, min(ts["ppw"]),
         med["blas"], fl / med["blas"] / 1e6), flush=True)
-L.check(lib.carel_gemm_set_variant(80)); L.check(lib.carel_gemm_set_variant(90))
-print("sum: v1 %.1f us  pp %.1f us  ppl %.1f us  ppw %.1f us  ppl4 %.1f us  blas %.1f us" % (tot[1], tot[3], tot["ppl"], tot["ppw"], tot["ppl4"], tot["blas"]))
+L.check(lib.carel_gemm_set_variant(91))
+print("sum: v1 %.1f us  pp %.1f us  ppw %.1f us  blas %.1f us" % (tot[1], tot[3], tot["ppw"], tot["blas"]))
 # tile width experiments: npn forced (variant 70 + n) on the wide GEMMs
 for name, form, epi, M, N, K in [s for s in shapes if s[4] >= 2304]:
     A = rnd(M, K); B = rnd(N, K) if form == L.GEMM_NT else rnd(K, N)
@@ -94,4 +93,4 @@ for name, M, N in [("wgrad FFN2 TN", 768, 3072), ("wgrad FFN1 TN", 3072, 768), (
     fl = 2.0 * M * N * T
     print("%-14s M=%5d N=%5d K=%5d | v1/s%d %6.1f us %5.0f TF | pp/s%d %6.1f us %5.0f TF | ppw %6.1f us %5.0f TF" % (name, M, N, T, res[1][0][1], m1, fl / m1 / 1e6, res[3][0][1], m3, fl / m3 / 1e6, m4, fl / m4 / 1e6), flush=True)
 print("wgrad sum (GEMM + reduce): v1 %.1f us  pp %.1f us  ppw %.1f us" % (wt[1], wt[3], wt[4]))
-L.check(lib.carel_gemm_set_variant(0)); L.check(lib.carel_gemm_set_variant(90))
+L.check(lib.carel_gemm_set_variant(0)); L.check(lib.carel_gemm_set_variant(91))

@@ -47,6 +47,11 @@ def run(passes, verbose=True, layers=12):
         bad += (not ok)
         if verbose:
             print("pass %2d B=%2d shape %s loss %.6f %s" % (it, B, shape, res[0][0], "ok" if ok else "MISMATCH"), flush=True)
+            if not ok:
+                for k in res[0][1]:
+                    if not torch.equal(res[0][1][k], res[1][1][k]):
+                        d = (res[0][1][k] - res[1][1][k]).abs()
+                        print("    %-60s %8d of %8d differ, max %.3e (|g| max %.3e)" % (k, int((d > 0).sum()), d.numel(), float(d.max()), float(res[0][1][k].abs().max())), flush=True)
     return bad
 
 

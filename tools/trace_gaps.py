@@ -1,22 +1,20 @@
 #!/usr/bin/env python3
-"""Idle gaps between consecutive kernels from a rocprofv3 --kernel-trace CSV: python tools/trace_gaps.py <kernel_trace.csv>"""
+"""Idle time between consecutive kernels of one training step in a rocprofv3 kernel trace (serial run: one stream, so every gap
+is GPU idle time): total, and grouped by the kernel that FOLLOWS the gap.  python tools/trace_gaps.py trace.csv"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda x: x[0])
-# steady-state window: the last 60 % of the trace
-lo = int(len(ks) * 0.4)
-ks = ks[lo:]
-busy = sum(e - s for s, e, _ in ks)
-span = ks[-1][1] - ks[0][0]
-gaps = collections.Counter(); gsum = collections.Counter()
-tot_gap = 0
-for (s0, e0, n0), (s1, e1, n1) in zip(ks, ks[1:]):
-    g = s1 - e0
-    if g > 0:
-        tot_gap += g
-        key = n0.split("(")[0][:40] + " -> " + n1.split("(")[0][:40]
-        gaps[key] += 1; gsum[key] += g
-print("kernels %d  span %.3f ms  busy %.3f ms (%.1f%%)  idle between kernels %.3f ms (%.1f%%)" % (len(ks), span / 1e6, busy / 1e6, 100 * busy / span, tot_gap / 1e6, 100 * tot_gap / span))
-print("mean gap %.2f us" % (tot_gap / max(1, len(ks) - 1) / 1e3))
-for k, v in gsum.most_common(25):
-    print("%8.1f us total  %5d x  %6.2f us  %s" % (v / 1e3, gaps[k], v / gaps[k] / 1e3, k))
+def nm(r): return r["Kernel_Name"].split("(")[0].replace("void carel::", "").replace("carel::", "").replace("(anonymous namespace)::", "")[:44]
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm(r)) for r in rows)
+starts = [e[0] for e in ev if e[2].startswith("embed_fwd")]
+s0, s1 = starts[-4], starts[-3]
+step = [e for e in ev if s0 <= e[0] < s1]
+busy = sum(e[1] - e[0] for e in step)
+print("step %.3f ms: %d kernels, busy %.3f ms, idle %.3f ms" % ((s1 - s0) / 1e6, len(step), busy / 1e6, (s1 - s0 - busy) / 1e6))
+by = collections.defaultdict(lambda: [0, 0])
+bk = collections.defaultdict(lambda: [0, 0])
+for a, b in zip(step, step[1:]):
+    g = max(0, b[0] - a[1]); by[b[2]][0] += g; by[b[2]][1] += 1
+for e in step: bk[e[2]][0] += e[1] - e[0]; bk[e[2]][1] += 1
+print("%-46s %6s %9s %9s | %9s %9s" % ("kernel", "n", "busy us", "avg us", "gap-before us", "avg gap"))
+for k, (d, c) in sorted(bk.items(), key=lambda x: -x[1][0] - by[x[0]][0]):
+    print("%-46s %6d %9.1f %9.1f | %9.1f %9.1f" % (k, c, d / 1e3, d / c / 1e3, by[k][0] / 1e3, by[k][0] / max(1, by[k][1]) / 1e3))
