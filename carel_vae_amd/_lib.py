@@ -173,7 +173,7 @@ class EnTailArgs(C.Structure):
 
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32 = range(6)
+EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32, EPI_BIAS_GELU_DG, EPI_MUL_BF16 = range(8)
 
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header exports
 SIGNATURES = {

@@ -128,6 +128,13 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
   f32x2 ez;
   return pk_splat(0.5f) * x * (pk_splat(1.0f) + erf_as2(x * pk_splat(0.70710678118654752f), ez));
 }
+// both at once (one erf, one exp): g = gelu(x), dg = gelu'(x); the same operations as the two functions above
+__device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& g, f32x2& dg) {
+  f32x2 ez;
+  const f32x2 one_p = pk_splat(1.0f) + erf_as2(x * pk_splat(0.70710678118654752f), ez);
+  g = pk_splat(0.5f) * x * one_p;
+  dg = pk_fma(x * pk_splat(0.39894228040143268f), ez, pk_splat(0.5f) * one_p);
+}
 __device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {
   f32x2 ez;
   const f32x2 cdf = pk_splat(0.5f) * (pk_splat(1.0f) + erf_as2(x * pk_splat(0.70710678118654752f), ez));

@@ -222,12 +222,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       const float4 a = *(const float4*)(ct + r * CT_LD + c8), b = *(const float4*)(ct + r * CT_LD + c8 + 4);
       float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       epi_store8<EPI>(p, v, m0 + r, n0 + h * 64 + c8);
-      if (EPI == EPI_DGELU_BF16) {
+      if (epi_is_dgelu(EPI)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[e] += v[e];
       }
     }
-    if (EPI == EPI_DGELU_BF16 && p.colsum_part) {       // block-uniform branch
+    if (epi_is_dgelu(EPI) && p.colsum_part) {       // block-uniform branch
       __syncthreads();
       float* sc = ct;                                     // [32][64] partial column sums
 #pragma unroll
@@ -379,14 +379,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_big(GemmParams p) {
           const float4 a = *(const float4*)(ct + r * CT_LD + cchunk * 8), b = *(const float4*)(ct + r * CT_LD + cchunk * 8 + 4);
           float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
           epi_store8<EPI>(p, v, m0 + r, n0 + h * 48 + cchunk * 8);
-          if (EPI == EPI_DGELU_BF16) {
+          if (epi_is_dgelu(EPI)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[r >> 7][e] += v[e];
           }
         }
       }
     }
-    if (EPI == EPI_DGELU_BF16 && p.colsum_part) {       // per-128-row partial column sums (bias gradient), block-uniform
+    if (epi_is_dgelu(EPI) && p.colsum_part) {       // per-128-row partial column sums (bias gradient), block-uniform
       __syncthreads();
       float* sc = ct;                                     // [2][85][48]
       if (rbase < 85) {
@@ -647,9 +647,9 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
 #define NEED(ptr, what) if (!(ptr)) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: epilogue needs " what)
   switch (epi) {
     case EPI_BIAS_BF16: NEED(p.out0, "out_bf16"); break;
-    case EPI_BIAS_GELU: NEED(p.out0, "out_bf16"); NEED(p.out1, "out2_bf16"); break;
+    case EPI_BIAS_GELU: case EPI_BIAS_GELU_DG: NEED(p.out0, "out_bf16"); NEED(p.out1, "out2_bf16"); break;
     case EPI_BIAS_DROP_RESID: NEED(p.outf, "out_f32"); NEED(p.resid, "resid_f32"); break;
-    case EPI_DGELU_BF16: NEED(p.out0, "out_bf16"); NEED(p.aux, "aux_bf16"); break;
+    case EPI_DGELU_BF16: case EPI_MUL_BF16: NEED(p.out0, "out_bf16"); NEED(p.aux, "aux_bf16"); break;
     case EPI_ADD_F32: NEED(p.outf, "out_f32"); break;
     case EPI_SLAB_F32: NEED(p.outf, "out_f32"); break;
     default: return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: unknown epilogue %d", epi);
@@ -660,6 +660,7 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
     switch (epi) {
       case EPI_BIAS_BF16: return launch<false, false, EPI_BIAS_BF16>(p, 1, stream);
       case EPI_BIAS_GELU: return launch<false, false, EPI_BIAS_GELU>(p, 1, stream);
+      case EPI_BIAS_GELU_DG: return launch<false, false, EPI_BIAS_GELU_DG>(p, 1, stream);
       case EPI_BIAS_DROP_RESID: return launch<false, false, EPI_BIAS_DROP_RESID>(p, 1, stream);
       case EPI_ADD_F32: return launch<false, false, EPI_ADD_F32>(p, 1, stream);
     }
@@ -667,6 +668,7 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
     switch (epi) {
       case EPI_BIAS_BF16: return launch<false, true, EPI_BIAS_BF16>(p, 1, stream);
       case EPI_DGELU_BF16: return launch<false, true, EPI_DGELU_BF16>(p, 1, stream);
+      case EPI_MUL_BF16: return launch<false, true, EPI_MUL_BF16>(p, 1, stream);
       case EPI_ADD_F32: return launch<false, true, EPI_ADD_F32>(p, 1, stream);
     }
   } else if (form == CAREL_GEMM_TN) {

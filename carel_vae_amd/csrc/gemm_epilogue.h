@@ -14,7 +14,14 @@ enum : int {
   EPI_DGELU_BF16 = 3,       // out0(bf16) = acc * gelu'(aux_bf16)                     (dgrad of FFN2)
   EPI_ADD_F32 = 4,          // outf(f32) = acc + resid(f32)?                          (dgrad of QKV / FFN1)
   EPI_SLAB_F32 = 5,         // outf[z](f32) = acc                                     (wgrad split-K)
+  EPI_BIAS_GELU_DG = 6,     // out0(bf16) = gelu'(u) ; out1(bf16) = gelu(u), u = bf16(acc+bias)   (FFN1 when a backward follows)
+  EPI_MUL_BF16 = 7,         // out0(bf16) = acc * aux_bf16                             (dgrad of FFN2 on the saved gelu'(u))
 };
+// The encoder saves gelu'(u) instead of u: the forward epilogue has erf(u / sqrt 2) and exp(-u^2 / 2) in registers anyway, and the
+// backward epilogue then costs one multiply per element instead of an erf and an exp (it was VALU-bound on them: ~5 us per tile).
+constexpr bool epi_is_gelu(int e) { return e == EPI_BIAS_GELU || e == EPI_BIAS_GELU_DG; }
+constexpr bool epi_is_dgelu(int e) { return e == EPI_DGELU_BF16 || e == EPI_MUL_BF16; }      // aux-scaled output + optional column sums
+constexpr bool epi_has_bias(int e) { return e == EPI_BIAS_BF16 || epi_is_gelu(e) || e == EPI_BIAS_DROP_RESID; }
 
 struct GemmParams {
   const bf16_t* A; const bf16_t* B;
@@ -41,7 +48,7 @@ struct GemmParams {
 template <int EPI>
 __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
   const long off = row * p.ldc + col;
-  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
+  if (epi_has_bias(EPI)) {
     if (p.bias) {
       const float4 b = *(const float4*)(p.bias + col);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -57,6 +64,12 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
     uint2 g = {pack2bf(gelu_erf(u0), gelu_erf(u1)), pack2bf(gelu_erf(u2), gelu_erf(u3))};
     *(uint2*)(p.out1 + off) = g;
+  } else if (EPI == EPI_BIAS_GELU_DG) {
+    const f32x2 ua = {bf2f(f2bf(v[0])), bf2f(f2bf(v[1]))}, ub = {bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))};
+    f32x2 ga, gb, da, db;
+    gelu_erf_both2(ua, ga, da); gelu_erf_both2(ub, gb, db);
+    *(uint2*)(p.out0 + off) = uint2{pack2bf(da.x, da.y), pack2bf(db.x, db.y)};
+    *(uint2*)(p.out1 + off) = uint2{pack2bf(ga.x, ga.y), pack2bf(gb.x, gb.y)};
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r = *(const float4*)(p.resid + off);
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
@@ -72,6 +85,11 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     const float u2 = bf2f((bf16_t)(a.y & 0xffff)), u3 = bf2f((bf16_t)(a.y >> 16));
     uint2 o = {pack2bf(v[0] * gelu_erf_grad(u0), v[1] * gelu_erf_grad(u1)),
                pack2bf(v[2] * gelu_erf_grad(u2), v[3] * gelu_erf_grad(u3))};
+    *(uint2*)(p.out0 + off) = o;
+  } else if (EPI == EPI_MUL_BF16) {
+    const uint2 a = *(const uint2*)(p.aux + off);
+    uint2 o = {pack2bf(v[0] * bf2f((bf16_t)(a.x & 0xffff)), v[1] * bf2f((bf16_t)(a.x >> 16))),
+               pack2bf(v[2] * bf2f((bf16_t)(a.y & 0xffff)), v[3] * bf2f((bf16_t)(a.y >> 16)))};
     *(uint2*)(p.out0 + off) = o;
   } else if (EPI == EPI_ADD_F32) {
     float4 o = {v[0], v[1], v[2], v[3]};
@@ -103,7 +121,7 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 struct EpiIn8 { float4 r0, r1; uint4 a; };
 template <int EPI>
 __device__ __forceinline__ void epi_bias8(const GemmParams& p, long col, float* b) {
-  if ((EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) && p.bias) {
+  if (epi_has_bias(EPI) && p.bias) {
     const float4 b0 = *(const float4*)(p.bias + col), b1 = *(const float4*)(p.bias + col + 4);
     b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
   }
@@ -112,13 +130,13 @@ template <int EPI>
 __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col, EpiIn8& in) {
   const long off = row * p.ldc + col;
   if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) { in.r0 = *(const float4*)(p.resid + off); in.r1 = *(const float4*)(p.resid + off + 4); }
-  if (EPI == EPI_DGELU_BF16) in.a = *(const uint4*)(p.aux + off);
+  if (epi_is_dgelu(EPI)) in.a = *(const uint4*)(p.aux + off);
 }
 // after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
 template <int EPI>
 __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col) {
   const long off = row * p.ldc + col;
-  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RESID) {
+  if (epi_has_bias(EPI)) {
     if (p.bias) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += b[e];
@@ -134,6 +152,17 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
     *(uint4*)(p.out1 + off) = pack8(u);
+  } else if (EPI == EPI_BIAS_GELU_DG) {
+    float u[8], d[8];
+    unpack8(pack8(v), u);     // both on the bf16-rounded pre-activation (what the reference's backward would see saved in bf16)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      f32x2 g, dg;
+      gelu_erf_both2(f32x2{u[e], u[e + 1]}, g, dg);
+      u[e] = g.x; u[e + 1] = g.y; d[e] = dg.x; d[e + 1] = dg.y;
+    }
+    *(uint4*)(p.out0 + off) = pack8(d);
+    *(uint4*)(p.out1 + off) = pack8(u);
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r0 = in.r0, r1 = in.r1;
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
@@ -148,6 +177,12 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
     unpack8(in.a, u);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf_grad2(f32x2{u[e], u[e + 1]}); v[e] *= g.x; v[e + 1] *= g.y; }
+    *(uint4*)(p.out0 + off) = pack8(v);
+  } else if (EPI == EPI_MUL_BF16) {
+    float u[8];
+    unpack8(in.a, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= u[e];
     *(uint4*)(p.out0 + off) = pack8(v);
   } else if (EPI == EPI_ADD_F32) {
     float4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};

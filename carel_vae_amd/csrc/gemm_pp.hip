@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   auto row_of = [&](int b) { return m0 + (AT ? (b >> 1) * 128 + wr * 32 : wr * 64 + (b >> 1) * 32) + (b & 1) * 16 + (lane & 15); };
   // (npn 3 with a residual / aux input has no registers for two blocks of inputs: load and use block by block there;
   // the encoder never runs that combination -- N = 2304 is the bias-only QKV projection)
-  constexpr bool PIPE = NPN < 3 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_SLAB_F32;
+  constexpr bool PIPE = NPN < 3 || EPI == EPI_BIAS_BF16 || epi_is_gelu(EPI) || EPI == EPI_SLAB_F32;
   EpiIn8 in[PIPE ? 2 : 1][NQ > 0 ? NQ : 1];
   auto load_block = [&](int b, EpiIn8* dst) {
     const long row = row_of(b);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
       if (ok) {
         epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col);
-        if (EPI == EPI_DGELU_BF16) {
+        if (epi_is_dgelu(EPI)) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
         }
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       if (row < (long)p.M) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
     }
   }
-  if (EPI == EPI_DGELU_BF16 && p.colsum_part) {                // block-uniform; dispatcher guarantees NF even here
+  if (epi_is_dgelu(EPI) && p.colsum_part) {                // block-uniform; dispatcher guarantees NF even here
     // per-128-row column sums of the stored values (the FFN1 bias gradient): 16 lanes -> 1, then wave rows 2r, 2r+1
     float* sc = (float*)smem;                                  // [4 wave rows][BN]; every LDS read / DMA has retired
 #pragma unroll
@@ -404,14 +404,14 @@ void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
 // npn (1..3) when the ping-pong kernel should run this GEMM, 0 when it cannot or should not.
 int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
   if (p.N % 96 || p.K % 64 || p.K < 256 || p.M < 1) return 0;
-  if (bt ? !(epi == EPI_BIAS_BF16 || epi == EPI_DGELU_BF16 || epi == EPI_ADD_F32)
-         : !(epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RESID || epi == EPI_ADD_F32)) return 0;
+  if (bt ? !(epi == EPI_BIAS_BF16 || epi_is_dgelu(epi) || epi == EPI_ADD_F32)
+         : !(epi == EPI_BIAS_BF16 || epi_is_gelu(epi) || epi == EPI_BIAS_DROP_RESID || epi == EPI_ADD_F32)) return 0;
   const int tiles_m = (p.M + 255) / 256;
   int best = 0; double best_score = 0.0;
   for (int npn = bt ? 2 : 3; npn >= 1; --npn) {
     if (p.N % (96 * npn)) continue;
     if (g_pp_force_npn && npn != g_pp_force_npn && p.N % (96 * g_pp_force_npn) == 0 && !(bt && g_pp_force_npn == 3)) continue;
-    if (epi == EPI_DGELU_BF16 && p.colsum_part && (npn & 1)) continue;      // the fused column sums need fragment pairs
+    if (epi_is_dgelu(epi) && p.colsum_part && (npn & 1)) continue;      // the fused column sums need fragment pairs
     const long tiles = (long)tiles_m * (p.N / (96 * npn));
     const long rounds = (tiles + 255) / 256;
     const double fill = (double)tiles / (double)(rounds * 256);           // share of the CU-rounds that do work
@@ -494,6 +494,7 @@ int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s
     switch (epi) {
       case EPI_BIAS_BF16: return launch_pp_n<false, EPI_BIAS_BF16>(p, npn, s);
       case EPI_BIAS_GELU: return launch_pp_n<false, EPI_BIAS_GELU>(p, npn, s);
+      case EPI_BIAS_GELU_DG: return launch_pp_n<false, EPI_BIAS_GELU_DG>(p, npn, s);
       case EPI_BIAS_DROP_RESID: return launch_pp_n<false, EPI_BIAS_DROP_RESID>(p, npn, s);
       case EPI_ADD_F32: return launch_pp_n<false, EPI_ADD_F32>(p, npn, s);
     }
@@ -501,6 +502,7 @@ int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s
     switch (epi) {
       case EPI_BIAS_BF16: return launch_pp_n<true, EPI_BIAS_BF16>(p, npn, s);
       case EPI_DGELU_BF16: return launch_pp_n<true, EPI_DGELU_BF16>(p, npn, s);
+      case EPI_MUL_BF16: return launch_pp_n<true, EPI_MUL_BF16>(p, npn, s);
       case EPI_ADD_F32: return launch_pp_n<true, EPI_ADD_F32>(p, npn, s);
     }
   }

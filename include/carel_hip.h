@@ -62,6 +62,9 @@ const char* carel_last_error(void);
 #define CAREL_EPI_DGELU_BF16 3      /* out_bf16 = acc * gelu_erf'(aux_bf16)                      */
 #define CAREL_EPI_ADD_F32 4         /* out_f32 = acc (+ resid_f32)                               */
 #define CAREL_EPI_SLAB_F32 5        /* out_f32[z] = acc of K-slice z   (z < splits)              */
+#define CAREL_EPI_BIAS_GELU_DG 6    /* u = bf16(acc + bias): out_bf16 = gelu_erf'(u) ; out2_bf16 = gelu_erf(u)  (NT form; what the
+                                       training encoder saves: the backward epilogue then needs no erf / exp)   */
+#define CAREL_EPI_MUL_BF16 7        /* out_bf16 = acc * aux_bf16  (NN form; colsum_part as for DGELU)            */
 
 typedef struct carel_gemm_args {
   const void* A;        /* bf16 */
@@ -88,7 +91,7 @@ typedef struct carel_gemm_args {
   void* colsum_a;       /* optional, CAREL_GEMM_TN only: f32 [splits][M] = sum over the K (token) dimension of A[k][m] per
                            K-slice, i.e. the bias gradient that goes with the weight gradient; computed with one extra
                            ones-vector MFMA per step in the first tile column */
-  void* colsum_part;    /* optional, CAREL_EPI_DGELU_BF16 only: f32 [M/128][N] per-row-tile column sums of the output
+  void* colsum_part;    /* optional, CAREL_EPI_DGELU_BF16 / CAREL_EPI_MUL_BF16 only: f32 [M/128][N] per-row-tile column sums of the output
                            (pre-rounding); summing them over M/128 gives the FFN1 bias gradient */
 } carel_gemm_args;
 

@@ -63,6 +63,34 @@ def test_forward_dropout_residual_epilogue(p):
     assert rel_err(out, y + r.double()) < TOL
 
 
+@pytest.mark.parametrize("M", [256, 8192])
+def test_gelu_derivative_saved_by_the_forward_equals_dgelu_of_the_saved_preactivation(M):
+    """What the training encoder runs: FFN1 saves gelu'(u) (EPI_BIAS_GELU_DG) and the FFN2 data gradient multiplies by it
+    (EPI_MUL_BF16).  Against the older pair (save u, EPI_DGELU_BF16 evaluates gelu'(u) in backward): the gelu outputs are
+    bit-identical, the saved derivative is the bf16 rounding of the fp32 derivative the old backward computed, so du differs
+    by that one rounding (2^-9 relative) -- and both agree with fp64 to bf16 accuracy.  Bias-gradient column sums included."""
+    N, K = 3072, 768
+    A, W, b = _rand((M, K), 1, 71).bfloat16(), _rand((N, K), 0.05, 72).bfloat16(), _rand((N,), 0.1, 73)
+    u, g = (torch.empty((M, N), device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    gp, g2 = torch.empty_like(u), torch.empty_like(u)
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out_bf16=u, out2_bf16=g, bias=b)
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU_DG, M, N, K, out_bf16=gp, out2_bf16=g2, bias=b)
+    assert torch.equal(g, g2)
+    ud = u.double()
+    ref_gp = 0.5 * (1 + torch.erf(ud / math.sqrt(2))) + ud * torch.exp(-0.5 * ud * ud) / math.sqrt(2 * math.pi)
+    assert float((gp.double() - ref_gp).abs().max()) < 2 ** -8            # |gelu'| <= 1.13: half a bf16 ulp there is 2^-9 * 1.13
+    dy, W2 = _rand((M, 768), 1, 74).bfloat16(), _rand((768, N), 0.05, 75).bfloat16()
+    du_old, du_new = torch.empty_like(u), torch.empty_like(u)
+    cs_old, cs_new = (torch.empty((M // 128, N), device="cuda") for _ in range(2))
+    gemm(dy, W2, L.GEMM_NN, L.EPI_DGELU_BF16, M, N, 768, out_bf16=du_old, aux=u, colsum_part=cs_old)
+    gemm(dy, W2, L.GEMM_NN, L.EPI_MUL_BF16, M, N, 768, out_bf16=du_new, aux=gp, colsum_part=cs_new)
+    ref = (dy.double() @ W2.double()) * ref_gp
+    assert rel_err(du_old, ref) < TOL_BF16 and rel_err(du_new, ref) < TOL_BF16
+    exact = (dy.double() @ W2.double()) * gp.double()                     # the new epilogue's own definition
+    assert rel_err(du_new, exact) < TOL_BF16 / 2
+    assert rel_err(cs_new.sum(0), exact.sum(0)) < 1e-4 and rel_err(cs_old.sum(0), ref.sum(0)) < 1e-4
+
+
 def test_dgrad_nn_forms():
     M, Nout, Nin = 384, 3072, 768            # dX[M,Nin] = dY[M,Nout] @ W[Nout,Nin]
     dY, W = _rand((M, Nout), 1, 11).bfloat16(), _rand((Nout, Nin), 0.05, 12).bfloat16()
@@ -242,6 +270,8 @@ def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, wide):
             gemm(A, W, L.GEMM_NT, L.EPI_BIAS_BF16, M, N, K, out_bf16=o["qkv"], bias=b)
             o["u"], o["g"] = torch.empty_like(o["qkv"]), torch.empty_like(o["qkv"])
             gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out_bf16=o["u"], out2_bf16=o["g"], bias=b)
+            o["gp"], o["g2"] = torch.empty_like(o["qkv"]), torch.empty_like(o["qkv"])
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU_DG, M, N, K, out_bf16=o["gp"], out2_bf16=o["g2"], bias=b)
             o["h"] = torch.empty((M, N), device="cuda")
             gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=o["h"], bias=b, resid=r, drop=(9, 5, 3 * N, 0.1))
             o["dx"] = torch.empty((M, N), device="cuda")
@@ -251,9 +281,12 @@ def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, wide):
             if N % 192 == 0:           # the fused column sums pair two 16-column fragments: even npn
                 o["du"], o["cs"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M // 128, N), device="cuda")
                 gemm(A, Wn, L.GEMM_NN, L.EPI_DGELU_BF16, M, N, K, out_bf16=o["du"], aux=u, colsum_part=o["cs"])
+                o["dm"], o["cs_m"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M // 128, N), device="cuda")
+                gemm(A, Wn, L.GEMM_NN, L.EPI_MUL_BF16, M, N, K, out_bf16=o["dm"], aux=u, colsum_part=o["cs_m"])
             res[v] = o
+    assert torch.equal(res[3]["g2"], res[3]["g"])           # the gelu output does not depend on which companion is saved
     for k in res[1]:
-        if k == "cs":       # column sums: same addends, different summation tree
+        if k in ("cs", "cs_m"):       # column sums: same addends, different summation tree
             assert rel_err(res[3][k], res[1][k]) < 1e-5
         else:
             assert torch.equal(res[3][k], res[1][k]), (k, float((res[3][k].float() - res[1][k].float()).abs().max()))

@@ -13,8 +13,10 @@ T = int(os.environ.get("T", 8192))
 shapes = [("fwd QKV   NT", L.GEMM_NT, L.EPI_BIAS_BF16, T, 2304, 768),
           ("fwd out   NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, T, 768, 768),
           ("fwd FFN1  NT", L.GEMM_NT, L.EPI_BIAS_GELU, T, 3072, 768),
+          ("fwd FFN1+dg NT", L.GEMM_NT, L.EPI_BIAS_GELU_DG, T, 3072, 768),
           ("fwd FFN2  NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, T, 768, 3072),
           ("dgrad FFN2 NN", L.GEMM_NN, L.EPI_DGELU_BF16, T, 3072, 768),
+          ("dgrad FFN2* NN", L.GEMM_NN, L.EPI_MUL_BF16, T, 3072, 768),
           ("dgrad FFN1 NN", L.GEMM_NN, L.EPI_ADD_F32, T, 768, 3072),
           ("dgrad out  NN", L.GEMM_NN, L.EPI_BIAS_BF16, T, 768, 768),
           ("dgrad QKV  NN", L.GEMM_NN, L.EPI_ADD_F32, T, 768, 2304),
@@ -34,7 +36,7 @@ for name, form, epi, M, N, K in shapes:
     kw = dict(out_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16), out2_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16),
               out_f32=torch.empty((M, N), device="cuda"), bias=torch.zeros(N, device="cuda"), resid=torch.zeros((M, N), device="cuda"),
               aux=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), drop=(1, 2, 0, 0.1))
-    if epi == L.EPI_DGELU_BF16: kw["colsum_part"] = torch.empty((M // 128, N), device="cuda")
+    if epi in (L.EPI_DGELU_BF16, L.EPI_MUL_BF16): kw["colsum_part"] = torch.empty((M // 128, N), device="cuda")
     def run(v):                                     # 3 ("pp"): the ping-pong kernel with the fine schedule (hook 90); "ppw": wide phases (91, default)
         L.check(lib.carel_gemm_set_variant(3 if v == "ppw" else v))
         L.check(lib.carel_gemm_set_variant(91 if v == "ppw" else 90))
