@@ -611,6 +611,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }
   if (v >= 100 && v <= 116) { gemm_pp_wgrad_force(v - 100); return CAREL_OK; }         // ping-pong weight gradient: split-K factor forced (0 = heuristic)
+  if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles
   if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
   g_gemm_variant = v;
   return CAREL_OK;

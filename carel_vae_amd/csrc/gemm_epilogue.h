@@ -40,6 +40,8 @@ struct GemmParams {
   float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
   int split_tile_factor;    // internal split-K heuristic: the caller runs this many equal GEMMs side by side (1 = just this one)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
+  int pp_xr, pp_bc;         // ping-pong kernel, NT / NN: the 8 XCDs tile the grid as pp_xr x (8 / pp_xr) rectangles, each walked in
+                            // column blocks of pp_bc tiles (so that a round of 32 tiles per XCD is compact); pp_xr = 0: plain chunks
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -216,6 +218,7 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s);   
 // as possible -- the slices need not be equal, so any split factor works)
 void gemm_pp_force_npn(int n);
 void gemm_pp_wide_variant(int on);
+void gemm_pp_xcd_rect(int on);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);

@@ -39,6 +39,7 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+static int g_pp_xcd_rect = 1;    // tuning hook (carel_gemm_set_variant(120 / 121)): XCD tile map of the NT / NN forms: row-major chunks / rectangles
 constexpr int PP_A_BYTES = 32768;
 #ifndef CAREL_PP_MPRIO
 #define CAREL_PP_MPRIO 1           // s_setprio level of the matrix segment (experiment: CAREL_EXTRA_FLAGS=-DCAREL_PP_MPRIO=0)
@@ -73,12 +74,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   // One tile per workgroup.  (A persistent loop over tiles was built and measured: the next tile's first counted vmcnt
   // wait then absorbs the previous tile's store acknowledgements, and those arrive at the HBM write rate -- an XCD's 32 CUs
   // write more per round than its L2 holds -- so nothing overlapped, and the loop-carried state cost 40-60 VGPRs.)
-  int tm, tn;
+  int tm, tn, kz = 0;                                            // kz = K slice (weight-gradient form), not blockIdx.z: see below
   {
-    const int nwg = p.tiles_m * p.tiles_n, bid = blockIdx.x;
-    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int tid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    tm = tid / p.tiles_n; tn = tid - tm * p.tiles_n;
+    const int tiles = p.tiles_m * p.tiles_n;
+    // position in dispatch order (x fastest, then z); workgroups are dealt to the XCDs round-robin in that order
+    const int flat = (int)blockIdx.x + (int)blockIdx.z * tiles, nwg = tiles * (int)gridDim.z;
+    const int xcd = flat & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (flat >> 3);   // contiguous chunk per XCD
+    if (AT) {
+      // weight gradient: items ordered (K slice, N tile, M tile) -- an XCD's ~nwg/8 workgroups share ONE K slice of both operands
+      // (or two neighbouring ones) and a few tile columns, instead of touching every slice (PMC: 180 MB fetched per launch for 63 MB
+      // of operands with the x-then-z order)
+      kz = item / tiles;
+      const int t = item - kz * tiles;
+      tn = t / p.tiles_m; tm = t - tn * p.tiles_m;
+    } else if (p.pp_xr) {
+      const int xc = 8 / p.pp_xr, R = p.tiles_m / p.pp_xr, C = p.tiles_n / xc, local = flat >> 3;
+      const int xi = xcd / xc, xj = xcd - xi * xc;
+      const int per = R * p.pp_bc, blk = local / per, rem = local - blk * per;
+      const int r = rem / p.pp_bc;
+      tm = xi * R + r; tn = xj * C + blk * p.pp_bc + (rem - r * p.pp_bc);
+    } else {
+      tm = item / p.tiles_n; tn = item - tm * p.tiles_n;
+    }
   }
   const long m0 = (long)tm * 256, n0 = (long)tn * BN;
 
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
   // K range of this z slice: the K tiles are dealt to gridDim.z slices as evenly as possible (slices may differ by one)
   const int nk_all = p.K >> 6;
-  const int kt0 = (int)(((long)blockIdx.z * nk_all) / gridDim.z), kt1 = (int)(((long)(blockIdx.z + 1) * nk_all) / gridDim.z);
+  const int kt0 = (int)(((long)kz * nk_all) / gridDim.z), kt1 = (int)(((long)(kz + 1) * nk_all) / gridDim.z);
   const int nk = kt1 - kt0;
   const long a_step = AT ? 64 * p.lda * 2 : 128, b_step = BT ? 64 * p.ldb * 2 : 128;
   const char* a_ptr = (const char*)(AT ? p.A + m0 : p.A + m0 * p.lda) + kt0 * a_step;      // first K tile of the slice
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) p.colsum_a[(long)blockIdx.z * p.M + m0 + h * 128 + wr * 32 + i * 16 + lane] = acc1[h][i][0];
+      for (int i = 0; i < 2; ++i) p.colsum_a[(long)kz * p.M + m0 + h * 128 + wr * 32 + i * 16 + lane] = acc1[h][i][0];
   }
   if (DBG == 4) {
 #pragma unroll
@@ -294,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   // ---- epilogue: accumulators -> fused epilogue, 8 consecutive columns per lane ---------------------------------------
   // Row blocks b = (h, i) of 16 rows; the inputs (residual / pre-GELU rows) of block b + 1 are requested before block b is
   // stored, the bias once per column group up front: no load ever queues behind a store of its own wave (see epi_in8).
+  if (EPI == EPI_SLAB_F32) p.outf += ((long)kz - (long)blockIdx.z) * p.M * p.ldc;      // the shared epilogue indexes slabs by blockIdx.z
   const int rho = lane >> 4;
   constexpr int NQ = NF / 2;
   float cs[NQ > 0 ? NQ : 1][8];
@@ -381,6 +400,25 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
     attr = true;
   }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
+  p.pp_xr = 0; p.pp_bc = 1;
+  if (!AT && g_pp_xcd_rect) {
+    // XCD rectangles: the partition xr x (8 / xr) of the tile grid whose rectangles stage the fewest operand rows (R x 256 of A plus
+    // C x 96 npn of B), each walked in column blocks so that one round (32 tiles per XCD) is compact too: FFN1 forward then keeps
+    // half of W1 (2.4 MB) + four row blocks of A (1.5 MB) in a 4-MiB L2 per round instead of streaming all of W1 through it twice
+    long best = -1;
+    for (int xr = 8; xr >= 1; xr >>= 1) {
+      const int xc = 8 / xr;
+      if (p.tiles_m % xr || p.tiles_n % xc) continue;
+      const long cost = (long)(p.tiles_m / xr) * 256 + (long)(p.tiles_n / xc) * 96 * NPN;
+      if (best < 0 || cost < best) { best = cost; p.pp_xr = xr; }
+    }
+    if (p.pp_xr) {
+      const int R = p.tiles_m / p.pp_xr, C = p.tiles_n / (8 / p.pp_xr);
+      int bc = 1;
+      for (int d = 1; d <= C; ++d) if (C % d == 0 && (long)R * d <= 32) bc = d;
+      p.pp_bc = bc;
+    }
+  }
   hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
   return check_launch("gemm_pp_kernel");
 }
@@ -398,6 +436,7 @@ int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
 }  // namespace
 
 void gemm_pp_wide_variant(int on) { g_pp_wide = on ? 1 : 0; }
+void gemm_pp_xcd_rect(int on) { g_pp_xcd_rect = on ? 1 : 0; }
 static int g_pp_force_npn = 0;     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
 void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
 

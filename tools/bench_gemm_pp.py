@@ -37,9 +37,9 @@ for name, form, epi, M, N, K in shapes:
               out_f32=torch.empty((M, N), device="cuda"), bias=torch.zeros(N, device="cuda"), resid=torch.zeros((M, N), device="cuda"),
               aux=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), drop=(1, 2, 0, 0.1))
     if epi in (L.EPI_DGELU_BF16, L.EPI_MUL_BF16): kw["colsum_part"] = torch.empty((M // 128, N), device="cuda")
-    def run(v):                                     # 3 ("pp"): the ping-pong kernel with the fine schedule (hook 90); "ppw": wide phases (91, default)
+    def run(v):                                     # 3 ("pp"): the ping-pong kernel with row-major XCD chunks (hook 120); "ppw": XCD rectangles (121, default)
         L.check(lib.carel_gemm_set_variant(3 if v == "ppw" else v))
-        L.check(lib.carel_gemm_set_variant(91 if v == "ppw" else 90))
+        L.check(lib.carel_gemm_set_variant(121 if v == "ppw" else 120))
         return lambda: gemm(A, B, form, epi, M, N, K, **kw)
     Bm = B.t() if form == L.GEMM_NT else B
     fns = {1: run, 3: run}
@@ -53,10 +53,10 @@ for name, form, epi, M, N, K in shapes:
     med = {k: statistics.median(v) for k, v in ts.items()}
     fl = 2.0 * M * N * K
     for k in tot: tot[k] += med[k]
-    print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp %6.1f us %5.0f TF | ppw %6.1f us %5.0f TF (min %6.1f) | blas %6.1f us %5.0f TF" % (
+    print("%-14s M=%5d N=%5d K=%5d | v1 %6.1f us %5.0f TF | pp/chunks %6.1f us %5.0f TF | pp/rect %6.1f us %5.0f TF (min %6.1f) | blas %6.1f us %5.0f TF" % (
         name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, med["ppw"], fl / med["ppw"] / 1e6, min(ts["ppw"]),
         med["blas"], fl / med["blas"] / 1e6), flush=True)
-L.check(lib.carel_gemm_set_variant(91))
+L.check(lib.carel_gemm_set_variant(121))
 print("sum: v1 %.1f us  pp %.1f us  ppw %.1f us  blas %.1f us" % (tot[1], tot[3], tot["ppw"], tot["blas"]))
 # tile width experiments: npn forced (variant 70 + n) on the wide GEMMs
 for name, form, epi, M, N, K in [s for s in shapes if s[4] >= 2304]:
@@ -82,7 +82,7 @@ for name, M, N in [("wgrad FFN2 TN", 768, 3072), ("wgrad FFN1 TN", 3072, 768), (
     for rnd_i in range(4):
         for v in (1, 3, 4):
             L.check(lib.carel_gemm_set_variant(3 if v == 4 else v))
-            L.check(lib.carel_gemm_set_variant(91 if v == 4 else 90))
+            L.check(lib.carel_gemm_set_variant(91 if v == 4 else 90))      # 3: fine schedule, 4: wide (default)
             sp = lib.carel_gemm_wgrad_splits(M, N, T)
             slabs = torch.empty((sp, M, N), device="cuda")
             def f():
