@@ -244,43 +244,56 @@ def input_pipeline_leg(dev, model, optim, batch_size):
 
 
 def sentence_transformer_leg(dev, steps):
-    """chi_ec_sentence_transformer.py's fit() step (:84-87): 16 sentences, BERT-base (vocab 21128), mean pooling, batch-semi-hard
-    triplet loss (margin 4.45), gradient-norm clip + AdamW; S = 128 dense and ECPE-like sentence lengths."""
+    """The fit() step (:84-87) of chi_ec_sentence_transformer.py (BERT-base, vocab 21128, margin 4.45) and of
+    en_ec_sentence_transformer.py (all-mpnet-base-v2 = MPNet-base, vocab 30527, relative-position attention bias, L2-normalised
+    embeddings; margin 5): 16 sentences, mean pooling, batch-semi-hard triplet loss, gradient-norm clip + AdamW; S = 128 dense and
+    ECPE-like sentence lengths."""
     from carel_vae_amd import drl_classifier as M
     from carel_vae_amd import sentence_transformer as S
     from carel_vae_amd.data import synthetic_ecpe_batch
-    model = S.SentenceTransformer(M.encoder_config("zh"), seed=0).to(dev)
-    model.train(True)
-    loss_mod = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45)
-    optim = S.FusedAdamW(model, lr=2e-5)
     out = {}
-    for shape in ("A", "B"):
-        feats = []
-        for i in range(4):
-            b = synthetic_ecpe_batch(16, 128, 21128, 8, seed=500 + i, shape=shape)
-            feats.append(({"input_ids": b["input_ids"].to(dev), "attention_mask": b["attention_masks"].to(dev), "token_type_ids": b["token_type_ids"].to(dev),
-                           "seq_lengths": b["attention_masks"].sum(1).tolist()}, (b["emo_labels"].view(-1) % 4).to(dev)))
+    for lang, cfg_name, vocab, margin in (("zh", "zh", 21128, 4.45), ("en_mpnet", "mpnet", 30527, 5.0)):
+        model = S.SentenceTransformer(M.encoder_config(cfg_name), seed=0).to(dev)
+        model.train(True)
+        loss_mod = S.losses.BatchSemiHardTripletLoss(model=model, margin=margin)
+        optim = S.FusedAdamW(model, lr=2e-5)
+        res = {}
+        for shape in ("A", "B"):
+            feats = []
+            for i in range(4):
+                b = synthetic_ecpe_batch(16, 128, vocab, 8, seed=500 + i, shape=shape)
+                ids = b["input_ids"]
+                if cfg_name == "mpnet":                    # <pad> = 1 for MPNet's position ids (the generator pads with 0)
+                    ids = torch.where(b["attention_masks"] == 0, torch.ones_like(ids), ids.clamp(min=3))
+                feats.append(({"input_ids": ids.to(dev), "attention_mask": b["attention_masks"].to(dev), "token_type_ids": b["token_type_ids"].to(dev),
+                               "seq_lengths": b["attention_masks"].sum(1).tolist()}, (b["emo_labels"].view(-1) % 4).to(dev)))
 
-        def step(i):
-            f, lab = feats[i % 4]
-            loss = loss_mod([f], lab)
-            loss.backward()
-            optim.step()
-            optim.zero_grad()
-            return loss
-        for i in range(3):
-            step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            loss = step(i)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["dense" if shape == "A" else "ecpe_shaped"] = {"ms_per_step": 1e3 * dt / steps, "sentences_per_s": 16 * steps / dt, "final_loss": float(loss.detach())}
-        log("sentence-transformer leg, shape %s: %.3f ms/step" % (shape, 1e3 * dt / steps))
-    out["note"] = "fit() step of chi_ec_sentence_transformer.py: B=16, S=128, BERT-base vocab 21128, dropout on, triplet margin 4.45, clip 1.0 + AdamW; one GPU; parity unpinned (see DESIGN.md)"
-    del model, optim
-    torch.cuda.empty_cache()
+            def step(i):
+                f, lab = feats[i % 4]
+                loss = loss_mod([f], lab)
+                loss.backward()
+                optim.step()
+                optim.zero_grad()
+                return loss
+            for i in range(3):
+                step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                loss = step(i)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["dense" if shape == "A" else "ecpe_shaped"] = {"ms_per_step": 1e3 * dt / steps, "sentences_per_s": 16 * steps / dt, "final_loss": float(loss.detach())}
+            log("sentence-transformer leg %s, shape %s: %.3f ms/step" % (lang, shape, 1e3 * dt / steps))
+        if lang == "zh":
+            out.update(res)
+        else:
+            out[lang] = res
+        del model, optim, loss_mod
+        torch.cuda.empty_cache()
+    out["note"] = ("fit() step: B=16, S=128, dropout on, clip 1.0 + AdamW, one GPU.  Top level: chi_ec_sentence_transformer.py (BERT-base vocab 21128, "
+                   "margin 4.45); en_mpnet: en_ec_sentence_transformer.py (MPNet-base vocab 30527 + relative-position bias + Normalize, margin 5).  "
+                   "sentence_transformers parity unpinned; the MPNet encoder restatement is pinned to transformers.MPNetModel (see DESIGN.md)")
     return out
 
 

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcarel_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CarelError(RuntimeError):
@@ -58,7 +58,7 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("batch", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p)]
+                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p), ("rel_bias_dist", C.c_void_p), ("d_rel_bias_dist", C.c_void_p)]
 
 
 class TailArgs(C.Structure):
@@ -120,7 +120,8 @@ class EncoderArgs(C.Structure):
                 ("overlap_wgrad", C.c_int32),
                 ("layer_grads", C.POINTER(LayerGrads)),
                 ("d_word_emb", C.c_void_p), ("d_pos_emb", C.c_void_p), ("d_type_emb", C.c_void_p),
-                ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p)]
+                ("d_emb_ln_g", C.c_void_p), ("d_emb_ln_b", C.c_void_p), ("dx", C.c_void_p),
+                ("rel_bias_dist", C.c_void_p), ("d_rel_bias_dist", C.c_void_p)]
 
 
 class HostPackArgs(C.Structure):
@@ -190,6 +191,8 @@ SIGNATURES = {
     "carel_mean_pool_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_triplet_semihard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "carel_grad_norm_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_l2_normalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_l2_normalize_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_rbf_mmd_fwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_rbf_mmd_bwd": (C.c_int, [C.POINTER(MmdArgs), C.c_void_p]),
     "carel_pdist_fwd": (C.c_int, [C.POINTER(PdistArgs), C.c_void_p]),
@@ -244,6 +247,8 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "carel_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "carel_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "carel_relpos_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "carel_relpos_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 _lib = None

@@ -75,17 +75,24 @@ struct AttnParams {
   int B, S;
   Dropout drop;             // element index ((b*NH + h)*S + q)*S + k
   const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
+  const float* rel;         // MPNet relative-position bias by distance: [NH][256], entry 127 + (key - query); null = none
+  float* drel;              // bwd: its gradient, accumulated with atomics by every (sample, head, layer); same layout
 };
 
 constexpr float MASK_NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, as HF adds it
 constexpr int ATTN_BWD_LDS = 16384 + 16384 + 32768 + 1024;
+constexpr int ATTN_BWD_LDS_REL = ATTN_BWD_LDS + 2048;     // + bias by distance [256] + its gradient [256]
 
 // =========================================================================================== forward
+// REL: scores += rel[h][127 + key - query] (transformers MPNetAttention: `attention_scores += position_bias`, the bias shared by all
+// layers; en_ec_sentence_transformer.py:22 loads all-mpnet-base-v2)
+template <bool REL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 512];
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 512 + (REL ? 1024 : 0)];
   char* kimg = smem;
   char* vimg = smem + 16384;
   float* maskadd = (float*)(smem + 32768);
+  float* relb = (float*)(smem + 32768 + 512);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
   const int S = p.S;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   stage_att(qbase + 2 * HID, QKV_LD, rows, vimg);
   for (int k = threadIdx.x; k < rows; k += 256)
     maskadd[k] = p.cu ? (k < len ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f);
+  if (REL) relb[threadIdx.x] = p.rel[h * 256 + threadIdx.x];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave >= nkt) return;                       // no barrier below this point
@@ -126,7 +134,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (kt < nkt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = x[kt][r] * 0.125f + maskadd[kt * 32 + acc32_row(r, lane)];
+        const int key = kt * 32 + acc32_row(r, lane);
+        float v = x[kt][r] * 0.125f;
+        if (REL) v += relb[127 + key - (q0 + (lane & 31))];
+        v += maskadd[key];
         x[kt][r] = v;
         m = fmaxf(m, v);
       }
@@ -184,13 +195,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 __device__ __forceinline__ int swz_ds(int k) { return ((k & 3) << 3) | ((k >> 2) & 7); }
 __device__ __forceinline__ int ds_off(int k, int q) { return k * 256 + ((((q >> 2) ^ swz_ds(k)) & 31) << 3) + (q & 3) * 2; }
 
+template <bool REL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // ATTN_BWD_LDS bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ATTN_BWD_LDS (+ REL: 2048) bytes
   char* qimg = smem;                 // Q  [S][64]
   char* doimg = smem + 16384;        // dO [S][64]; re-used for K in the dQ phase
   char* dsimg = smem + 32768;        // dS^T [k][q] bf16, 256-B rows
   float* lse = (float*)(smem + 65536);
   float* delta = lse + 128;
+  float* relb = (float*)(smem + ATTN_BWD_LDS);                  // REL: bias by distance, and the sums of dS over this (sample, head)
+  float* relg = relb + 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
   const int S = p.S;
@@ -202,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   const bf16_t* obase = p.ctx + row0 * HID + h * HD;
   stage_att(qbase, QKV_LD, rows, qimg);
   stage_att(dobase, HID, rows, doimg);
+  if (REL) { relb[threadIdx.x] = p.rel[h * 256 + threadIdx.x]; relg[threadIdx.x] = 0.f; }
   for (int k = threadIdx.x; k < rows; k += 256) lse[k] = k < len ? p.lse[((long)b * NH + h) * S + k] : 0.f;
   {  // delta[q] = sum_d dO[q][d] * O[q][d]; 2 threads per query, 32 d each
     const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
@@ -257,10 +272,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + acc32_row(r, lane);
         const bool live = klive && q < len;      // rows / keys past the sample belong to its neighbours: contribute exact zeros
-        const float pr = live ? __expf(sa[r] * 0.125f + madd - lse[q]) : 0.f;
+        float sc = sa[r] * 0.125f;
+        if (REL) sc += relb[127 + key - q];
+        const float pr = live ? __expf(sc + madd - lse[q]) : 0.f;
         const float dm = dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
         pd[r] = live ? pr * dm : 0.f;
-        dsv[r] = live ? pr * (dp[r] * dm - delta[q]) * 0.125f : 0.f;    // includes the 1/sqrt(d) of the scores
+        const float ds_raw = live ? pr * (dp[r] * dm - delta[q]) : 0.f;  // d loss / d score
+        dsv[r] = ds_raw * 0.125f;                                        // includes the 1/sqrt(d) of the q.k part of the scores
+        // the bias enters the scores unscaled: its gradient is the plain sum of dS over the diagonal key - query (within one
+        // instruction the 32 keys of a half-wave hit 32 different addresses)
+        if (REL && live) atomicAdd(relg + 127 + key - q, ds_raw);
       }
       // dS^T[k][q] -> LDS (4 consecutive q per register group)
 #pragma unroll
@@ -294,6 +315,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     }
   }
   __syncthreads();                           // every wave: dO image dead, dS^T complete
+  if (REL && threadIdx.x < 255) {
+    const float g = relg[threadIdx.x];
+    if (g != 0.f) atomicAdd(p.drel + h * 256 + threadIdx.x, g);
+  }
   stage_att(qbase + HID, QKV_LD, rows, doimg);  // K image for the dQ phase
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -345,6 +370,8 @@ static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who
   p->qkv = (const bf16_t*)a->qkv; p->att_mask = (const long*)a->attention_mask; p->ctx = (bf16_t*)a->ctx;
   p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
   p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens;
+  p->rel = (const float*)a->rel_bias_dist; p->drel = (float*)a->d_rel_bias_dist;
+  if (bwd && p->rel && !p->drel) return set_error(CAREL_ERR_ARG, "%s: rel_bias_dist needs d_rel_bias_dist in the backward", who);
   p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   return CAREL_OK;
 }
@@ -354,7 +381,8 @@ extern "C" int carel_attention_fwd(const carel_attn_args* a, void* stream_) {
   AttnParams p;
   int rc = attn_prepare(a, &p, "carel_attention_fwd", false);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.B * NH), dim3(256), 0, stream, p);
+  if (p.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(p.B * NH), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(p.B * NH), dim3(256), 0, stream, p);
   return check_launch("attn_fwd_kernel");
 }
 
@@ -365,10 +393,40 @@ extern "C" int carel_attention_bwd(const carel_attn_args* a, void* stream_) {
   if (rc) return rc;
   static bool attr_set = false;     // idempotent; a benign race sets it twice
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS_REL);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.B * NH), dim3(256), ATTN_BWD_LDS, stream, p);
+  if (p.rel) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(p.B * NH), dim3(256), ATTN_BWD_LDS_REL, stream, p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(p.B * NH), dim3(256), ATTN_BWD_LDS, stream, p);
   return check_launch("attn_bwd_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ MPNet relative positions
+// The learned table is relative_attention_bias.weight [32 buckets][12 heads]; bucket[i] (int32 [256], entry i = distance key - query
+// = i - 127, entry 255 unused) is computed by the caller with the very expression of transformers
+// MPNetEncoder.relative_position_bucket (a float32 log and a truncation: not re-derived here, so no rounding can differ).
+namespace carel {
+__global__ void relpos_expand_kernel(const float* table, const int* bucket, float* dist) {     // -> dist [NH][256]
+  const int h = blockIdx.x, i = threadIdx.x;
+  dist[h * 256 + i] = i < 255 ? table[bucket[i] * NH + h] : 0.f;
+}
+__global__ void relpos_reduce_kernel(const float* ddist, const int* bucket, float* dtable, int accumulate) {   // -> dtable [32][NH]
+  const int h = blockIdx.x, bkt = threadIdx.x;                                // 32 threads
+  float s = 0.f;
+  for (int i = 0; i < 255; ++i) if (bucket[i] == bkt) s += ddist[h * 256 + i];
+  dtable[bkt * NH + h] = accumulate ? dtable[bkt * NH + h] + s : s;
+}
+}  // namespace carel
+
+extern "C" int carel_relpos_expand(const void* table, const void* bucket, void* dist, void* stream) {
+  if (!table || !bucket || !dist) return set_error(CAREL_ERR_ARG, "carel_relpos_expand: null tensor");
+  hipLaunchKernelGGL(relpos_expand_kernel, dim3(NH), dim3(256), 0, (hipStream_t)stream, (const float*)table, (const int*)bucket, (float*)dist);
+  return check_launch("relpos_expand_kernel");
+}
+extern "C" int carel_relpos_reduce(const void* ddist, const void* bucket, void* dtable, int32_t accumulate, void* stream) {
+  if (!ddist || !bucket || !dtable) return set_error(CAREL_ERR_ARG, "carel_relpos_reduce: null tensor");
+  hipLaunchKernelGGL(relpos_reduce_kernel, dim3(NH), dim3(32), 0, (hipStream_t)stream, (const float*)ddist, (const int*)bucket, (float*)dtable, (int)accumulate);
+  return check_launch("relpos_reduce_kernel");
 }

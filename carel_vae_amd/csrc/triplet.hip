@@ -134,6 +134,29 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
   }
 }
 
+// models.Normalize (all-mpnet-base-v2's third module): y = x / max(||x||_2, 1e-12) per row (torch.nn.functional.normalize), and its
+// backward dx = (g - y (y . g)) / max(||x||, 1e-12).  One workgroup per row.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ norm, int hidden) {
+  __shared__ float red[8];
+  const long r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < hidden; c += 256) { const float v = x[r * hidden + c]; s += v * v; }
+  s = block_sum(s, red);
+  const float n = fmaxf(sqrtf(s), 1e-12f);
+  if (threadIdx.x == 0) norm[r] = n;
+  for (int c = threadIdx.x; c < hidden; c += 256) y[r * hidden + c] = x[r * hidden + c] / n;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ norm,
+                                                         float* __restrict__ dx, int hidden) {
+  __shared__ float red[8];
+  const long r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < hidden; c += 256) s += g[r * hidden + c] * y[r * hidden + c];
+  s = block_sum(s, red);
+  const float n = norm[r];
+  for (int c = threadIdx.x; c < hidden; c += 256) dx[r * hidden + c] = (g[r * hidden + c] - y[r * hidden + c] * s) / n;
+}
+
 }  // namespace carel
 
 using namespace carel;
@@ -149,6 +172,16 @@ extern "C" int carel_mean_pool_bwd(const void* g, const void* row_sample, const 
   hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const int*)row_sample,
                      (const int*)len, (float*)dx, (long)rows, hidden);
   return check_launch("mean_pool_bwd_kernel");
+}
+extern "C" int carel_l2_normalize_fwd(const void* x, int32_t rows, int32_t hidden, void* y, void* norm, void* stream) {
+  if (!x || !y || !norm || rows < 1 || hidden < 1) return set_error(CAREL_ERR_ARG, "carel_l2_normalize_fwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (float*)norm, hidden);
+  return check_launch("l2norm_fwd_kernel");
+}
+extern "C" int carel_l2_normalize_bwd(const void* g, const void* y, const void* norm, int32_t rows, int32_t hidden, void* dx, void* stream) {
+  if (!g || !y || !norm || !dx || rows < 1 || hidden < 1) return set_error(CAREL_ERR_ARG, "carel_l2_normalize_bwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)y, (const float*)norm, (float*)dx, hidden);
+  return check_launch("l2norm_bwd_kernel");
 }
 extern "C" int carel_triplet_semihard(const void* emb, const void* labels, int32_t batch, int32_t hidden, float margin, void* loss_out, void* demb,
                                       void* stream) {

@@ -33,12 +33,21 @@ def make_opt(**kw):
     return SimpleNamespace(**d)
 
 
+REL_KEY = "encoder.encoder.relative_attention_bias.weight"
+
+
 def encoder_config(language="zh", **kw):
-    """BERT-base geometry of `hfl/chinese-roberta-wwm-ext` (:159) or `roberta-base` (:162)."""
-    if language == "en":
+    """BERT-base geometry of `hfl/chinese-roberta-wwm-ext` (:159) or `roberta-base` (:162); "mpnet": the encoder of
+    sentence-transformers/all-mpnet-base-v2 (en_ec_sentence_transformer.py:22; transformers MPNetConfig defaults): RoBERTa-style
+    position ids, no token types (type_vocab 1 = an all-zero placeholder row that is never updated) and a learned
+    relative-position attention bias [32 buckets, 12 heads] shared by all layers (rel_pos)."""
+    if language == "mpnet":
+        cfg = dict(vocab_size=30527, max_pos=514, type_vocab=1, ln_eps=1e-5, roberta=1, pad_id=1, rel_pos=True)
+    elif language == "en":
         cfg = dict(vocab_size=50265, max_pos=514, type_vocab=1, ln_eps=1e-5, roberta=1, pad_id=1)
     else:
         cfg = dict(vocab_size=21128, max_pos=512, type_vocab=2, ln_eps=1e-12, roberta=0, pad_id=0)
+    cfg.setdefault("rel_pos", False)
     cfg.update(layers=12, hidden_dropout=0.1, attn_dropout=0.1)
     cfg.update(kw)
     return SimpleNamespace(**cfg)
@@ -92,8 +101,10 @@ class _Layer(nn.Module):
 
 
 class _Stack(nn.Module):
-    def __init__(self, n):
+    def __init__(self, n, rel_pos=False):
         super().__init__()
+        if rel_pos:      # registered BEFORE the layers: in the flat buffer it sits with the embeddings, whose gradients are the last to complete
+            self.relative_attention_bias = _Holder((32, NH), bias=False)
         self.layer = nn.ModuleList([_Layer() for _ in range(n)])
 
 
@@ -119,7 +130,7 @@ class CarelEncoder(nn.Module):
         super().__init__()
         self.config = cfg
         self.embeddings = _Embeddings(cfg)
-        self.encoder = _Stack(cfg.layers)
+        self.encoder = _Stack(cfg.layers, getattr(cfg, "rel_pos", False))
         self.pooler = _Pooler()
 
 
@@ -381,6 +392,8 @@ class DrlClassifier(nn.Module):
         e = "encoder.embeddings."
         order += [e + "word_embeddings.weight", e + "position_embeddings.weight", e + "token_type_embeddings.weight",
                   e + "LayerNorm.weight", e + "LayerNorm.bias"]
+        if getattr(self.cfg, "rel_pos", False):
+            order.append(REL_KEY)            # with the embeddings: complete only after the LAST layer's backward, like them
         for l in range(self.cfg.layers):
             p = f"encoder.encoder.layer.{l}."
             order += [p + "attention.self.query.weight", p + "attention.self.key.weight", p + "attention.self.value.weight",
@@ -579,7 +592,29 @@ class DrlClassifier(nn.Module):
         a.scratch = None if ws.scratch is None else ws.scratch.data_ptr()
         a.d_word_emb, a.d_pos_emb, a.d_type_emb = self._g(e + "word_embeddings.weight"), self._g(e + "position_embeddings.weight"), self._g(e + "token_type_embeddings.weight")
         a.d_emb_ln_g, a.d_emb_ln_b = self._g(e + "LayerNorm.weight"), self._g(e + "LayerNorm.bias")
+        if getattr(c, "rel_pos", False):
+            r = self._rel_buffers()
+            L.check(L.load().carel_relpos_expand(self._w(REL_KEY), r.bucket.data_ptr(), r.dist.data_ptr(), L.current_stream()), "carel_relpos_expand")
+            a.rel_bias_dist, a.d_rel_bias_dist = r.dist.data_ptr(), r.ddist.data_ptr()
         return a
+
+    def _rel_buffers(self):
+        """MPNet relative positions: bucket[i] = relative_position_bucket(i - 127) with the expression of transformers
+        MPNetEncoder.relative_position_bucket (num_buckets 32, max_distance 128), the bias by distance [12, 256] made from the
+        learned table before every forward, and the gradient by distance the attention backward kernels accumulate into."""
+        r = getattr(self, "_rel", None)
+        dev = self._flat.device
+        if r is None or r.bucket.device != dev:
+            rel = torch.arange(-127, 129, dtype=torch.long)
+            n = -rel
+            ret = (n < 0).to(torch.long) * 16
+            n = torch.abs(n)
+            large = 8 + (torch.log(n.float() / 8) / math.log(128 / 8) * 8).to(torch.long)
+            ret = ret + torch.where(n < 8, n, torch.min(large, torch.full_like(large, 15)))
+            r = self._rel = SimpleNamespace(bucket=ret.to(torch.int32).to(dev).contiguous(),
+                                            dist=torch.zeros((NH, 256), device=dev, dtype=torch.float32),
+                                            ddist=torch.zeros((NH, 256), device=dev, dtype=torch.float32))
+        return r
 
     @staticmethod
     def _prep_ids(t, Bp):
@@ -764,6 +799,9 @@ class DrlClassifier(nn.Module):
             if self._adam_hook is not None and not accumulate and (self._dp is None or work is not None):
                 self._adam_hook._layer_ready(l, after=work)
 
+        rel = self._rel_buffers() if getattr(self.cfg, "rel_pos", False) else None
+        if rel is not None:
+            rel.ddist.zero_()
         lag = 1 if self.overlap_wgrad else 0     # with the side stream a layer completes one call late (include/carel_hip.h)
         for l in range(self.cfg.layers - 1, -1, -1):
             L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
@@ -773,6 +811,8 @@ class DrlClassifier(nn.Module):
             L.check(lib.carel_encoder_backward_join(C.byref(ea), st), "carel_encoder_backward_join")
             layer_ready(0)
         L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
+        if rel is not None:      # fold the gradient by distance (every layer's attention backward added to it) into the table's buckets
+            L.check(lib.carel_relpos_reduce(rel.ddist.data_ptr(), rel.bucket.data_ptr(), self._g(REL_KEY), 0, st), "carel_relpos_reduce")
 
     def _bind_grads(self):
         if self._grad_views is None:

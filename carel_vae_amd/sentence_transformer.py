@@ -1,5 +1,6 @@
 """MI355X implementation of the sentence-embedding fine-tune of chi_ec_sentence_transformer.py (the zh script: a
-BERT-architecture SimCSE checkpoint) -- the names the script uses from the third-party `sentence_transformers` package:
+BERT-architecture SimCSE checkpoint) and en_ec_sentence_transformer.py (the English script: all-mpnet-base-v2 = MPNet encoder +
+mean pooling + Normalize) -- the names the scripts use from the third-party `sentence_transformers` package:
 
     from carel_vae_amd.sentence_transformer import SentenceTransformer, InputExample, losses
     model = SentenceTransformer(...)                                              (:22)
@@ -13,8 +14,11 @@ HIP kernels (csrc/triplet.hip, csrc/adam.hip).  The loop of `fit` (AdamW lr 2e-5
 max_grad_norm 1) follows the package's published defaults.  PARITY UNPINNED: the package is absent from this container and from
 the reference tree; oracle/carel_oracle_st.py restates its published algorithm and tests/test_gpu_triplet.py holds this module to
 that restatement.  Pretrained checkpoints cannot be fetched offline: the constructor takes an encoder configuration (random
-init) or a state dict with HF BertModel key names.  The English script's MPNet encoder (relative-position attention bias) is not
-built.
+init) or a state dict with HF BertModel / MPNetModel key names.  MPNet (encoder_config("mpnet")): the relative-position attention
+bias is added inside the attention kernels (csrc/attention.hip, REL instantiations; its table gradient is accumulated by distance and
+folded into the 32 buckets), the embeddings have no token types, and the sentence embedding is L2-normalised (models.Normalize);
+the MPNet encoder restatement in oracle/carel_oracle.py is pinned to the installed transformers MPNetModel
+(tests/test_oracle_triplet.py).
 """
 import ctypes as C
 import math
@@ -29,6 +33,7 @@ from . import _lib as L
 from . import drl_classifier as M
 
 H = 768
+TT_KEY = "encoder.embeddings.token_type_embeddings.weight"
 
 
 class InputExample:
@@ -97,37 +102,65 @@ class SentenceTransformer(nn.Module):
     BERT-base); tokenizer: any object with the HF `encode_plus` interface; state_dict: HF BertModel weights
     (`embeddings.*`, `encoder.layer.*`; a `pooler.*` entry is accepted and ignored like models.Transformer ignores it)."""
 
-    def __init__(self, encoder_cfg=None, tokenizer=None, max_seq_length=128, seed=None, state_dict=None):
+    def __init__(self, encoder_cfg=None, tokenizer=None, max_seq_length=128, seed=None, state_dict=None, normalize=None):
         super().__init__()
+        if isinstance(encoder_cfg, str):                 # the checkpoint names the reference scripts pass (weights are NOT fetched)
+            encoder_cfg = M.encoder_config("mpnet" if "mpnet" in encoder_cfg.lower() else "zh")
         cfg = encoder_cfg if encoder_cfg is not None else M.encoder_config("zh")
+        self.mpnet = bool(getattr(cfg, "rel_pos", False))
+        # modules.json of all-mpnet-base-v2: Transformer, Pooling(mean), Normalize; the zh SimCSE checkpoint: Transformer, Pooling
+        self.normalize = self.mpnet if normalize is None else bool(normalize)
         # the engine: a DrlClassifier whose encoder (flat fp32 parameters + bf16 shadow, workspaces, kernels) is what runs; its
         # VAE heads are never touched
         self._m = M.DrlClassifier(M.make_opt(pair_bow_dim=8), cfg, seed=seed)
         self._m.cls_only_last = False            # mean pooling reads every attended token of the last layer
         self.tokenizer, self.max_seq_length = tokenizer, int(max_seq_length)
         self._fwd = 0
+        if self.mpnet:                                   # MPNetEmbeddings has no token types: the engine's row stays zero
+            with torch.no_grad():
+                self._m._named[TT_KEY].zero_()
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
     # ---- parameters: the BertModel without its pooler ---------------------------------------------------------------
     def _enc_keys(self):
-        return [k for k in self._m._order if k.startswith("encoder.") and not k.startswith("encoder.pooler.")]
+        return [k for k in self._m._order if k.startswith("encoder.") and not k.startswith("encoder.pooler.") and not (self.mpnet and k == TT_KEY)]
+
+    # MPNetModel names its attention sub-modules attn.q / k / v / o and attention.LayerNorm; the engine stores BERT names
+    _MPNET = ((".attention.attn.q.", ".attention.self.query."), (".attention.attn.k.", ".attention.self.key."),
+              (".attention.attn.v.", ".attention.self.value."), (".attention.attn.o.", ".attention.output.dense."),
+              (".attention.LayerNorm.", ".attention.output.LayerNorm."))
+
+    def _to_internal(self, k):
+        if self.mpnet:
+            for hf, ours in self._MPNET:
+                k = k.replace(hf, ours)
+        return k
+
+    def _to_public(self, k):
+        if self.mpnet:
+            for hf, ours in self._MPNET:
+                k = k.replace(ours, hf)
+        return k
 
     def parameters(self, recurse=True):
         return iter([self._m._named[k] for k in self._enc_keys()])
 
     def named_parameters(self, prefix="", recurse=True):
-        return iter([(k[len("encoder."):], self._m._named[k]) for k in self._enc_keys()])
+        return iter([(self._to_public(k[len("encoder."):]), self._m._named[k]) for k in self._enc_keys()])
 
     def state_dict(self, *a, **k):
-        return {k_[len("encoder."):]: self._m._named[k_].detach().clone() for k_ in self._m._order if k_.startswith("encoder.")}
+        return {self._to_public(k_[len("encoder."):]): self._m._named[k_].detach().clone() for k_ in self._m._order
+                if k_.startswith("encoder.") and not (self.mpnet and k_ == TT_KEY)}
 
     def load_state_dict(self, sd, strict=True):
         full = self._m.state_dict()
         for k, v in sd.items():
-            kk = "encoder." + k
-            if kk not in full:
-                if strict:
+            if k.endswith("position_ids"):
+                continue
+            kk = "encoder." + self._to_internal(k)
+            if kk not in full or (self.mpnet and kk == TT_KEY):
+                if strict and kk != TT_KEY:
                     raise KeyError(k)
                 continue
             full[kk] = v
@@ -211,6 +244,10 @@ class SentenceTransformer(nn.Module):
         emb = torch.empty((c.B, H), device=m._flat.device, dtype=torch.float32)
         L.check(lib.carel_mean_pool_fwd(x_last, c.row0.data_ptr(), c.len_dev.data_ptr(), c.B, H, emb.data_ptr(), L.current_stream()), "carel_mean_pool_fwd")
         c.ea, c.ws = ea, ws
+        if self.normalize:                                   # models.Normalize
+            c.y, c.norm = torch.empty_like(emb), torch.empty(c.B, device=emb.device, dtype=torch.float32)
+            L.check(lib.carel_l2_normalize_fwd(emb.data_ptr(), c.B, H, c.y.data_ptr(), c.norm.data_ptr(), L.current_stream()), "carel_l2_normalize_fwd")
+            return c.y
         return emb
 
     def _backward(self, c, g):
@@ -223,10 +260,16 @@ class SentenceTransformer(nn.Module):
         dx = m._ws.get(key)
         if dx is None:
             dx = m._ws[key] = torch.empty((c.rows, H), device=g.device, dtype=torch.float32)
+        if self.normalize:
+            gp = torch.empty_like(g)
+            L.check(lib.carel_l2_normalize_bwd(g.data_ptr(), c.y.data_ptr(), c.norm.data_ptr(), c.B, H, gp.data_ptr(), L.current_stream()), "carel_l2_normalize_bwd")
+            g = gp
         L.check(lib.carel_mean_pool_bwd(g.data_ptr(), c.row_sample.data_ptr(), c.len_dev.data_ptr(), c.rows, H, dx.data_ptr(), L.current_stream()),
                 "carel_mean_pool_bwd")
         c.ea.dx = dx.data_ptr()
         m._backward_encoder(c.ea, accumulate)
+        if self.mpnet:                                       # no token types in MPNet: the placeholder row takes no gradient (and so never moves)
+            m._grad_view(TT_KEY).zero_()
         if accumulate:
             m._flat_grad.add_(prev)
         m._bind_grads()
@@ -311,7 +354,8 @@ class SentenceTransformer(nn.Module):
         torch.save(self.state_dict(), os.path.join(path, "pytorch_model.bin"))
         cfg = self._m.cfg
         with open(os.path.join(path, "carel_sentence_transformer.txt"), "w") as f:
-            f.write("architecture: BERT-base (12 x 768), pooling: mean, max_seq_length: %d, vocab_size: %d\n" % (self.max_seq_length, cfg.vocab_size))
+            f.write("architecture: %s (12 x 768), pooling: mean%s, max_seq_length: %d, vocab_size: %d\n" % (
+                "MPNet-base" if self.mpnet else "BERT-base", ", normalize" if self.normalize else "", self.max_seq_length, cfg.vocab_size))
 
 
 class WarmupLinear:

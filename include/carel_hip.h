@@ -29,7 +29,7 @@ extern "C" {
 #define CAREL_ERR_HIP (-3)    /* a HIP runtime call or launch failed    */
 
 /* ABI version of this header; carel_abi_version() must return the same number. */
-#define CAREL_ABI_VERSION 2
+#define CAREL_ABI_VERSION 3
 
 int carel_abi_version(void);
 /* Checks that `device` is a gfx950 part and records nothing else.  ref: `model.to(device)` :932 */
@@ -194,10 +194,19 @@ typedef struct carel_attn_args {
   /* token packing: sample b owns rows [cu_seqlens[b], cu_seqlens[b+1]) of qkv/ctx/dctx/dqkv and attends to exactly
    * those (attention_mask is ignored); seq_len stays the ORIGINAL padded length (dropout index, lse stride). */
   const void* cu_seqlens;      /* int32 [B+1] or NULL */
+  /* MPNet relative-position bias (transformers MPNetAttention: attention_scores += position_bias; the encoder of
+   * en_ec_sentence_transformer.py:22): f32 [heads][256], entry 127 + (key position - query position), made from the learned
+   * [32 buckets][heads] table by carel_relpos_expand; NULL = no bias (BERT / RoBERTa). */
+  const void* rel_bias_dist;
+  void* d_rel_bias_dist;       /* bwd, required with rel_bias_dist: f32 [heads][256], ACCUMULATED into (atomics); the caller zeroes
+                                  it once per step and folds it into the table gradient with carel_relpos_reduce */
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);
 int carel_attention_bwd(const carel_attn_args* args, void* stream);
+/* bucket: int32 [256], bucket[i] = relative_position_bucket(i - 127) (entry 255 unused), computed by the caller */
+int carel_relpos_expand(const void* table_f32_32xH, const void* bucket, void* dist_f32_Hx256, void* stream);
+int carel_relpos_reduce(const void* ddist_f32_Hx256, const void* bucket, void* dtable_f32_32xH, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-encoder orchestration over caller-owned buffers.  Replaces `self.encoder(...)` (ref :202-206;
@@ -257,6 +266,9 @@ typedef struct carel_encoder_args {
   const carel_layer_grads* layer_grads;     /* HOST array [n_layers] */
   void* d_word_emb; void* d_pos_emb; void* d_type_emb; void* d_emb_ln_g; void* d_emb_ln_b;
   void* dx;
+  /* MPNet relative-position bias, shared by all layers (see carel_attn_args): NULL = none.  d_rel_bias_dist is accumulated into by
+   * every layer's attention backward; the caller zeroes it before the first carel_encoder_backward_layer of a step. */
+  const void* rel_bias_dist; void* d_rel_bias_dist;
 } carel_encoder_args;
 
 /* The library's two low-priority streams of the current device (created on first use, never destroyed):
@@ -425,12 +437,16 @@ int carel_rmsprop_step(void* param_f32, const void* grad_f32, void* square_avg_f
  *     the gradient w.r.t. the embeddings for upstream gradient 1; batch <= 64; labels int32.
  *   carel_grad_norm_clip: out2 = {||grad||_2, min(1, max_norm / (norm + 1e-6))} (torch.nn.utils.clip_grad_norm_);
  *     scratch = 1024 floats; pass out2 + 1 as carel_adam_args.grad_scale_dev.
+ *   carel_l2_normalize_*: models.Normalize (the third module of all-mpnet-base-v2): y = x / max(||x||_2, 1e-12) per row; norm f32
+ *     [rows] is saved for the backward dx = (g - y (y . g)) / norm.
  * ---------------------------------------------------------------------------------------------- */
 int carel_mean_pool_fwd(const void* x_f32, const void* row0_i32, const void* len_i32, int32_t batch, int32_t hidden, void* out_f32, void* stream);
 int carel_mean_pool_bwd(const void* g_f32, const void* row_sample_i32, const void* len_i32, int64_t rows, int32_t hidden, void* dx_f32, void* stream);
 int carel_triplet_semihard(const void* emb_f32, const void* labels_i32, int32_t batch, int32_t hidden, float margin, void* loss_out_f32,
                            void* demb_f32, void* stream);
 int carel_grad_norm_clip(const void* grad_f32, int64_t n, float max_norm, void* scratch_f32, void* out2_f32, void* stream);
+int carel_l2_normalize_fwd(const void* x_f32, int32_t rows, int32_t hidden, void* y_f32, void* norm_f32, void* stream);
+int carel_l2_normalize_bwd(const void* g_f32, const void* y_f32, const void* norm_f32, int32_t rows, int32_t hidden, void* dx_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RBF-MMD statistic.  Replaces MMDStatistic.__call__ (ref :547-569) + pdist (ref :580-589) and

@@ -43,10 +43,16 @@ class EncoderConfig:
     max_pos: int = 512
     type_vocab: int = 2
     ln_eps: float = 1e-12
-    variant: str = "bert"          # "bert" (:159) or "roberta" (:162)
+    variant: str = "bert"          # "bert" (:159), "roberta" (:162) or "mpnet" (en_ec_sentence_transformer.py:22: all-mpnet-base-v2)
     pad_id: int = 0                # roberta: 1
     hidden_dropout: float = 0.1    # HF defaults, active under model.train() (:822)
     attn_dropout: float = 0.1
+    rel_pos: bool = False          # MPNet: attention_scores += relative_attention_bias[bucket(key - query)] (shared by all layers)
+
+    @staticmethod
+    def mpnet_base() -> "EncoderConfig":
+        """transformers MPNetConfig defaults (microsoft/mpnet-base, all-mpnet-base-v2): no token types, RoBERTa position ids"""
+        return EncoderConfig(vocab_size=30527, max_pos=514, type_vocab=1, ln_eps=1e-5, variant="mpnet", pad_id=1, rel_pos=True)
 
     @staticmethod
     def roberta_base() -> "EncoderConfig":
@@ -159,6 +165,8 @@ def param_shapes(cfg: EncoderConfig, opt: Opt) -> Dict[str, tuple]:
     s[e + "token_type_embeddings.weight"] = (cfg.type_vocab, H)
     s[e + "LayerNorm.weight"] = (H,)
     s[e + "LayerNorm.bias"] = (H,)
+    if cfg.rel_pos:
+        s["encoder.encoder.relative_attention_bias.weight"] = (32, cfg.heads)
     for l in range(cfg.layers):
         p = f"encoder.encoder.layer.{l}."
         for n in ("query", "key", "value"):
@@ -219,6 +227,10 @@ def init_params(cfg: EncoderConfig, opt: Opt, seed: int = 0) -> Dict[str, torch.
                 a = 1.0 + 0.05 * rs.standard_normal(shp)
             elif "LayerNorm.bias" in k or k.endswith(".bias"):
                 a = 0.02 * rs.standard_normal(shp)
+            elif "relative_attention_bias" in k:
+                a = 0.5 * rs.standard_normal(shp)          # large enough to move attention visibly in the parity tests
+            elif cfg.variant == "mpnet" and "token_type_embeddings" in k:
+                a = np.zeros(shp)                          # MPNet has no token types: the row exists only as a zero placeholder
             else:
                 a = 0.02 * rs.standard_normal(shp)
         else:
@@ -264,10 +276,33 @@ def linear(x, w, b, quant: Quant = None):
 
 def position_ids(ids: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
     B, S = ids.shape
-    if cfg.variant == "roberta":   # transformers modeling_roberta.py create_position_ids_from_input_ids
+    if cfg.variant in ("roberta", "mpnet"):   # transformers modeling_roberta.py / modeling_mpnet.py create_position_ids_from_input_ids
         m = (ids != cfg.pad_id).to(torch.int64)
         return torch.cumsum(m, dim=1) * m + cfg.pad_id
     return torch.arange(S, dtype=torch.int64).unsqueeze(0).expand(B, S)
+
+
+def mpnet_relative_position_bucket(relative_position, num_buckets=32, max_distance=128):
+    """transformers MPNetEncoder.relative_position_bucket, expression by expression (float32 log, truncation)."""
+    ret = 0
+    n = -relative_position
+    num_buckets //= 2
+    ret += (n < 0).to(torch.long) * num_buckets
+    n = torch.abs(n)
+    max_exact = num_buckets // 2
+    is_small = n < max_exact
+    val_if_large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).to(torch.long)
+    val_if_large = torch.min(val_if_large, torch.full_like(val_if_large, num_buckets - 1))
+    ret += torch.where(is_small, n, val_if_large)
+    return ret
+
+
+def mpnet_position_bias(table: torch.Tensor, S: int) -> torch.Tensor:
+    """MPNetEncoder.compute_position_bias: [1, heads, S, S], entry [h, i, j] = table[bucket(j - i), h]"""
+    ctx = torch.arange(S, dtype=torch.long)[:, None]
+    mem = torch.arange(S, dtype=torch.long)[None, :]
+    rp = mpnet_relative_position_bucket(mem - ctx)
+    return table[rp].permute(2, 0, 1).unsqueeze(0)
 
 
 def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: EncoderConfig,
@@ -283,8 +318,9 @@ def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: 
     H, nh = cfg.hidden, cfg.heads
     dh = H // nh
     e = "encoder.embeddings."
-    x = P[e + "word_embeddings.weight"][ids] + P[e + "position_embeddings.weight"][position_ids(ids, cfg)] \
-        + P[e + "token_type_embeddings.weight"][token_type]
+    x = P[e + "word_embeddings.weight"][ids] + P[e + "position_embeddings.weight"][position_ids(ids, cfg)]
+    if cfg.variant != "mpnet":     # MPNetEmbeddings has no token types (the key exists here as an all-zero, never-updated row)
+        x = x + P[e + "token_type_embeddings.weight"][token_type]
     x = layer_norm(x, P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], cfg.ln_eps)
     ph, pa = (cfg.hidden_dropout, cfg.attn_dropout) if train else (0.0, 0.0)
     m = dropout_scale_mask(seed, SITE_EMBED, (B, S, H), ph, row_offset)
@@ -292,6 +328,7 @@ def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: 
         x = x * m
     neg = torch.finfo(torch.float32).min
     mask_add = (1.0 - att_mask.to(torch.float32))[:, None, None, :] * neg      # [B,1,1,S]
+    pos_bias = mpnet_position_bias(P["encoder.encoder.relative_attention_bias.weight"], S) if cfg.rel_pos else None
     if taps is not None:
         taps["x0"] = x
     for l in range(cfg.layers):
@@ -300,7 +337,10 @@ def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: 
         k = linear(x, P[p + "attention.self.key.weight"], P[p + "attention.self.key.bias"], quant)
         v = linear(x, P[p + "attention.self.value.weight"], P[p + "attention.self.value.bias"], quant)
         q, k, v = (_q(t, quant).view(B, S, nh, dh).transpose(1, 2) for t in (q, k, v))
-        s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)) + mask_add
+        s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+        if pos_bias is not None:   # MPNetSelfAttention: scores / sqrt(d), += position_bias, += attention_mask
+            s = s + pos_bias
+        s = s + mask_add
         pr = torch.softmax(s, dim=-1)
         m = dropout_scale_mask(seed, site_attn_probs(l), (B, nh, S, S), pa, row_offset)
         if m is not None:

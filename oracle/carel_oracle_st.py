@@ -24,11 +24,34 @@ def mean_pool(hidden: torch.Tensor, att_mask: torch.Tensor) -> torch.Tensor:
     return (hidden * m).sum(1) / m.sum(1).clamp(min=1e-9)
 
 
-def encode(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: O.EncoderConfig, train=False, seed=None, quant=None) -> torch.Tensor:
-    """sentence embedding = mean pooling of the LAST hidden states (the BERT pooler is not used by models.Transformer)."""
+def encode(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: O.EncoderConfig, train=False, seed=None, quant=None,
+           normalize=None) -> torch.Tensor:
+    """sentence embedding = mean pooling of the LAST hidden states (the BERT pooler is not used by models.Transformer);
+    normalize (default: the MPNet variant only): models.Normalize, the third module of all-mpnet-base-v2 -- F.normalize(p=2, dim=1)."""
     taps = {}
     O.encoder_forward(P, ids, att_mask, token_type, cfg, train=train, seed=seed, quant=quant, taps=taps)
-    return mean_pool(taps[f"x{cfg.layers}"], att_mask)
+    emb = mean_pool(taps[f"x{cfg.layers}"], att_mask)
+    if normalize is None:
+        normalize = cfg.variant == "mpnet"
+    return torch.nn.functional.normalize(emb, p=2, dim=1) if normalize else emb
+
+
+def mpnet_key_to_internal(k: str) -> str:
+    """transformers MPNetModel state-dict key -> the BERT-style key this package (and the oracle) stores it under."""
+    k = k.replace(".attention.attn.q.", ".attention.self.query.").replace(".attention.attn.k.", ".attention.self.key.")
+    k = k.replace(".attention.attn.v.", ".attention.self.value.").replace(".attention.attn.o.", ".attention.output.dense.")
+    k = k.replace(".attention.LayerNorm.", ".attention.output.LayerNorm.")
+    return k
+
+
+def params_from_mpnet_state_dict(sd: Dict[str, torch.Tensor], cfg: O.EncoderConfig) -> Dict[str, torch.Tensor]:
+    """HF MPNetModel weights -> oracle parameter dict (keys "encoder." + internal name; zero token-type placeholder row)."""
+    P = {"encoder." + mpnet_key_to_internal(k): v.detach().clone().float() for k, v in sd.items() if not k.endswith("position_ids")}
+    P["encoder.embeddings.token_type_embeddings.weight"] = torch.zeros((1, cfg.hidden))
+    if "encoder.pooler.dense.weight" not in P:
+        P["encoder.pooler.dense.weight"] = torch.zeros((cfg.hidden, cfg.hidden))
+        P["encoder.pooler.dense.bias"] = torch.zeros(cfg.hidden)
+    return P
 
 
 def euclidean_distance(emb: torch.Tensor) -> torch.Tensor:
@@ -99,7 +122,8 @@ NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")
 
 def encoder_keys(P):
     """the parameters models.Transformer holds and uses: the whole BertModel except its pooler (no gradient -> never stepped)"""
-    return [k for k in P if k.startswith("encoder.") and not k.startswith("encoder.pooler.")]
+    return [k for k in P if k.startswith("encoder.") and not k.startswith("encoder.pooler.")
+            and not (k.endswith("token_type_embeddings.weight") and "encoder.encoder.relative_attention_bias.weight" in P)]   # MPNet: no token types
 
 
 def fit_steps(P: Dict[str, torch.Tensor], batches: List[dict], cfg: O.EncoderConfig, margin: float, lr=2e-5, weight_decay=0.01,

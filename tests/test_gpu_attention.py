@@ -131,3 +131,76 @@ def test_packed_attention_matches_per_sample_reference():
         start += n
     # rows that belong to no sample were not touched
     assert float((ctx[T:] - 7.0).abs().max()) == 0.0 and float((dqkv[T:] - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_relative_position_bias_forward_backward_and_table_gradient(packed):
+    """MPNet: scores += table[bucket(key - query), head] (transformers MPNetAttention; en_ec_sentence_transformer.py:22).  The kernels
+    read the bias by distance (carel_relpos_expand) and accumulate its gradient by distance; carel_relpos_reduce folds that into the
+    32 x 12 table.  Checked against fp64 autograd through the same bucket map, dense (padding mask) and packed, with dropout."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    S = 128
+    lens = [128, 77, 33, 5]
+    B = len(lens)
+    table = (torch.randn((32, NH), generator=g) * 0.7).cuda()
+    rp = O.mpnet_relative_position_bucket(torch.arange(-127, 129)).to(torch.int32).cuda().contiguous()      # entry i = distance i - 127
+    dist, ddist = torch.empty((NH, 256), device="cuda"), torch.zeros((NH, 256), device="cuda")
+    L.check(lib.carel_relpos_expand(table.data_ptr(), rp.data_ptr(), dist.data_ptr(), L.current_stream()), "relpos expand")
+    T = sum(lens)
+    if packed:
+        Tp = (T + 127) // 128 * 128
+        qkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device="cuda")
+        qkv[:Tp] = (torch.randn((Tp, 3 * H), generator=g) * 1.5).cuda().bfloat16()
+        dctx = torch.zeros((B * S, H), dtype=torch.bfloat16, device="cuda")
+        dctx[:Tp] = torch.randn((Tp, H), generator=g).cuda().bfloat16()
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+        mask = None
+        row0 = [int(v) for v in np.cumsum([0] + lens[:-1])]
+    else:
+        qkv = (torch.randn((B * S, 3 * H), generator=g) * 1.5).cuda().bfloat16()
+        dctx = torch.randn((B * S, H), generator=g).cuda().bfloat16()
+        mask = torch.zeros((B, S), dtype=torch.int64)
+        for b, n in enumerate(lens):
+            mask[b, :n] = 1
+            dctx[b * S + n:(b + 1) * S] = 0       # padded queries carry no gradient (nothing downstream reads them), as in the encoder
+        mask = mask.cuda()
+        cu = None
+        row0 = [b * S for b in range(B)]
+    p, seed, site = 0.1, 9, O.site_attn_probs(1)
+    a = L.AttnArgs()
+    ctx = torch.zeros((B * S, H), device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros((B, NH, S), device="cuda")
+    dqkv = torch.zeros((B * S, 3 * H), device="cuda", dtype=torch.bfloat16)
+    a.qkv, a.attention_mask, a.ctx, a.lse, a.dctx, a.dqkv = qkv.data_ptr(), (None if mask is None else mask.data_ptr()), ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dqkv.data_ptr()
+    a.batch, a.seq_len, a.heads, a.head_dim = B, S, NH, HD
+    a.drop_seed, a.drop_site, a.drop_idx_offset, a.drop_p = seed, site, 0, p
+    a.cu_seqlens = None if cu is None else cu.data_ptr()
+    a.rel_bias_dist, a.d_rel_bias_dist = dist.data_ptr(), ddist.data_ptr()
+    L.check(lib.carel_attention_fwd(C.byref(a), L.current_stream()), "attn fwd rel")
+    L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd rel")
+    dtable = torch.empty((32, NH), device="cuda")
+    L.check(lib.carel_relpos_reduce(ddist.data_ptr(), rp.data_ptr(), dtable.data_ptr(), 0, L.current_stream()), "relpos reduce")
+    torch.cuda.synchronize()
+    keep_all = torch.from_numpy(O.dropout_keep(seed, site, np.arange(B * NH * S * S, dtype=np.uint64).astype(np.uint32), p).astype(np.float64) / (1 - p)).view(B, NH, S, S).cuda()
+    tab = table.double().requires_grad_(True)
+    worst = 0.0
+    for b, n in enumerate(lens):
+        r0 = row0[b]
+        x = qkv[r0:r0 + n].double().view(n, 3, NH, HD).requires_grad_(True)
+        q, k, v = (x[:, i].transpose(0, 1) for i in range(3))
+        bias = tab[O.mpnet_relative_position_bucket(torch.arange(n)[None, :] - torch.arange(n)[:, None]).cuda()].permute(2, 0, 1)     # [NH, n, n]
+        s = q @ k.transpose(-1, -2) / math.sqrt(HD) + bias
+        pr = torch.softmax(s, dim=-1) * keep_all[b, :, :n, :n]
+        out = (pr @ v).transpose(0, 1).reshape(n, H)
+        assert rel_err(ctx[r0:r0 + n], out.detach()) < 8e-3, b
+        np.testing.assert_allclose(lse[b, :, :n].cpu().numpy(), torch.logsumexp(s, -1).detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+        out.backward(dctx[r0:r0 + n].double())
+        worst = max(worst, rel_err(dqkv[r0:r0 + n], x.grad.reshape(n, 3 * H)))
+    assert worst < 2e-2, worst
+    assert rel_err(dtable, tab.grad) < 1e-2, rel_err(dtable, tab.grad)
+    # a second backward ACCUMULATES into the distance buffer (every layer of the encoder adds to the same one)
+    L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd rel 2")
+    dtable2 = torch.empty((32, NH), device="cuda")
+    L.check(lib.carel_relpos_reduce(ddist.data_ptr(), rp.data_ptr(), dtable2.data_ptr(), 0, L.current_stream()), "relpos reduce")
+    assert rel_err(dtable2, 2 * dtable) < 1e-5

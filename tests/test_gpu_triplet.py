@@ -110,13 +110,39 @@ class CharTokenizer:
         return {"input_ids": t(ids), "attention_mask": t(att), "token_type_ids": t([0] * max_length)}
 
 
-def _setup(dropout=0.0):
-    cfg = O.EncoderConfig(layers=2, vocab_size=300)
+class MpnetCharTokenizer(CharTokenizer):
+    """<s>=0, </s>=2, <pad>=1 (the RoBERTa-style special ids MPNet's position ids are built around)."""
+
+    def encode_plus(self, text, text_pair=None, add_special_tokens=True, max_length=32, padding="max_length", return_token_type_ids=True,
+                    truncation=True, return_attention_mask=True, return_tensors="pt"):
+        ids = [0] + [ord(c) % 150 + 120 for c in text][:max_length - 2] + [2]
+        att = [1] * len(ids) + [0] * (max_length - len(ids))
+        ids = ids + [1] * (max_length - len(ids))
+        t = lambda v: torch.tensor([v])
+        return {"input_ids": t(ids), "attention_mask": t(att), "token_type_ids": t([0] * max_length)}
+
+
+VARIANTS = ["bert", "mpnet"]          # chi_ec_sentence_transformer.py (BERT SimCSE checkpoint) / en_ec_sentence_transformer.py (all-mpnet-base-v2)
+
+
+def _public(model, k):
+    """oracle key ("encoder." + BERT-style name) -> the model's state-dict key (MPNetModel names for the MPNet variant)"""
+    return model._to_public(k[len("encoder."):])
+
+
+def _setup(dropout=0.0, variant="bert"):
     opt = O.Opt(pair_bow_dim=8)
+    if variant == "mpnet":
+        cfg = O.EncoderConfig(layers=2, vocab_size=300, max_pos=514, type_vocab=1, ln_eps=1e-5, variant="mpnet", pad_id=1, rel_pos=True)
+        mcfg = M.encoder_config("mpnet", vocab_size=300, layers=2, hidden_dropout=dropout, attn_dropout=dropout)
+        tok = MpnetCharTokenizer()
+    else:
+        cfg = O.EncoderConfig(layers=2, vocab_size=300)
+        mcfg = M.encoder_config("zh", vocab_size=300, layers=2, hidden_dropout=dropout, attn_dropout=dropout)
+        tok = CharTokenizer()
     P = O.init_params(cfg, opt, seed=5)
-    mcfg = M.encoder_config("zh", vocab_size=300, layers=2, hidden_dropout=dropout, attn_dropout=dropout)
-    model = S.SentenceTransformer(mcfg, tokenizer=CharTokenizer(), max_seq_length=32)
-    model.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")})
+    model = S.SentenceTransformer(mcfg, tokenizer=tok, max_seq_length=32)
+    model.load_state_dict({_public(model, k): v for k, v in P.items() if k.startswith("encoder.") and not (variant == "mpnet" and "token_type" in k)})
     model.to("cuda")
     rs = np.random.RandomState(3)
     sents = ["".join(chr(0x4E00 + int(c)) for c in rs.randint(0, 200, size=rs.randint(2, 29))) for _ in range(48)]
@@ -124,8 +150,10 @@ def _setup(dropout=0.0):
     return cfg, P, model, sents, labels
 
 
-def test_embeddings_and_three_fit_steps_against_the_restatement():
-    cfg, P, model, sents, labels = _setup()
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_embeddings_and_three_fit_steps_against_the_restatement(variant):
+    cfg, P, model, sents, labels = _setup(variant=variant)
+    margin = 4.45 if variant == "bert" else 0.6            # MPNet embeddings are L2-normalised: distances <= 2
     feats = model.tokenize(sents[:16])
     b = dict(input_ids=feats["input_ids"], attention_masks=feats["attention_mask"], token_type_ids=feats["token_type_ids"])
     want = ST.encode(P, b["input_ids"], b["attention_masks"], b["token_type_ids"], cfg)
@@ -141,24 +169,27 @@ def test_embeddings_and_three_fit_steps_against_the_restatement():
     # three steps of fit(): loss values, gradient norm of the first step, direction and size of the weight update
     examples = [S.InputExample(texts=[s], label=l) for s, l in zip(sents, labels)]
     loader = torch.utils.data.DataLoader(examples, shuffle=False, batch_size=16)
-    loss = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45)
+    loss = S.losses.BatchSemiHardTripletLoss(model=model, margin=margin)
     model.fit(train_objectives=[(loader, loss)], epochs=1, warmup_steps=1, optimizer_params={"lr": 1e-3}, output_path=None)
     batches = []
     for s in range(0, 48, 16):
         f = model.tokenize(sents[s:s + 16])
         batches.append(dict(input_ids=f["input_ids"], attention_masks=f["attention_mask"], token_type_ids=f["token_type_ids"],
                             labels=torch.tensor(labels[s:s + 16])))
-    ref_losses, ref_norms, W = ST.fit_steps(P, batches, cfg, margin=4.45, lr=1e-3, warmup_steps=1, total_steps=3)
+    ref_losses, ref_norms, W = ST.fit_steps(P, batches, cfg, margin=margin, lr=1e-3, warmup_steps=1, total_steps=3)
     got_losses = model.last_fit.losses
     assert abs(got_losses[0] - ref_losses[0]) <= 2e-3 * abs(ref_losses[0]), (got_losses, ref_losses)
     for a_, b_ in zip(got_losses, ref_losses):                         # steps 2, 3 see weights that moved by bf16-noisy Adam updates
         assert abs(a_ - b_) <= 2e-2 * abs(b_), (got_losses, ref_losses)
     sd = model.state_dict()
     moved = 0
-    for k in ("encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight", "embeddings.position_embeddings.weight",
-              "encoder.layer.1.output.LayerNorm.weight", "encoder.layer.0.intermediate.dense.bias"):
+    probe = ["encoder.layer.0.attention.self.query.weight", "encoder.layer.1.output.dense.weight", "embeddings.position_embeddings.weight",
+             "encoder.layer.1.output.LayerNorm.weight", "encoder.layer.0.intermediate.dense.bias"]
+    if variant == "mpnet":
+        probe[4] = "encoder.relative_attention_bias.weight"          # the bias table is trained (and weight-decayed) like any embedding
+    for k in probe:
         d_ref = W["encoder." + k] - P["encoder." + k]
-        d_got = sd[k].cpu() - P["encoder." + k]
+        d_got = sd[_public(model, "encoder." + k)].cpu() - P["encoder." + k]
         assert float(d_ref.norm()) > 0
         cos = float((d_ref.flatten() @ d_got.flatten()) / (d_ref.norm() * d_got.norm()))
         assert cos > 0.9 and 0.8 < float(d_got.norm() / d_ref.norm()) < 1.25, (k, cos, float(d_got.norm() / d_ref.norm()))
@@ -167,14 +198,19 @@ def test_embeddings_and_three_fit_steps_against_the_restatement():
     # the pooler is not part of the sentence model's parameters and did not move
     assert torch.equal(sd["pooler.dense.weight"].cpu(), P["encoder.pooler.dense.weight"])
     assert "pooler.dense.weight" not in dict(model.named_parameters())
+    if variant == "mpnet":             # MPNetModel key names; no token types anywhere; unit-norm embeddings
+        assert "encoder.layer.0.attention.attn.q.weight" in sd and not any("token_type" in k for k in sd)
+        assert float(model._m._named[S.TT_KEY].detach().abs().max()) == 0.0
+        assert float((torch.from_numpy(model.encode(sents[:16], batch_size=16)).norm(dim=1) - 1).abs().max()) < 1e-5
 
 
-def test_first_step_gradients_and_clip_norm_against_the_restatement():
-    cfg, P, model, sents, labels = _setup()
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_first_step_gradients_and_clip_norm_against_the_restatement(variant):
+    cfg, P, model, sents, labels = _setup(variant=variant)
     f = model.tokenize(sents[:16])
     lab = torch.tensor(labels[:16])
     model.train(True)
-    loss_mod = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45)
+    loss_mod = S.losses.BatchSemiHardTripletLoss(model=model, margin=4.45 if variant == "bert" else 0.6)
     emb = model(f)["sentence_embedding"]
     emb.retain_grad()
     loss = loss_mod.batch_semi_hard_triplet_loss(lab, emb)
@@ -193,7 +229,7 @@ def test_first_step_gradients_and_clip_norm_against_the_restatement():
         gr = Wr[k].grad
         if gr is None or float(gr.norm()) < 1e-7:
             continue
-        worst[k] = relnorm(named[k[len("encoder."):]].grad, gr)
+        worst[k] = relnorm(named[_public(model, k)].grad, gr)
     assert max(worst.values()) < 6e-2 and float(np.median(list(worst.values()))) < 2e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     opt = S.FusedAdamW(model, lr=1e-3)
     opt.step()
