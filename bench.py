@@ -45,9 +45,13 @@ def parse():
     ap.add_argument("--no-ecpe", action="store_true", help="skip the secondary ECPE-shaped leg")
     ap.add_argument("--no-varlen", action="store_true", help="run padded positions through the encoder like the reference does")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
-    ap.add_argument("--no-adam-in-backward", action="store_true",
-                    help="run the whole fused Adam in optim.step() instead of layer by layer beside the backward pass")
-    ap.add_argument("--no-forward-chains", action="store_true", help="forward pass as one chain (keeps the weight-gradient side stream)")
+    ap.add_argument("--adam-in-backward", action="store_true",
+                    help="run the fused Adam layer by layer beside the backward pass (auxiliary stream) instead of in optim.step(); measured "
+                         "1 % slower than the plain order since the round-2 GEMMs fill the chip (tools/ab_bench.sh)")
+    ap.add_argument("--forward-chains", action="store_true",
+                    help="forward pass as two half-batch chains on two streams (results identical); measured ~1 % slower with the round-2 GEMMs")
+    ap.add_argument("--no-adam-in-backward", action="store_true", help=argparse.SUPPRESS)      # (accepted: these are the defaults now)
+    ap.add_argument("--no-forward-chains", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gemm-variant", type=int, action="append", default=[],
                     help="tuning hook passed to carel_gemm_set_variant before the run (repeatable; 1 = 128x128 kernel only, 5x = ping-pong tile threshold)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -341,7 +345,7 @@ def main():
     if world > 1 or force_dp:
         from carel_vae_amd.dp import DataParallel
         dp = DataParallel(model)
-    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=not (a.no_adam_in_backward or a.no_overlap))
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=a.adam_in_backward and not a.no_overlap)
 
     batches, lengths = [], []
     for i in range(4):
@@ -350,7 +354,7 @@ def main():
         batches.append({k: v.to(dev) for k, v in b.items()})
     model.varlen = not a.no_varlen
     model.overlap_wgrad = not a.no_overlap
-    model.forward_chains = (not a.no_forward_chains) and dp is None        # DataParallel switches the second chain off (dp.py)
+    model.forward_chains = a.forward_chains and dp is None        # DataParallel switches the second chain off (dp.py)
 
     def step(i):
         b = batches[i % len(batches)]

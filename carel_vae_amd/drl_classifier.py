@@ -343,7 +343,8 @@ class DrlClassifier(nn.Module):
         self.varlen = True                   # skip padded positions (results identical; see _pack_info)
         self.cls_only_last = True            # last layer's row-wise half on the [CLS] rows only (results identical)
         self.overlap_wgrad = True            # weight-gradient GEMMs on a second stream beside the dgrad chain (results identical)
-        self.forward_chains = True           # dense batches: the two halves of the batch as two forward chains (results identical)
+        self.forward_chains = False          # dense batches: the two halves of the batch as two forward chains on two streams (results
+                                             # identical; opt-in: ~1 % slower than one chain since the round-2 GEMMs fill the chip)
         self._fwd_count = 0
         self._noise = None
         self._ws = {}                        # small per-shape buffers (tail, [CLS] index arrays)

@@ -20,6 +20,7 @@ def run(passes, verbose=True, layers=12):
         m = M.DrlClassifier(opt, cfg, seed=3).to(dev)
         m.train()
         m.overlap_wgrad = overlap
+        m.forward_chains = overlap          # (opt-in since round 2: keep the two-chain forward under test)
         models.append((m, M.FusedAdam(m, lr=1e-5, fuse_into_backward=overlap)))
     bad = 0
     for it in range(passes):
