@@ -167,3 +167,32 @@ def test_bench_launches_its_own_ranks_and_checks_the_count(monkeypatch):
     seen["n"] = 1                                    # a run that silently used one GPU is an error, not a result
     with pytest.raises(SystemExit):
         bench.launch_ranks(a)
+
+
+def test_mpnet_host_logic_bucket_map_and_state_dict_names():
+    """CPU: the relative-position bucket map the model hands to the kernels is the oracle's (= transformers') function, entry by entry,
+    and the MPNet sentence model speaks MPNetModel key names (round trip through load_state_dict / state_dict, no token types)."""
+    import torch
+    from carel_vae_amd import drl_classifier as M
+    from carel_vae_amd import sentence_transformer as S
+    from oracle import carel_oracle as O
+    cfg = M.encoder_config("mpnet", vocab_size=64, layers=1)
+    model = S.SentenceTransformer(cfg, seed=0)
+    assert model.mpnet and model.normalize
+    rel = model._m._rel_buffers()
+    want = O.mpnet_relative_position_bucket(torch.arange(-127, 129))
+    assert torch.equal(rel.bucket.cpu().long(), want)
+    assert rel.dist.shape == (12, 256) and rel.ddist.shape == (12, 256)
+    sd = model.state_dict()
+    assert "encoder.relative_attention_bias.weight" in sd and sd["encoder.relative_attention_bias.weight"].shape == (32, 12)
+    assert "encoder.layer.0.attention.attn.q.weight" in sd and "encoder.layer.0.attention.LayerNorm.bias" in sd
+    assert not any("token_type" in k or ".self." in k for k in sd)
+    sd2 = {k: torch.full_like(v, 0.25) for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    back = model.state_dict()
+    assert all(torch.equal(back[k], sd2[k]) for k in sd2)
+    assert float(model._m._named[S.TT_KEY].detach().abs().max()) == 0.0          # the placeholder type row is not loadable / stays zero
+    names = [k for k, _ in model.named_parameters()]
+    assert len(names) == len(set(names)) and "pooler.dense.weight" not in names and "embeddings.token_type_embeddings.weight" not in names
+    # the string constructor of the reference scripts selects the architecture (weights are never fetched)
+    assert S.SentenceTransformer("sentence-transformers/all-mpnet-base-v2", seed=0).mpnet
