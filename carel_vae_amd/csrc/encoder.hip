@@ -227,7 +227,7 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     la.h1 += (size_t)r0 * EH * 4; la.st1 += (size_t)r0 * 2 * 4; la.x1_bf16 += (size_t)r0 * EH * 2; la.u += (size_t)r0 * EI * 2;
     la.g += (size_t)r0 * EI * 2; la.h2 += (size_t)r0 * EH * 4; la.st2 += (size_t)r0 * 2 * 4;
     if ((rc = gemm_call(la.xin_bf16, w.qkv_w, EH, EH, (int)T, 3 * EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_BF16, 1, la.qkv, nullptr, nullptr,
-                        w.qkv_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+                        w.qkv_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains))) return rc;
     carel_attn_args at;
     at.qkv = la.qkv; at.attention_mask = a->attention_mask ? (const void*)((const long*)a->attention_mask + b0 * S) : nullptr;
     at.ctx = la.ctx; at.lse = la.lse; at.dctx = nullptr; at.dqkv = nullptr;
@@ -247,10 +247,10 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
       Actx = cctx; res1 = cxres; rmap = a->cls_orig_rows;
     }
     if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
-                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap))) return rc;
+                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains))) return rc;
     if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, la.u, la.g, nullptr,
-                        w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+                        w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
                         w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains))) return rc;
     char* next_bf16 = nullptr;
@@ -375,7 +375,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = group_done(2))) return rc;
   if (cls_only && (rc = wait_group(3))) return rc;             // the compact result parks in dqkv
   if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, 0, 0, 0, 0.f, stream))) return rc;
+                      nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
   if (cls_only) {
     // expand the compact [CLS] gradients to token rows: dctx (attention backward input) and the residual-path
     // gradient dh1 (added by the QKV dgrad epilogue) are zero everywhere else

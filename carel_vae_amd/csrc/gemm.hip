@@ -426,11 +426,15 @@ static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-m
 // GemmParams::split_tile_factor (carel::gemm_bf16_ex, internal): the caller runs this many equal GEMMs side by side (the
 // forward's half-batch chains), so the split factor is chosen as for ONE GEMM over all of their rows -- the same K
 // partition, hence the same bits, as the single-chain forward.
+static int g_auto_split_min_k = 768;   // carel_gemm_set_variant(130 / 131): internal split-K for K >= 1536 only (round-1 behaviour) / K >= 768
 static int auto_splits(const GemmParams& p, size_t ws_bytes) {
-  if (g_gemm_variant != 0) return 1;
+  if (g_gemm_variant != 0 || p.K < g_auto_split_min_k) return 1;
   const int tiles = p.tiles_m * p.tiles_n * (p.split_tile_factor > 0 ? p.split_tile_factor : 1);
+  if (p.K < 1536 && tiles >= 64) return 1;      // K = 768 at 84+ tiles (packed ECPE batches): the slab pass costs more than it saves (measured)
   int s = 1;
-  while (tiles * s < 256 && p.K >= 768 && (p.K / (s * 2)) >= 384 && p.K % (128 * s) == 0 &&
+  // a K slice keeps >= 6 K steps (384); grids of a few workgroups (the [CLS]-only last layer: 6-24 tiles, each K step a
+  // full L2 / HBM round trip of ~1.5 us with nothing else resident on the CU) go down to 3
+  while (tiles * s < 256 && p.K >= 768 && (p.K / (s * 2)) >= (tiles * s < 64 ? 192 : 384) && p.K % (128 * s) == 0 &&
          (size_t)(s * 2) * p.M * p.N * 4 <= ws_bytes) s *= 2;
   return s;
 }
@@ -611,6 +615,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }
   if (v >= 100 && v <= 116) { gemm_pp_wgrad_force(v - 100); return CAREL_OK; }         // ping-pong weight gradient: split-K factor forced (0 = heuristic)
+  if (v == 130 || v == 131) { g_auto_split_min_k = v == 130 ? 1536 : 768; return CAREL_OK; }
   if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles
   if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
   g_gemm_variant = v;
