@@ -11,7 +11,8 @@ cfg = M.encoder_config("zh")
 torch.manual_seed(0)
 model = M.DrlClassifier(opt, cfg, seed=1).to(dev); model.train()
 optim = M.FusedAdam(model, lr=1e-5)
-b = {k: v.to(dev) for k, v in D.synthetic_ecpe_batch(64, 128, cfg.vocab_size, opt.pair_bow_dim, seed=5, shape="A").items()}
+SHAPE = os.environ.get("SHAPE", "A")          # A dense, B ECPE-shaped lengths (padding skipped)
+b = {k: v.to(dev) for k, v in D.synthetic_ecpe_batch(64, 128, cfg.vocab_size, opt.pair_bow_dim, seed=5, shape=SHAPE).items()}
 lengths = b["attention_masks"].sum(1).tolist()
 def step(i):
     loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"], b["bow_reps"], i % 41, seq_lengths=lengths)
@@ -19,7 +20,7 @@ def step(i):
 for i in range(10): step(i)
 torch.cuda.synchronize()
 for mode in ("overlap", "serial"):
-    model.overlap_wgrad = mode == "overlap"; model.forward_chains = mode == "overlap"
+    model.overlap_wgrad = mode == "overlap"
     for i in range(5): step(i)
     torch.cuda.synchronize()
     N = 30
@@ -37,3 +38,13 @@ for mode in ("overlap", "serial"):
     t2 = time.perf_counter()
     print("%-8s host enqueue %.2f ms/step (forward %.2f, backward+Adam %.2f); GPU drained %.2f ms after the last enqueue; total %.2f ms/step" % (
         mode, 1e3 * (t1 - t0) / N, 1e3 * tf / N, 1e3 * tb / N, 1e3 * (t2 - t1), 1e3 * (t2 - t0) / N))
+
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    model.overlap_wgrad = True
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(20): step(i)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
