@@ -22,6 +22,8 @@ int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void*
 
 // carel_gemm_bf16 with the split-K heuristic told that `split_tile_factor` equal GEMMs run side by side (the forward's
 // half-batch chains): the split factor is then chosen as for ONE GEMM over all their rows -- same K partition, same bits; gemm.hip
+// (| GEMM_EX_FIXED_ROWS: M is the same whatever the batch -- the [CLS]-only last layer -- so a finer K partition is allowed)
+constexpr int GEMM_EX_FIXED_ROWS = 0x100;
 int gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream);
 // largest value carel_gemm_wgrad_splits(M, N, T) can take under any tuning-hook setting (slab buffer sizing); gemm.hip
 int gemm_wgrad_splits_max(int M, int N, long T);

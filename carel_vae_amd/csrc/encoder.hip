@@ -239,6 +239,7 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     const bool cls_only = a->n_cls > 0 && i + 1 == a->n_layers;
     if (cls_only && !whole) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: internal: [CLS]-only layer on a partial batch");
     long R = T;                                  // rows of the row-wise half of this layer
+    const int fixed = cls_only ? GEMM_EX_FIXED_ROWS : 0;
     const void* Actx = la.ctx; const void* res1 = xa; const void* rmap = whole ? a->tok_row : nullptr;
     if (cls_only) {                              // only the [CLS] rows of the last layer are ever read
       R = a->n_cls;
@@ -247,12 +248,12 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
       Actx = cctx; res1 = cxres; rmap = a->cls_orig_rows;
     }
     if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
-                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains))) return rc;
+                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
     if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, la.u, la.g, nullptr,
-                        w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains))) return rc;
+                        w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains | fixed))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains))) return rc;
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
     char* next_bf16 = nullptr;
     if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16 + (size_t)r0 * EH * 2;
     if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, xa, next_bf16, la.st2, stream))) return rc;
@@ -362,7 +363,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream))) return rc;
   if ((rc = group_done(1))) return rc;
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
-                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
+                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0)))) return rc;
   // LN1 backward (its bf16 output goes to a second buffer: the FFN2 weight gradient may still be reading dyb)
   if ((rc = wait_group(2))) return rc;
   if ((rc = layernorm_bwd_rows(a->dx, la.h1, la.st1, w.ln1_g, R, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb2,
@@ -375,7 +376,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = group_done(2))) return rc;
   if (cls_only && (rc = wait_group(3))) return rc;             // the compact result parks in dqkv
   if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
+                      nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0)))) return rc;
   if (cls_only) {
     // expand the compact [CLS] gradients to token rows: dctx (attention backward input) and the residual-path
     // gradient dh1 (added by the QKV dgrad epilogue) are zero everywhere else

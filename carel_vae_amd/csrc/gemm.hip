@@ -429,12 +429,17 @@ static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-m
 static int g_auto_split_min_k = 768;   // carel_gemm_set_variant(130 / 131): internal split-K for K >= 1536 only (round-1 behaviour) / K >= 768
 static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   if (g_gemm_variant != 0 || p.K < g_auto_split_min_k) return 1;
-  const int tiles = p.tiles_m * p.tiles_n * (p.split_tile_factor > 0 ? p.split_tile_factor : 1);
-  if (p.K < 1536 && tiles >= 64) return 1;      // K = 768 at 84+ tiles (packed ECPE batches): the slab pass costs more than it saves (measured)
+  const int factor = p.split_tile_factor & 0xff;
+  const int tiles = p.tiles_m * p.tiles_n * (factor > 0 ? factor : 1);
+  // K = 768: only where the caller says the row count does not depend on the batch (GEMM_EX_FIXED_ROWS: the [CLS]-only last layer,
+  // M = 128 whatever the batch) -- the K partition, and with it every bit of a sample's result, must not depend on how a batch is
+  // sharded over ranks (tests/test_gpu_dp2.py); at 84+ tiles (packed ECPE batches) the slab pass costs more than it saves (measured)
+  const bool one_row_tile = (p.split_tile_factor & GEMM_EX_FIXED_ROWS) && p.M <= 128;
+  if (p.K < 1536 && !one_row_tile) return 1;
   int s = 1;
-  // a K slice keeps >= 6 K steps (384); grids of a few workgroups (the [CLS]-only last layer: 6-24 tiles, each K step a
-  // full L2 / HBM round trip of ~1.5 us with nothing else resident on the CU) go down to 3
-  while (tiles * s < 256 && p.K >= 768 && (p.K / (s * 2)) >= (tiles * s < 64 ? 192 : 384) && p.K % (128 * s) == 0 &&
+  // a K slice keeps >= 6 K steps (384); the one-row-tile grids (6-24 workgroups, each K step a full L2 / HBM round trip of ~1.5 us
+  // with nothing else resident on the CU) go down to 3
+  while (tiles * s < 256 && p.K >= 768 && (p.K / (s * 2)) >= (one_row_tile ? 192 : 384) && p.K % (128 * s) == 0 &&
          (size_t)(s * 2) * p.M * p.N * 4 <= ws_bytes) s *= 2;
   return s;
 }
