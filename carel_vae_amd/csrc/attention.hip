@@ -65,6 +65,32 @@ __device__ __forceinline__ bf16x8 acc_as_operand(const f32x16& x, int s) {
 
 __device__ __forceinline__ bf16x8 load_frag_global(const bf16_t* p) { return *(const bf16x8*)p; }
 
+
+// A wave's [32 rows][64 d] result sits in two 32x32 accumulators with the ROW on the lane and 4-element groups of d spread over
+// the registers and the two half-waves: stored straight from there every instruction writes 16-byte fragments of 32 different
+// rows (8 instructions per 128-byte line; measured: the stores were 27 % of the backward kernel).  Through a 4-KiB LDS slot of the
+// wave's own (XOR-swizzled 16-byte chunks: conflict-free both ways) every instruction stores 8 whole 128-byte rows instead.
+__device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[2], float scale, char* slot, bf16_t* grow0, long ld, int row_base, int nrows_live) {
+  const int l = threadIdx.x & 63, r = l & 31, hh = l >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = dt * 32 + 8 * i + 4 * hh;                          // 4 consecutive d
+      const int chunk = (d >> 3) ^ ((r >> 1) & 7);
+      const uint2 v = {pack2bf(acc[dt][4 * i] * scale, acc[dt][4 * i + 1] * scale), pack2bf(acc[dt][4 * i + 2] * scale, acc[dt][4 * i + 3] * scale)};
+      *(uint2*)(slot + r * 128 + chunk * 16 + (d & 4) * 2) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the slot is this wave's own: no barrier needed
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (l >> 3), c = l & 7;
+    const uint4 v = *(const uint4*)(slot + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    if (row_base + row < nrows_live) *(uint4*)(grow0 + (long)row * ld + c * 8) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // reads done before the slot is rewritten
+}
+
 struct AttnParams {
   const bf16_t* qkv;        // [B*S, 2304]
   const long* att_mask;     // [B, S] (1 = attend) or null
@@ -77,8 +103,13 @@ struct AttnParams {
   const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
   const float* rel;         // MPNet relative-position bias by distance: [NH][256], entry 127 + (key - query); null = none
   float* drel;              // bwd: its gradient, accumulated with atomics by every (sample, head, layer); same layout
+  uint32_t* dbits;          // optional [B][NH][S/32][S]: bit (q & 31) of word [q >> 5][key] = "probability (q, key) kept by dropout";
+                            // written by the forward, read by the backward instead of re-hashing every element (15 % of its time)
 };
 
+#ifndef CAREL_ATTN_ABLATE
+#define CAREL_ATTN_ABLATE 0        // timing ablations of the backward kernel (wrong results): tools/ablate_attn.py
+#endif
 constexpr float MASK_NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, as HF adds it
 constexpr int ATTN_BWD_LDS = 16384 + 16384 + 32768 + 1024;
 constexpr int ATTN_BWD_LDS_REL = ATTN_BWD_LDS + 2048;     // + bias by distance [256] + its gradient [256]
@@ -145,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float lsum = 0.f;
+  uint32_t wlo = 0u, whi = 0u;
   const uint32_t ebase = (uint32_t)((((long)b * NH + h) * S + (q0 + (lane & 31))) * S);
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -153,8 +185,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const float e = __expf(x[kt][r] - m);
         lsum += e;
-        x[kt][r] = e * dropout_mult(p.drop, ebase + kt * 32 + acc32_row(r, lane));
+        const float dm = dropout_mult(p.drop, ebase + kt * 32 + acc32_row(r, lane));
+        x[kt][r] = e * dm;
+        if (p.dbits && p.drop.thresh != 0u) {      // wave-uniform: the 64 decisions of this register as two words (keys row(r, 0) / row(r, 1), bit = query & 31)
+          const unsigned long long bal = __ballot(dm != 0.f);
+          if (lane == kt * 16 + r) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+        }
       }
+    }
+  }
+  if (p.dbits && p.drop.thresh != 0u) {       // lane n = kt * 16 + r holds the words of keys kt*32 + row(r, hh = 0 / 1)
+    const int kt = lane >> 4, r = lane & 15;
+    if (kt < nkt) {
+      uint32_t* w = p.dbits + (((long)b * NH + h) * (S >> 5) + wave) * S + kt * 32 + (r & 3) + 8 * (r >> 2);
+      w[0] = wlo; w[4] = whi;
     }
   }
   lsum += __shfl_xor(lsum, 32, 64);
@@ -178,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       }
     }
   }
+  // (whole-row stores through an extra 16 KiB of LDS were measured here too: no gain -- 12.6 MB of output against 37.7 MB of input)
   bf16_t* crow = p.ctx + (row0 + q0 + (lane & 31)) * HID + h * HD;
   if (qlive) {
 #pragma unroll
@@ -258,7 +303,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     const int key = kw + (lane & 31);
     const bool klive = key < len;
     const float madd = p.cu ? (klive ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f);
+    const bool use_bits = p.dbits != nullptr && p.drop.thresh != 0u;      // wave-uniform
+    uint32_t kbits[4] = {0u, 0u, 0u, 0u};
+    if (use_bits) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+        if (qt < nt) kbits[qt] = p.dbits[(((long)b * NH + h) * (S >> 5) + qt) * S + key];
+    }
+#pragma unroll 1
     for (int qt = 0; qt < nt; ++qt) {
+      const uint32_t kb = qt == 0 ? kbits[0] : qt == 1 ? kbits[1] : qt == 2 ? kbits[2] : kbits[3];
       f32x16 sa, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -274,8 +328,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         const bool live = klive && q < len;      // rows / keys past the sample belong to its neighbours: contribute exact zeros
         float sc = sa[r] * 0.125f;
         if (REL) sc += relb[127 + key - q];
-        const float pr = live ? __expf(sc + madd - lse[q]) : 0.f;
-        const float dm = dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
+        const float pr = live ? (CAREL_ATTN_ABLATE == 3 ? (sc + madd - lse[q]) : __expf(sc + madd - lse[q])) : 0.f;
+        const float dm = CAREL_ATTN_ABLATE == 1 ? 1.0f
+                       : use_bits ? (((kb >> (acc32_row(r, lane) & 31)) & 1u) ? p.drop.scale : 0.0f)
+                                  : dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
         pd[r] = live ? pr * dm : 0.f;
         const float ds_raw = live ? pr * (dp[r] * dm - delta[q]) : 0.f;  // d loss / d score
         dsv[r] = ds_raw * 0.125f;                                        // includes the 1/sqrt(d) of the q.k part of the scores
@@ -300,26 +356,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         }
       }
     }
-    bf16_t* out = p.dqkv + (row0 + key) * QKV_LD + h * HD;
-    if (klive) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int d = dt * 32 + 8 * i + 4 * hh;
-          uint2 a = {pack2bf(dk[dt][4 * i], dk[dt][4 * i + 1]), pack2bf(dk[dt][4 * i + 2], dk[dt][4 * i + 3])};
-          uint2 c = {pack2bf(dv[dt][4 * i], dv[dt][4 * i + 1]), pack2bf(dv[dt][4 * i + 2], dv[dt][4 * i + 3])};
-          *(uint2*)(out + HID + d) = a;
-          *(uint2*)(out + 2 * HID + d) = c;
-        }
-    }
   }
+  if (CAREL_ATTN_ABLATE == 2) return;
   __syncthreads();                           // every wave: dO image dead, dS^T complete
   if (REL && threadIdx.x < 255) {
     const float g = relg[threadIdx.x];
     if (g != 0.f) atomicAdd(p.drel + h * 256 + threadIdx.x, g);
   }
   stage_att(qbase + HID, QKV_LD, rows, doimg);  // K image for the dQ phase
+  // (dK, dV stay in registers until the very end: stored here, the vmcnt(0) below -- which the K image needs -- would also wait for
+  // their 25 MB of writes)
+  char* slot = qimg + wave * 4096;           // the Q image is dead now (every wave has left the main loop): 4 KiB per wave for the row stores
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!active) return;
@@ -343,16 +390,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(frag32_tr<false>(doimg, dt * 32, 16 * ks), bf, dq[dt]);
     }
   }
-  bf16_t* out = p.dqkv + (row0 + kw + (lane & 31)) * QKV_LD + h * HD;
-  if (kw + (lane & 31) < len) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d = dt * 32 + 8 * i + 4 * hh;
-        uint2 a = {pack2bf(dq[dt][4 * i], dq[dt][4 * i + 1]), pack2bf(dq[dt][4 * i + 2], dq[dt][4 * i + 3])};
-        *(uint2*)(out + d) = a;
-      }
+  if (CAREL_ATTN_ABLATE != 4) {
+    bf16_t* out = p.dqkv + (row0 + kw) * QKV_LD + h * HD;
+    store_rows_via_lds(dq, 1.0f, slot, out, QKV_LD, kw, len);
+    store_rows_via_lds(dk, 1.0f, slot, out + HID, QKV_LD, kw, len);
+    store_rows_via_lds(dv, 1.0f, slot, out + 2 * HID, QKV_LD, kw, len);
   }
 }
 
@@ -371,6 +413,7 @@ static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who
   p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
   p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens;
   p->rel = (const float*)a->rel_bias_dist; p->drel = (float*)a->d_rel_bias_dist;
+  p->dbits = (uint32_t*)a->drop_bits;
   if (bwd && p->rel && !p->drel) return set_error(CAREL_ERR_ARG, "%s: rel_bias_dist needs d_rel_bias_dist in the backward", who);
   p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   return CAREL_OK;
