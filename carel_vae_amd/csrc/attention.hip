@@ -103,8 +103,6 @@ struct AttnParams {
   const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
   const float* rel;         // MPNet relative-position bias by distance: [NH][256], entry 127 + (key - query); null = none
   float* drel;              // bwd: its gradient, accumulated with atomics by every (sample, head, layer); same layout
-  uint32_t* dbits;          // optional [B][NH][S/32][S]: bit (q & 31) of word [q >> 5][key] = "probability (q, key) kept by dropout";
-                            // written by the forward, read by the backward instead of re-hashing every element (15 % of its time)
 };
 
 #ifndef CAREL_ATTN_ABLATE
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float lsum = 0.f;
-  uint32_t wlo = 0u, whi = 0u;
   const uint32_t ebase = (uint32_t)((((long)b * NH + h) * S + (q0 + (lane & 31))) * S);
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -185,20 +182,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const float e = __expf(x[kt][r] - m);
         lsum += e;
-        const float dm = dropout_mult(p.drop, ebase + kt * 32 + acc32_row(r, lane));
-        x[kt][r] = e * dm;
-        if (p.dbits && p.drop.thresh != 0u) {      // wave-uniform: the 64 decisions of this register as two words (keys row(r, 0) / row(r, 1), bit = query & 31)
-          const unsigned long long bal = __ballot(dm != 0.f);
-          if (lane == kt * 16 + r) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
-        }
+        x[kt][r] = e * dropout_mult(p.drop, ebase + kt * 32 + acc32_row(r, lane));
       }
-    }
-  }
-  if (p.dbits && p.drop.thresh != 0u) {       // lane n = kt * 16 + r holds the words of keys kt*32 + row(r, hh = 0 / 1)
-    const int kt = lane >> 4, r = lane & 15;
-    if (kt < nkt) {
-      uint32_t* w = p.dbits + (((long)b * NH + h) * (S >> 5) + wave) * S + kt * 32 + (r & 3) + 8 * (r >> 2);
-      w[0] = wlo; w[4] = whi;
     }
   }
   lsum += __shfl_xor(lsum, 32, 64);
@@ -303,16 +288,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     const int key = kw + (lane & 31);
     const bool klive = key < len;
     const float madd = p.cu ? (klive ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f);
-    const bool use_bits = p.dbits != nullptr && p.drop.thresh != 0u;      // wave-uniform
-    uint32_t kbits[4] = {0u, 0u, 0u, 0u};
-    if (use_bits) {
-#pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
-        if (qt < nt) kbits[qt] = p.dbits[(((long)b * NH + h) * (S >> 5) + qt) * S + key];
-    }
-#pragma unroll 1
+    // (recording the forward's dropout decisions as bits and reading them here instead of re-hashing was built and measured:
+    // forward +1 us, backward -0.5 us -- the hash hides behind the MFMA / LDS latencies of the loop; not kept)
     for (int qt = 0; qt < nt; ++qt) {
-      const uint32_t kb = qt == 0 ? kbits[0] : qt == 1 ? kbits[1] : qt == 2 ? kbits[2] : kbits[3];
       f32x16 sa, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -329,9 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         float sc = sa[r] * 0.125f;
         if (REL) sc += relb[127 + key - q];
         const float pr = live ? (CAREL_ATTN_ABLATE == 3 ? (sc + madd - lse[q]) : __expf(sc + madd - lse[q])) : 0.f;
-        const float dm = CAREL_ATTN_ABLATE == 1 ? 1.0f
-                       : use_bits ? (((kb >> (acc32_row(r, lane) & 31)) & 1u) ? p.drop.scale : 0.0f)
-                                  : dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
+        const float dm = CAREL_ATTN_ABLATE == 1 ? 1.0f : dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
         pd[r] = live ? pr * dm : 0.f;
         const float ds_raw = live ? pr * (dp[r] * dm - delta[q]) : 0.f;  // d loss / d score
         dsv[r] = ds_raw * 0.125f;                                        // includes the 1/sqrt(d) of the q.k part of the scores
@@ -413,7 +389,6 @@ static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who
   p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
   p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens;
   p->rel = (const float*)a->rel_bias_dist; p->drel = (float*)a->d_rel_bias_dist;
-  p->dbits = (uint32_t*)a->drop_bits;
   if (bwd && p->rel && !p->drel) return set_error(CAREL_ERR_ARG, "%s: rel_bias_dist needs d_rel_bias_dist in the backward", who);
   p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   return CAREL_OK;

@@ -15,11 +15,11 @@ constexpr int EH = 768, EI = 3072, ENH = 12;
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LayerAct {
-  char* xin_bf16; char* qkv; char* lse; char* dbits; char* ctx; char* h1; char* st1; char* x1_bf16; char* u; char* g; char* h2; char* st2;
+  char* xin_bf16; char* qkv; char* lse; char* ctx; char* h1; char* st1; char* x1_bf16; char* u; char* g; char* h2; char* st2;
 };
 struct ActLayout {
   size_t per_layer, total;
-  size_t o_xin, o_qkv, o_lse, o_dbits, o_ctx, o_h1, o_st1, o_x1, o_u, o_g, o_h2, o_st2;
+  size_t o_xin, o_qkv, o_lse, o_ctx, o_h1, o_st1, o_x1, o_u, o_g, o_h2, o_st2;
   size_t o_embst, o_xa, o_xb, o_cctx, o_cxres, o_layers;
 };
 
@@ -29,7 +29,6 @@ ActLayout act_layout(long B, long S, int L, int inference) {
   a.o_xin = o; o += al(T * EH * 2);
   a.o_qkv = o; o += al(T * 3 * EH * 2);
   a.o_lse = o; o += al((size_t)B * ENH * S * 4);
-  a.o_dbits = o; o += inference ? 0 : al((size_t)B * ENH * (S / 32) * S * 4);      // attention-dropout keep bits (forward -> backward)
   a.o_ctx = o; o += al(T * EH * 2);
   a.o_h1 = o; o += al(T * EH * 4);
   a.o_st1 = o; o += al(T * 2 * 4);
@@ -54,7 +53,7 @@ ActLayout act_layout(long B, long S, int L, int inference) {
 LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
   char* p = base + a.o_layers + (inference ? 0 : (size_t)l * a.per_layer);
   LayerAct r;
-  r.xin_bf16 = p + a.o_xin; r.qkv = p + a.o_qkv; r.lse = p + a.o_lse; r.dbits = p + a.o_dbits; r.ctx = p + a.o_ctx; r.h1 = p + a.o_h1; r.st1 = p + a.o_st1;
+  r.xin_bf16 = p + a.o_xin; r.qkv = p + a.o_qkv; r.lse = p + a.o_lse; r.ctx = p + a.o_ctx; r.h1 = p + a.o_h1; r.st1 = p + a.o_st1;
   r.x1_bf16 = p + a.o_x1; r.u = p + a.o_u; r.g = p + a.o_g; r.h2 = p + a.o_h2; r.st2 = p + a.o_st2;
   return r;
 }
@@ -224,7 +223,7 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
   for (int i = l0; i < l1; ++i) {
     const carel_layer_params& w = a->layers[i];
     LayerAct la = layer_act(l, base, i, a->inference);
-    la.xin_bf16 += (size_t)r0 * EH * 2; la.qkv += (size_t)r0 * 3 * EH * 2; la.lse += (size_t)b0 * ENH * S * 4; la.dbits += (size_t)b0 * ENH * (S / 32) * S * 4; la.ctx += (size_t)r0 * EH * 2;
+    la.xin_bf16 += (size_t)r0 * EH * 2; la.qkv += (size_t)r0 * 3 * EH * 2; la.lse += (size_t)b0 * ENH * S * 4; la.ctx += (size_t)r0 * EH * 2;
     la.h1 += (size_t)r0 * EH * 4; la.st1 += (size_t)r0 * 2 * 4; la.x1_bf16 += (size_t)r0 * EH * 2; la.u += (size_t)r0 * EI * 2;
     la.g += (size_t)r0 * EI * 2; la.h2 += (size_t)r0 * EH * 4; la.st2 += (size_t)r0 * 2 * 4;
     if ((rc = gemm_call(la.xin_bf16, w.qkv_w, EH, EH, (int)T, 3 * EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_BF16, 1, la.qkv, nullptr, nullptr,
@@ -236,7 +235,6 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
     at.cu_seqlens = whole ? a->cu_seqlens : nullptr;
     at.rel_bias_dist = a->rel_bias_dist; at.d_rel_bias_dist = nullptr;
-    at.drop_bits = a->inference ? nullptr : la.dbits;
     if ((rc = carel_attention_fwd(&at, stream))) return rc;
     const bool cls_only = a->n_cls > 0 && i + 1 == a->n_layers;
     if (cls_only && !whole) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: internal: [CLS]-only layer on a partial batch");
@@ -396,7 +394,6 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * layer; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
   at.cu_seqlens = a->cu_seqlens;
   at.rel_bias_dist = a->rel_bias_dist; at.d_rel_bias_dist = a->d_rel_bias_dist;
-  at.drop_bits = la.dbits;
   if (a->tok_row) {
     // packed: the attention backward writes only rows that belong to a sample; the filler rows up to the next multiple
     // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows

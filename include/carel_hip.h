@@ -200,10 +200,6 @@ typedef struct carel_attn_args {
   const void* rel_bias_dist;
   void* d_rel_bias_dist;       /* bwd, required with rel_bias_dist: f32 [heads][256], ACCUMULATED into (atomics); the caller zeroes
                                   it once per step and folds it into the table gradient with carel_relpos_reduce */
-  /* optional, uint32 [batch][heads][seq_len / 32][seq_len]: the forward records which probabilities its dropout kept (bit q & 31 of
-   * word [q >> 5][key]) and the backward of the SAME arguments reads them instead of hashing every element again; NULL: the
-   * backward recomputes the mask (identical results) */
-  void* drop_bits;
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);

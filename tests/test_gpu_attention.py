@@ -15,11 +15,9 @@ pytestmark = pytest.mark.gpu
 NH, HD, H = 12, 64, 768
 
 
-def run_attn(qkv, mask, B, S, drop=(0, 0, 0, 0.0), dctx=None, bits=None):
+def run_attn(qkv, mask, B, S, drop=(0, 0, 0, 0.0), dctx=None):
     lib = L.load()
     a = L.AttnArgs()
-    if bits is not None:
-        a.drop_bits = bits.data_ptr()
     ctx = torch.empty((B * S, H), device="cuda", dtype=torch.bfloat16)
     lse = torch.empty((B, NH, S), device="cuda")
     a.qkv, a.attention_mask, a.ctx, a.lse = qkv.data_ptr(), (None if mask is None else mask.data_ptr()), ctx.data_ptr(), lse.data_ptr()
@@ -83,13 +81,6 @@ def test_attention_fwd_bwd(B, S, masked, p):
                 rows = b * S + pad
                 assert float(got[rows, H:].abs().max()) == 0.0
     assert torch.isfinite(got).all()
-    # the keep bits the forward records replace the backward's re-hash of every element: identical results, bit for bit
-    bits = torch.zeros((B, NH, S // 32, S), dtype=torch.int32, device="cuda")
-    ctx2, lse2, dqkv2 = run_attn(qkv, mask, B, S, drop, dctx, bits=bits)
-    assert torch.equal(ctx2, ctx) and torch.equal(lse2, lse) and torch.equal(dqkv2, dqkv)
-    if p > 0:
-        kept = sum(bin(int(w) & 0xFFFFFFFF).count("1") for w in bits[0, 0].flatten().tolist()) / float(S * S)
-        assert abs(kept - (1 - p)) < 0.02
 
 
 def test_attention_rejects_bad_shapes():
