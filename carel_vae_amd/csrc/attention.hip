@@ -136,15 +136,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   for (int k = threadIdx.x; k < rows; k += 256)
     maskadd[k] = p.cu ? (k < len ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f);
   if (REL) relb[threadIdx.x] = p.rel[h * 256 + threadIdx.x];
+  const int q0 = wave * 32;
+  const int hh = lane >> 5;
+  // Q fragments (B operand of S^T = K Q^T): Q[q0 + (l&31)][16s + 8hh + j] -- requested before the wait for the staged K / V images
+  bf16x8 qf[4];
+  if (wave < nkt) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = load_frag_global(qbase + (long)(q0 + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave >= nkt) return;                       // no barrier below this point
-  const int q0 = wave * 32;
-  const int hh = lane >> 5;
-  // Q fragments (B operand of S^T = K Q^T): Q[q0 + (l&31)][16s + 8hh + j]
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = load_frag_global(qbase + (long)(q0 + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
 
   f32x16 x[4];
 #pragma unroll
@@ -266,25 +268,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     s += __shfl_xor(s, 1, 64);
     if (q < rows && half == 0) delta[q] = s;      // 0 for q >= len
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int hh = lane >> 5;
   const int kw = wave * 32;                 // this wave's keys
   const bool active = wave < nt;
+  // K, V rows of this wave's keys as B operands: X[key = kw + (l&31)][16s + 8hh + j] -- requested BEFORE the wait for the staged
+  // images, so that their round trip to memory overlaps the images' instead of following it
+  bf16x8 kf[4], vf[4];
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = load_frag_global(qbase + HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
+      vf[s] = load_frag_global(qbase + 2 * HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
   if (active) {
-    // K, V rows of this wave's keys as B operands: X[key = kw + (l&31)][16s + 8hh + j]
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kf[s] = load_frag_global(qbase + HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
-      vf[s] = load_frag_global(qbase + 2 * HID + (long)(kw + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
-    }
     const int key = kw + (lane & 31);
     const bool klive = key < len;
     const float madd = p.cu ? (klive ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f);
