@@ -103,8 +103,12 @@ int32_t carel_gemm_wgrad_splits(int32_t M, int32_t N, int64_t T);
 /* test / tuning hook (process-wide, not thread-safe: set it before any other thread calls the library): 0 = choose the
  * kernel automatically, 1 = 128x128 kernel only, 2 = force the old 256x192 kernel, 3 = the 256 x 96n ping-pong kernel
  * wherever the shape allows; 50+k = the ping-pong kernel takes grids of at least 32*k workgroups (default 192);
- * 30/31 = automatic use of the old 256x192 tile off/on; 20..24 XCD tile layouts of the 128x128 kernel; 11..19 timing
- * ablations (wrong results; only in a -DCAREL_GEMM_ABLATE build) */
+ * 30/31 = automatic use of the old 256x192 tile off/on; 20..24 XCD tile layouts of the 128x128 kernel; 70+n = ping-pong tile width
+ * 96n forced (0 = heuristic); 90/91 = ping-pong schedule with fine (12-MFMA) / wide (24-MFMA, default) phases; 100+s = weight-gradient
+ * split-K factor of the ping-pong kernel forced to s (0 = heuristic); 120/121 = its XCD tile map: row-major chunks / rectangles
+ * (default); 130/131 = internal split-K for K >= 1536 only / also for the K = 768 one-row-tile GEMMs (default); 11..19, 61..68 timing
+ * ablations (wrong results; only in a -DCAREL_GEMM_ABLATE build).  None of the non-ablation settings changes results beyond the fp32
+ * summation order of split-K. */
 int carel_gemm_set_variant(int32_t variant);
 /* Measurement aid (bench.py roofline leg): while enabled, every carel_gemm_bf16 launch is bracketed by
  * HIP events on its stream.  carel_profile_gemm_read() synchronises and returns the summed kernel time
