@@ -250,7 +250,7 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
                         w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
     if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
-    if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, la.u, la.g, nullptr,
+    if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, a->inference ? nullptr : la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains | fixed))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
                         w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;

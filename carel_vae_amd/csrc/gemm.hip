@@ -658,7 +658,8 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
 #define NEED(ptr, what) if (!(ptr)) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: epilogue needs " what)
   switch (epi) {
     case EPI_BIAS_BF16: NEED(p.out0, "out_bf16"); break;
-    case EPI_BIAS_GELU: case EPI_BIAS_GELU_DG: NEED(p.out0, "out_bf16"); NEED(p.out1, "out2_bf16"); break;
+    case EPI_BIAS_GELU: NEED(p.out1, "out2_bf16"); break;                  // out_bf16 (the pre-activation) is optional
+    case EPI_BIAS_GELU_DG: NEED(p.out0, "out_bf16"); NEED(p.out1, "out2_bf16"); break;
     case EPI_BIAS_DROP_RESID: NEED(p.outf, "out_f32"); NEED(p.resid, "resid_f32"); break;
     case EPI_DGELU_BF16: case EPI_MUL_BF16: NEED(p.out0, "out_bf16"); NEED(p.aux, "aux_bf16"); break;
     case EPI_ADD_F32: NEED(p.outf, "out_f32"); break;

@@ -61,7 +61,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     *(uint2*)(p.out0 + off) = o;
   } else if (EPI == EPI_BIAS_GELU) {
     uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-    *(uint2*)(p.out0 + off) = o;
+    if (p.out0) *(uint2*)(p.out0 + off) = o;            // (inference: nobody reads the pre-activation -- out0 may be null)
     // GELU is evaluated on the bf16-rounded pre-activation that backward will read back
     float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
     uint2 g = {pack2bf(gelu_erf(u0), gelu_erf(u1)), pack2bf(gelu_erf(u2), gelu_erf(u3))};
@@ -148,7 +148,7 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
     *(uint4*)(p.out0 + off) = pack8(v);
   } else if (EPI == EPI_BIAS_GELU) {
     const uint4 o = pack8(v);
-    *(uint4*)(p.out0 + off) = o;
+    if (p.out0) *(uint4*)(p.out0 + off) = o;            // block-uniform; null in inference (half the epilogue's bytes)
     float u[8];
     unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
 #pragma unroll

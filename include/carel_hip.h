@@ -57,7 +57,7 @@ const char* carel_last_error(void);
 #define CAREL_GEMM_TN 2 /* C[M,N] = A[K,M]^T * B[K,N]          wgrad:   dY^T * X  (split-K)     */
 
 #define CAREL_EPI_BIAS_BF16 0       /* out_bf16 = acc (+ bias)                                   */
-#define CAREL_EPI_BIAS_GELU 1       /* out_bf16 = u = acc + bias ; out2_bf16 = gelu_erf(u)       */
+#define CAREL_EPI_BIAS_GELU 1       /* out_bf16 = u = acc + bias (optional: NULL skips it) ; out2_bf16 = gelu_erf(u) */
 #define CAREL_EPI_BIAS_DROP_RESID 2 /* out_f32 = dropout(acc + bias) + resid_f32                 */
 #define CAREL_EPI_DGELU_BF16 3      /* out_bf16 = acc * gelu_erf'(aux_bf16)                      */
 #define CAREL_EPI_ADD_F32 4         /* out_f32 = acc (+ resid_f32)                               */

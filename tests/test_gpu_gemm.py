@@ -44,6 +44,10 @@ def test_forward_gelu_epilogue():
     uu = u.double()
     ref_g = 0.5 * uu * (1 + torch.erf(uu / math.sqrt(2)))
     assert rel_err(g, ref_g) < TOL_BF16
+    # inference: the pre-activation is optional (nobody reads it without a backward) -- same gelu output, bit for bit
+    g2 = torch.empty_like(g)
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out2_bf16=g2, bias=b)
+    assert torch.equal(g2, g)
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
