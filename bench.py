@@ -461,7 +461,7 @@ def main():
         model.train()
         infer = {"value": 2048 / dti, "unit": "clause-pairs/s", "ms_per_2048_pairs": 1e3 * dti,
                  "note": "pair_probabilities (the kernel path of get_pair_preds): eval-mode encoder + fresh noise, 2048 ECPE-shaped pairs, "
-                         "chunks of 256, padding skipped; one GPU"}
+                         "chunks of 1024, padding skipped; one GPU"}
         log("inference leg: %.1f ms per 2048 pairs" % (1e3 * dti))
 
     # ---- config 4: the English three-space adversarial model (drl_classifier_en.py), one GPU ----

@@ -440,7 +440,7 @@ class DrlClassifier(_Base):
     def sampled_embeddings(self):
         raise L.CarelError("sampled_embeddings() belongs to the two-space model")
 
-    def pair_logits(self, input_ids, att_masks, token_type_ids, chunk=256):
+    def pair_logits(self, input_ids, att_masks, token_type_ids, chunk=1024):
         """pair_classifier([z_e, z_c]) with fresh emotion / cause noise (:336-353), chunked over the batch."""
         self._require_cuda()
         ops._chk_cuda(input_ids, att_masks, token_type_ids)
@@ -484,7 +484,7 @@ class DrlClassifier(_Base):
                                              out[s:s + B].data_ptr(), L.current_stream()), "carel_en_pair_logits")
         return out
 
-    def pair_probabilities(self, input_ids, att_masks, token_type_ids, chunk=256):
+    def pair_probabilities(self, input_ids, att_masks, token_type_ids, chunk=1024):
         return torch.sigmoid(self.pair_logits(input_ids, att_masks, token_type_ids, chunk))
 
     def get_pair_preds(self, input_ids, att_masks, token_type_ids):
