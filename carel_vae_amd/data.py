@@ -231,6 +231,60 @@ class ECPEDataset(torch.utils.data.Dataset):
 # ----------------------------------------------------------------------------------------------
 # BatchLoader: drop-in for `DataLoader(dataset, batch_size, shuffle, num_workers=0)` (ref :952-961)
 # ----------------------------------------------------------------------------------------------
+class _Batch(dict):
+    """A collated batch whose expensive fields may be gathered on first access (BatchLoader: the bag-of-words rows of a whole
+    evaluation set).  Behaves like the plain dict a DataLoader yields: keys(), items(), `in` and [] all see the lazy fields."""
+
+    def __init__(self):
+        super().__init__()
+        self._lazy = {}
+
+    def _materialise(self, k):
+        t, idx, pin = self._lazy.pop(k)
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            out = t.index_select(0, idx)
+        finally:
+            torch.set_num_threads(nt)
+        super().__setitem__(k, out.pin_memory() if pin else out)
+
+    def __missing__(self, k):
+        if k in self._lazy:
+            self._materialise(k)
+            return super().__getitem__(k)
+        raise KeyError(k)
+
+    def __contains__(self, k):
+        return super().__contains__(k) or k in self._lazy
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def _all(self):
+        for k in list(self._lazy):
+            self._materialise(k)
+
+    def keys(self):
+        self._all()
+        return super().keys()
+
+    def items(self):
+        self._all()
+        return super().items()
+
+    def values(self):
+        self._all()
+        return super().values()
+
+    def __iter__(self):
+        self._all()
+        return super().__iter__()
+
+    def __len__(self):
+        return super().__len__() + len(self._lazy)
+
+
 class BatchLoader:
     """Yields the same dict-of-tensors batches as `torch.utils.data.DataLoader(ECPEDataset, batch_size, shuffle,
     num_workers=0)` -- same keys, dtypes, shapes and, under the same `torch.manual_seed`, the same sample order (the index
@@ -305,7 +359,7 @@ class BatchLoader:
             idx = order[s:s + self.batch_size]
             if len(idx) < self.batch_size and self.drop_last:
                 return
-            batch = {}
+            batch = _Batch()
             # single-threaded on purpose: a parallel gather leaves the OpenMP pool spin-waiting on every core, which starves
             # the HIP runtime's threads -- measured: a whole training epoch 5x slower (tools/bench_train_epoch.py)
             nt = torch.get_num_threads()
@@ -316,6 +370,12 @@ class BatchLoader:
                         batch["bow_cols"] = self._sparse[0].index_select(0, idx)
                         batch["bow_vals"] = self._sparse[1].index_select(0, idx)
                         batch["bow_dim"] = self._sparse[2]
+                        continue
+                    if k == "bow_reps" and len(idx) > 256:
+                        # a whole evaluation set as ONE batch (ref :958): nothing on that path reads the bag-of-words rows
+                        # (get_pair_preds takes ids / masks / types), and gathering them is 95 KB per pair -- 42 ms of a 270-ms
+                        # epoch for the 1 938-pair test split.  Built on first access instead.
+                        batch._lazy["bow_reps"] = (t, idx, self.pin)
                         continue
                     out = t.index_select(0, idx)      # (the out= form of index_select is ~60x slower on CPU)
                     batch[k] = out.pin_memory() if self.pin else out

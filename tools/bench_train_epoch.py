@@ -33,7 +33,7 @@ def main():
     for name in names:
         torch.manual_seed(0)
         model = cv.DrlClassifier(opt, cv.encoder_config("zh"), seed=0).to("cuda")
-        optim = cv.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=True)
+        optim = cv.FusedAdam(model, lr=opt.vae_lr)
         if name == "DataLoader":
             tr = torch.utils.data.DataLoader(train_ds, batch_size=64, shuffle=True, num_workers=0)
             te = torch.utils.data.DataLoader(test_ds, batch_size=len(test_ds), shuffle=False, num_workers=0)
@@ -54,12 +54,12 @@ def main():
         cv.train(tr, te, model, [optim], "cuda", num_unpred_pairs=22, opt=opt, log=lambda *_: None)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if name == "BatchLoader" and os.environ.get("CAREL_PROFILE"):
+        if os.environ.get("CAREL_PROFILE") == name:
             import cProfile, pstats
             pr = cProfile.Profile(); pr.enable()
             cv.train(tr, te, model, [optim], "cuda", num_unpred_pairs=22, opt=opt, log=lambda *_: None)
             torch.cuda.synchronize(); pr.disable()
-            pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
         print("%-14s one epoch (41 steps of 64 + evaluation of %d pairs + checkpoint logic): %.3f s  -> %.0f training pairs/s end to end" % (
             name, n_test, dt, n_train / dt), flush=True)
 
