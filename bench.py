@@ -345,7 +345,9 @@ def main():
     if world > 1 or force_dp:
         from carel_vae_amd.dp import DataParallel
         dp = DataParallel(model)
-    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=a.adam_in_backward and not a.no_overlap)
+    # N > 1: each layer's Adam update starts as soon as that layer's gradient bucket has been all-reduced (dp.py), so the optimiser pass
+    # hides behind the remaining backward kernels and collectives instead of trailing the last (embedding) bucket
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=(a.adam_in_backward or world > 1) and not a.no_overlap)
 
     batches, lengths = [], []
     for i in range(4):
