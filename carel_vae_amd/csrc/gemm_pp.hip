@@ -507,6 +507,9 @@ int gemm_pp_wgrad_splits(int M, int N, long K) {
   if (s > nk / 8) s = nk / 8;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
+  // 129-160 workgroups of the 256 x 192 tile are consistently slower than 96-128 or 180+ (FFN gradients: T = 8192 s3 66.3 us vs s2 58.2 /
+  // s4 57.7; T = 1792 s3 31.5 vs s2 26.9; 2304 x 768: s4 54.3 vs s3 45.4 -- cause not found): step down one slice
+  if (tiles * s > 128 && tiles * s <= 160 && s > 1) --s;
   if (tiles * s < 64) return 0;      // short token counts: too few K tiles to slice -- the 128x128 kernel's finer tiles fill the chip better
   return (int)s;
 }
