@@ -147,7 +147,7 @@ def english_leg(dev, batch_size, steps):
     opt = ME.make_opt(pair_bow_dim=V)
     model = ME.DrlClassifier(opt, seed=0).to(dev)
     model.train()
-    opts = model.make_fused_optimizers(fuse_into_backward=True)
+    opts = model.make_fused_optimizers(fuse_into_backward=False)      # (per-layer Adam inside backward: 0.5 % slower here, tools/ab_en.py)
     out = {}
     for shape in ("A", "B"):
         bb, ll = [], []
