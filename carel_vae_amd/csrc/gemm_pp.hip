@@ -68,6 +68,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave & 3, wc = wave >> 2;                     // wc = ping-pong group
+  unsigned long long rt[5] = {0, 0, 0, 0, 0};                  // (DBG 9: 100-MHz real-time stamps of this workgroup's life)
+  if (DBG == 9) rt[0] = __builtin_amdgcn_s_memrealtime();
 
   // XCD-aware tile map: blocks with equal bid % 8 share an XCD (round-robin dispatch; speed only); each XCD walks a
   // contiguous chunk of the row-major tile order (bijective for any tile count)
@@ -208,24 +210,47 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   int sidx = 0;                                                // LDS stage of the current K tile
   bool first_tile = true;                                      // (ablation builds only)
   // one K tile; R = 0: steady state, R = r > 0: r tiles remain including this one (tail vmcnt tables, no issue past K)
+  int tile_no = 0;                                             // (DBG 9: in-kernel stamps of one steady-state K tile, workgroup 0)
   auto tile = [&](auto RR) {
     constexpr int R = decltype(RR)::value;
     const char* st = smem + sidx * STAGE;
+    const bool stamp = DBG == 9 && blockIdx.x == 0 && tile_no == (nk >> 1) && (wave == 0 || wave == 4);
     static_for<NP>([&](auto PP) {
       constexpr int P = decltype(PP)::value;
       constexpr int h = S::phase_h[P], j = S::phase_j[P];
+      unsigned long long ts[8];
+      if (DBG == 9) ts[0] = __builtin_amdgcn_s_memtime();
       // ---------------- load segment L(P): fragments of this phase, this phase's DMA units, counted wait -------------
       const bool do_reads = (DBG != 3 && DBG != 6 && DBG != 7 && DBG != 8) || first_tile;     // 6: DMA + barriers only, 7: barriers only, 8: MFMA + barriers only
+      // the phase's DMA unit e (tile t + delta); the wide NT schedule interleaves the units with the fragment-read groups: the four waves of a group
+      // saturate the LDS for ~270 cycles with their reads (in-kernel stamps, tools/stamp_gemm_pp.py), and an LDS-DMA instruction
+      // issued in between costs the wave its ~30 cycles of issue INSIDE that time instead of after it
+      // (row-image operands only, i.e. the NT form: with K-strided operands -- ds_read_b64_tr_b16 fragment reads -- the same interleave
+      // made the NN / TN forms 20-40 % SLOWER: measured, tools/bench_gemm_pp.py)
+      constexpr bool IL = WIDE && !AT && !BT;
+      auto issue_e = [&](auto E) {
+        constexpr int e = decltype(E)::value;
+        if constexpr (e < S::n_issue[P]) {
+          constexpr int u = S::issue_unit[P][e], d = S::issue_delta[P][e];
+          if constexpr ((R == 0 || d < R) && DBG != 1 && DBG != 7 && DBG != 8) {
+            int stg = sidx + d;
+            if (stg >= ST) stg -= ST;
+            issue(IC<u>{}, a_ptr, b_ptr, d, stg);
+          }
+        }
+      };
       if constexpr (WIDE) {
         if constexpr (P == 0) {
-          if (do_reads)
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
+          for (int hh = 0; hh < 2; ++hh) {
+            if (do_reads)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int ks = 0; ks < 2; ++ks)
                 fa[hh][i][ks] = AT ? frag16_col(st + hh * 16384, wr * 32 + i * 16, ks * 32) : frag16_row(st, wr * 64 + hh * 32 + i * 16, ks * 32);
+            if constexpr (IL) { if (hh == 0) issue_e(IC<0>{}); else issue_e(IC<1>{}); }
+          }
         }
       } else if constexpr (P == 0 || S::phase_h[P] != S::phase_h[P == 0 ? 0 : P - 1]) {
         if (do_reads)
@@ -244,20 +269,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
           for (int ks = 0; ks < 2; ++ks)
             fb[jj][ks] = BT ? frag16_col(pb, wc * 48 + jj * 16, ks * 32) : frag16_row(pb, wc * 48 + jj * 16, ks * 32);
       }
-      static_for<S::n_issue[P]>([&](auto E) {
+      if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[1] = __builtin_amdgcn_s_memtime(); }       // fragment reads issued
+      // the units not placed between read groups above (all of them for the fine schedule and for WIDE phases > 0)
+      static_for<S::MAXI>([&](auto E) {
         constexpr int e = decltype(E)::value;
-        constexpr int u = S::issue_unit[P][e], d = S::issue_delta[P][e];
-        if constexpr ((R == 0 || d < R) && DBG != 1 && DBG != 7 && DBG != 8) {
-          int stg = sidx + d;
-          if (stg >= ST) stg -= ST;
-          issue(IC<u>{}, a_ptr, b_ptr, d, stg);
-        }
+        if constexpr (!(IL && P == 0 && e < 2)) issue_e(IC<e>{});
       });
+      if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[2] = __builtin_amdgcn_s_memtime(); }       // DMA issued
       if constexpr (S::wait[R][P] >= 0 && DBG != 1 && DBG != 7 && DBG != 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
+      if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[3] = __builtin_amdgcn_s_memtime(); }       // counted vmcnt wait over
       if constexpr (WIDE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before the barrier: war = 1
+      if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[4] = __builtin_amdgcn_s_memtime(); }       // fragments landed
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if (DBG == 9) ts[5] = __builtin_amdgcn_s_memtime();                                              // barrier passed: matrix segment starts
       // ---------------- matrix segment M(P) --------------------------------------------------------------------------
       __builtin_amdgcn_s_setprio(CAREL_PP_MPRIO);
 #pragma unroll
@@ -283,16 +309,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (DBG == 9) ts[6] = __builtin_amdgcn_s_memtime();                                              // MFMAs issued
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if (DBG == 9) {
+        ts[7] = __builtin_amdgcn_s_memtime();
+        if (stamp && lane == 0 && p.splitk_ws) {
+          unsigned long long* o = (unsigned long long*)p.splitk_ws + ((wave >> 2) * 6 + P) * 8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = ts[i];
+        }
+      }
     });
     a_ptr += a_step; b_ptr += b_step;
     sidx = sidx + 1 == ST ? 0 : sidx + 1;
     first_tile = false;
+    ++tile_no;
   };
+  unsigned long long t_loop0 = 0;
+  if (DBG == 9) { t_loop0 = __builtin_amdgcn_s_memtime(); rt[1] = __builtin_amdgcn_s_memrealtime(); }
   for (int t = 0; t < nk - S::NTAIL; ++t) tile(IC<0>{});
   static_for<S::NTAIL>([&](auto I) { tile(IC<S::NTAIL - decltype(I)::value>{}); });
   if (wc == 0) __builtin_amdgcn_s_barrier();                   // both groups have now passed the same number of barriers
+  if (DBG == 9) rt[2] = __builtin_amdgcn_s_memrealtime();
+  if (DBG == 9 && p.splitk_ws && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    unsigned long long* o = (unsigned long long*)p.splitk_ws + 200 + (blockIdx.x ? 4 : 0);
+    o[0] = t_loop0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = nk;
+  }
 
   if (AT && do_cs && lane < 16) {                              // D[n][m]: every row n holds the same sum; lane = m
 #pragma unroll
@@ -367,6 +410,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     for (int b = 0; b < 4; ++b) {
       const long row = row_of(b);
       if (row < (long)p.M) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
+    }
+  }
+  if (DBG == 9) {
+    rt[3] = __builtin_amdgcn_s_memrealtime();                  // every store of this wave issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rt[4] = __builtin_amdgcn_s_memrealtime();                  // ... and acknowledged
+    if (p.splitk_ws && lane == 0 && wave == 0) {
+      unsigned long long* o = (unsigned long long*)p.splitk_ws + 512 + (long)blockIdx.x * 5;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = rt[i];
     }
   }
   if (epi_is_dgelu(EPI) && p.colsum_part) {                // block-uniform; dispatcher guarantees NF even here
@@ -523,7 +576,7 @@ int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s) {
 #ifdef CAREL_GEMM_ABLATE
 int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s) {     // NT, bias -> bf16 epilogue only
 #define PPD(N, D) if (npn == N && dbg == D) return g_pp_wide ? launch_pp<N, false, false, EPI_BIAS_BF16, D, true>(p, 1, s) : launch_pp<N, false, false, EPI_BIAS_BF16, D>(p, 1, s)
-#define PPDN(N) PPD(N, 1); PPD(N, 2); PPD(N, 3); PPD(N, 4); PPD(N, 5); PPD(N, 6); PPD(N, 7); PPD(N, 8)
+#define PPDN(N) PPD(N, 1); PPD(N, 2); PPD(N, 3); PPD(N, 4); PPD(N, 5); PPD(N, 6); PPD(N, 7); PPD(N, 8); PPD(N, 9)
   PPDN(1); PPDN(2); PPDN(3);
 #undef PPDN
 #undef PPD

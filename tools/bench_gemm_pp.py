@@ -39,7 +39,7 @@ for name, form, epi, M, N, K in shapes:
     if epi in (L.EPI_DGELU_BF16, L.EPI_MUL_BF16): kw["colsum_part"] = torch.empty((M // 128, N), device="cuda")
     def run(v):                                     # 3 ("pp"): the ping-pong kernel with row-major XCD chunks (hook 120); "ppw": XCD rectangles (121, default)
         L.check(lib.carel_gemm_set_variant(3 if v == "ppw" else v))
-        L.check(lib.carel_gemm_set_variant(121 if v == "ppw" else 120))
+        L.check(lib.carel_gemm_set_variant(120 if v == 3 else 121))
         return lambda: gemm(A, B, form, epi, M, N, K, **kw)
     Bm = B.t() if form == L.GEMM_NT else B
     fns = {1: run, 3: run}
@@ -57,7 +57,7 @@ for name, form, epi, M, N, K in shapes:
         name, M, N, K, med[1], fl / med[1] / 1e6, med[3], fl / med[3] / 1e6, med["ppw"], fl / med["ppw"] / 1e6, min(ts["ppw"]),
         med["blas"], fl / med["blas"] / 1e6), flush=True)
 L.check(lib.carel_gemm_set_variant(121))
-print("sum: v1 %.1f us  pp %.1f us  ppw %.1f us  blas %.1f us" % (tot[1], tot[3], tot["ppw"], tot["blas"]))
+print("sum: v1 %.1f us  pp/chunks %.1f us  pp/rect %.1f us  blas %.1f us" % (tot[1], tot[3], tot["ppw"], tot["blas"]))
 # tile width experiments: npn forced (variant 70 + n) on the wide GEMMs
 for name, form, epi, M, N, K in [s for s in shapes if s[4] >= 2304]:
     A = rnd(M, K); B = rnd(N, K) if form == L.GEMM_NT else rnd(K, N)

@@ -1,4 +1,4 @@
-"""Where does a ping-pong GEMM schedule (HOOK = 90: fine, 91: wide phases) differ from fp64 on exact small-integer data?
+"""Where does a ping-pong GEMM variant (HOOK = 90: fine, 91: wide phases) differ from fp64 on exact small-integer data?
 Prints the wrong 16x16 blocks per 256 x BN tile and the first wrong element with its per-K-tile partial sums."""
 import sys
 import torch

@@ -12,7 +12,7 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int MODE, int DEPTH>
-__global__ __launch_bounds__(512) void ingest(const char* src, long pitch, int rows, int iters, unsigned* sink) {
+__global__ __launch_bounds__(512) void ingest(const char* src, long pitch, int rows, int iters, unsigned* sink, int nw_active) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r8 = lane >> 3, c = lane & 7;
@@ -23,6 +23,7 @@ __global__ __launch_bounds__(512) void ingest(const char* src, long pitch, int r
   int piece = (blockIdx.x * 37 + wave) % pieces, cb = blockIdx.x % cbs;
   char* my_lds = smem + wave * (DEPTH * 1024);
   const bool dma = MODE == 0 || (MODE == 3 && wave < 4);
+  if (wave >= nw_active) iters = 0;            // only the first nw_active waves move data (how many issuing waves does a CU need?)
   for (int it = 0; it < iters; ++it) {
     if (dma) {
 #pragma unroll
@@ -56,19 +57,19 @@ __global__ __launch_bounds__(512) void ingest(const char* src, long pitch, int r
 }
 
 template <int MODE, int DEPTH>
-void run(const char* name, const char* src, long pitch, int rows, unsigned* sink, int wgs) {
+void run(const char* name, const char* src, long pitch, int rows, unsigned* sink, int wgs, int nw = 8) {
   const int iters = 400;
   const size_t lds = 8 * DEPTH * 1024;
   CHECK(hipFuncSetAttribute((const void*)ingest<MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((ingest<MODE, DEPTH>), dim3(wgs), dim3(512), lds, 0, src, pitch, rows, iters, sink);
+  hipLaunchKernelGGL((ingest<MODE, DEPTH>), dim3(wgs), dim3(512), lds, 0, src, pitch, rows, iters, sink, nw);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((ingest<MODE, DEPTH>), dim3(wgs), dim3(512), lds, 0, src, pitch, rows, iters, sink);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((ingest<MODE, DEPTH>), dim3(wgs), dim3(512), lds, 0, src, pitch, rows, iters, sink, nw);
   CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-  const double bytes = 5.0 * wgs * 8.0 * iters * DEPTH * 1024.0;
-  printf("%-28s depth %2d wgs %4d: %7.1f GB/s per CU   %6.2f TB/s chip\n", name, DEPTH, wgs, bytes / (ms * 1e-3) / 1e9 / (wgs < 256 ? wgs : 256), bytes / (ms * 1e-3) / 1e12);
+  const double bytes = 5.0 * wgs * (double)nw * iters * DEPTH * 1024.0;
+  printf("%-28s waves %d depth %2d wgs %4d: %7.1f GB/s per CU   %6.2f TB/s chip\n", name, nw, DEPTH, wgs, bytes / (ms * 1e-3) / 1e9 / (wgs < 256 ? wgs : 256), bytes / (ms * 1e-3) / 1e12);
 }
 
 int main(int argc, char** argv) {
@@ -79,6 +80,10 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&src, (size_t)rows * pitch)); CHECK(hipMemset(src, 1, (size_t)rows * pitch));
   CHECK(hipMalloc(&sink, 4));
   printf("footprint %.1f MB, pitch %ld B, %d rows\n", rows * pitch / 1e6, pitch, rows);
+  for (int nw : {1, 2, 4, 6, 8}) {          // how the LDS-DMA rate of a CU grows with the number of waves that issue it
+    run<0, 4>("LDS-DMA", src, pitch, rows, sink, 256, nw);
+    run<0, 8>("LDS-DMA", src, pitch, rows, sink, 256, nw);
+  }
   for (int wgs : {256, 512}) {
     run<0, 4>("LDS-DMA", src, pitch, rows, sink, wgs);
     run<0, 8>("LDS-DMA", src, pitch, rows, sink, wgs);
