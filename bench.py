@@ -118,9 +118,12 @@ def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
     def compare(B):
         batch, out0 = first[B]
         hip = hip_loss_fn(P0, batch, eps_e, eps_c, cfg, opt)
+        hip32 = hip_loss_fn(P0, batch, eps_e, eps_c, cfg, opt, fp32=True)      # the library's fp32 debug forward (carel_encoder_forward_f32)
         scale = sum(abs(weights[k] * out0[k]) for k in terms)
         return {"batch": B, "loss_cpu_fp32": out0["loss"], "loss_hip_bf16": hip["loss"],
                 "loss_rel_err": abs(hip["loss"] - out0["loss"]) / abs(out0["loss"]),
+                "loss_hip_fp32_debug": hip32["loss"], "loss_rel_err_fp32_debug": abs(hip32["loss"] - out0["loss"]) / abs(out0["loss"]),
+                "term_rel_err_fp32_debug": {k: abs(hip32[k] - out0[k]) / max(abs(out0[k]), 1e-12) for k in terms},
                 "loss_err_over_term_scale": abs(hip["loss"] - out0["loss"]) / scale,
                 "loss_share_of_term_scale": abs(out0["loss"]) / scale,
                 "term_rel_err": {k: abs(hip[k] - out0[k]) / max(abs(out0[k]), 1e-12) for k in terms}}
@@ -129,7 +132,8 @@ def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
     parity["note"] = ("HIP (bf16 MFMA, fp32 accumulate) vs the CPU fp32 path on the SAME weights, batch and noise, dropout off.  Headline = the bench "
                       "configuration (B=64, S=128, 12 layers, V=23771); north_star tolerance 1e-3 relative, asserted by "
                       "tests/test_gpu_model.py::test_bench_configuration_elbo_within_1e_3_of_cpu_fp32.  The 8-sample batch below has a total that is "
-                      "a near-cancellation of its weighted terms (loss_share_of_term_scale): every term still agrees to ~3e-4.")
+                      "a near-cancellation of its weighted terms (loss_share_of_term_scale): every term still agrees to ~3e-4.  *_fp32_debug: the same comparison "
+                      "with the encoder in the library's fp32 debug mode (model.debug_fp32): what is left there is kernel error, not bf16 rounding.")
     parity["small_batch_B8"] = p8
     return {"value": best["clause_pairs_per_s"], "unit": "clause-pairs/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
             "sample": "oracle train_step (fwd+bwd+Adam, fp32, 12 layers, S=128): best of the legs below (B=%d, set_detect_anomaly %s), median "
@@ -519,11 +523,12 @@ def main():
            "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "english_adversarial": english, "input_pipeline": pipeline,
            "sentence_transformer": sentence, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt):
+        def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt, fp32=False):
             m2 = M.DrlClassifier(M.make_opt(**vars(oopt)), M.encoder_config("zh", hidden_dropout=0.0, attn_dropout=0.0), seed=0)
             m2.load_state_dict(P0)
             m2.to(dev).train()
             m2.opt.dropout = 0.0
+            m2.debug_fp32 = fp32
             m2.set_noise(eps_e, eps_c)
             b = {k: v.to(dev) for k, v in batch.items()}
             t = m2.forward_terms(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"],

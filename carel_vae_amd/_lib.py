@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcarel_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CarelError(RuntimeError):
@@ -232,6 +232,8 @@ SIGNATURES = {
     "carel_encoder_act_bytes": (C.c_int64, [C.c_int32] * 4),
     "carel_encoder_scratch_bytes": (C.c_int64, [C.c_int32] * 2),
     "carel_encoder_x_last": (C.c_void_p, [C.POINTER(EncoderArgs)]),
+    "carel_encoder_f32_work_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "carel_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "carel_encoder_forward": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),
     "carel_encoder_backward_layer": (C.c_int, [C.POINTER(EncoderArgs), C.c_int32, C.c_void_p]),
     "carel_encoder_backward_embeddings": (C.c_int, [C.POINTER(EncoderArgs), C.c_void_p]),

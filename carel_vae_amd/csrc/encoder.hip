@@ -442,3 +442,116 @@ extern "C" int carel_encoder_backward_embeddings(const carel_encoder_args* a, vo
   // s.dy (f32 [T, 768]) is free here: scratch for the fixed-order position-table reduction
   return embed_ln_bwd_ex(&e, a->dx, a->d_word_emb, a->d_pos_emb, a->d_type_emb, a->d_emb_ln_g, a->d_emb_ln_b, s.part, s.dy, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 DEBUG forward (dropout off): the graph of carel_encoder_forward with every stored value in fp32 -- linears on the
+// f32-input matrix cores (carel_sgemm_f32: exact fp32 products, fp32 accumulation), attention, GELU (erff) and LayerNorm in
+// fp32 -- so that a difference from the fp32 reference is kernel error, not bf16 rounding.  Measurement / test tool:
+// ~20x slower than the bf16 path, forward only, dense rows only.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// one wave per (sample, head, query): scores over the S <= 128 keys, softmax, P V.  qkv f32 [T, 2304] = q | k | v blocks of 768.
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qkv, const long* __restrict__ mask, const float* __restrict__ rel,
+                                                      float* __restrict__ ctx, int S) {
+  const int lane = threadIdx.x;
+  const int q = blockIdx.x % S, h = (blockIdx.x / S) % ENH, b = blockIdx.x / (S * ENH);
+  __shared__ float qs[64], ps[128];
+  const float* base = qkv + (long)b * S * (3 * EH);
+  qs[lane] = base[(long)q * (3 * EH) + h * 64 + lane];
+  __syncthreads();
+  float sc[2], mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = lane + i * 64;
+    sc[i] = -INFINITY;
+    if (k < S && (!mask || mask[(long)b * S + k] != 0)) {
+      const float* kr = base + (long)k * (3 * EH) + EH + h * 64;
+      float d = 0.f;
+      for (int e = 0; e < 64; ++e) d = fmaf(qs[e], kr[e], d);
+      d *= 0.125f;                                             // 1 / sqrt(64)
+      if (rel) d += rel[h * 256 + 127 + k - q];
+      sc[i] = d;
+    }
+    mx = fmaxf(mx, sc[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float pr[2], sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = lane + i * 64;
+    // a sample with no attended key (the batch's filler samples): HF's additive finfo.min mask gives the uniform distribution
+    pr[i] = k < S ? (mx == -INFINITY ? 1.f : expf(sc[i] - mx)) : 0.f;
+    sum += pr[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  ps[lane] = pr[0] / sum; ps[lane + 64] = pr[1] / sum;
+  __syncthreads();
+  float acc = 0.f;
+  for (int k = 0; k < S; ++k) acc = fmaf(ps[k], base[(long)k * (3 * EH) + 2 * EH + h * 64 + lane], acc);
+  ctx[((long)b * S + q) * EH + h * 64 + lane] = acc;
+}
+
+__global__ __launch_bounds__(256) void gelu_f32_kernel(float* __restrict__ u, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float x = u[i]; u[i] = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+}
+
+struct F32Work { float *x, *x1, *h, *ctx, *qkv, *u, *stats; char* xb; size_t total; };
+F32Work f32_work(char* base, long B, long S) {
+  const size_t T = (size_t)B * S;
+  F32Work w; size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
+  w.x = (float*)take(T * EH * 4); w.x1 = (float*)take(T * EH * 4); w.h = (float*)take(T * EH * 4); w.ctx = (float*)take(T * EH * 4);
+  w.qkv = (float*)take(T * 3 * EH * 4); w.u = (float*)take(T * EI * 4); w.stats = (float*)take(T * 2 * 4); w.xb = take(T * EH * 2);
+  w.total = o;
+  return w;
+}
+
+}  // namespace
+
+extern "C" int64_t carel_encoder_f32_work_bytes(int32_t batch, int32_t seq_len) {
+  return (int64_t)f32_work(nullptr, batch, seq_len).total;
+}
+
+extern "C" int carel_encoder_forward_f32(const carel_encoder_args* a, void* work, void* x_out, void* stream_) {
+  const char* who = "carel_encoder_forward_f32";
+  if (!a || !work || !x_out) return set_error(CAREL_ERR_ARG, "%s: null argument", who);
+  if (a->hidden != EH || a->heads != ENH || a->intermediate != EI) return set_error(CAREL_ERR_SHAPE, "%s: only the BERT-base geometry (768/12/3072) is supported", who);
+  if (a->batch < 1 || a->n_layers < 1 || a->seq_len < 1 || a->seq_len > 128) return set_error(CAREL_ERR_SHAPE, "%s: bad batch / n_layers / seq_len (<= 128)", who);
+  if (a->tok_row || a->n_tokens || a->cu_seqlens) return set_error(CAREL_ERR_ARG, "%s: dense batches only (no token packing)", who);
+  if (!a->input_ids || !a->layers || !a->word_emb || !a->pos_emb || !a->type_emb || !a->emb_ln_g || !a->emb_ln_b) return set_error(CAREL_ERR_ARG, "%s: null tensor", who);
+  hipStream_t stream = (hipStream_t)stream_;
+  const long B = a->batch, S = a->seq_len, T = B * S;
+  const F32Work w = f32_work((char*)work, B, S);
+  int rc;
+  carel_embed_args e;
+  e.input_ids = a->input_ids; e.token_type_ids = a->token_type_ids; e.word_emb = a->word_emb; e.pos_emb = a->pos_emb; e.type_emb = a->type_emb;
+  e.ln_gamma = a->emb_ln_g; e.ln_beta = a->emb_ln_b; e.ln_eps = a->ln_eps; e.batch = a->batch; e.seq_len = a->seq_len; e.hidden = EH;
+  e.vocab_size = a->vocab_size; e.max_pos = a->max_pos; e.type_vocab = a->type_vocab; e.roberta = a->roberta; e.pad_id = a->pad_id;
+  e.drop_seed = 0; e.drop_idx_offset = 0; e.drop_p = 0.f; e.x_f32 = w.x; e.x_bf16 = w.xb; e.stats = w.stats; e.tok_row = nullptr; e.n_rows = 0;
+  if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
+  const size_t row_bytes = (size_t)T * EH * 4;
+  for (int i = 0; i < a->n_layers; ++i) {
+    const carel_layer_params& p = a->layers[i];                 // every weight f32 here
+    float* xin = w.x;
+    float* xout = i + 1 == a->n_layers ? (float*)x_out : w.x;
+    if ((rc = carel_sgemm_f32(xin, EH, 0, p.qkv_w, EH, 0, w.qkv, 3 * EH, (int)T, 3 * EH, EH, p.qkv_b, 0, 1, 0, stream))) return rc;
+    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * ENH * S)), dim3(64), 0, stream, (const float*)w.qkv, (const long*)a->attention_mask,
+                       (const float*)a->rel_bias_dist, w.ctx, (int)S);
+    if ((rc = check_launch("attn_f32_kernel"))) return rc;
+    if (hipMemcpyAsync(w.h, xin, row_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return set_error(CAREL_ERR_HIP, "%s: copy failed", who);
+    if ((rc = carel_sgemm_f32(w.ctx, EH, 0, p.out_w, EH, 0, w.h, EH, (int)T, EH, EH, p.out_b, 1, 1, 0, stream))) return rc;
+    if ((rc = carel_layernorm_fwd(w.h, p.ln1_g, p.ln1_b, a->ln_eps, T, EH, w.x1, nullptr, nullptr, stream))) return rc;
+    if ((rc = carel_sgemm_f32(w.x1, EH, 0, p.ffn1_w, EH, 0, w.u, EI, (int)T, EI, EH, p.ffn1_b, 0, 1, 0, stream))) return rc;
+    const long nu = T * EI;
+    hipLaunchKernelGGL(gelu_f32_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, stream, w.u, nu);
+    if ((rc = check_launch("gelu_f32_kernel"))) return rc;
+    if (hipMemcpyAsync(w.h, w.x1, row_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return set_error(CAREL_ERR_HIP, "%s: copy failed", who);
+    if ((rc = carel_sgemm_f32(w.u, EI, 0, p.ffn2_w, EI, 0, w.h, EH, (int)T, EH, EI, p.ffn2_b, 1, 1, 0, stream))) return rc;
+    if ((rc = carel_layernorm_fwd(w.h, p.ln2_g, p.ln2_b, a->ln_eps, T, EH, xout, nullptr, nullptr, stream))) return rc;
+  }
+  return CAREL_OK;
+}

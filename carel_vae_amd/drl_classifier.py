@@ -345,6 +345,8 @@ class DrlClassifier(nn.Module):
         self.overlap_wgrad = True            # weight-gradient GEMMs on a second stream beside the dgrad chain (results identical)
         self.forward_chains = False          # dense batches: the two halves of the batch as two forward chains on two streams (results
                                              # identical; opt-in: ~1 % slower than one chain since the round-2 GEMMs fill the chip)
+        self.debug_fp32 = False              # forward-only measurement mode: the encoder in fp32 (carel_encoder_forward_f32), dropout off;
+                                             # forward_terms() / forward() under torch.no_grad() only -- separates bf16 rounding from kernel error
         self._fwd_count = 0
         self._noise = None
         self._ws = {}                        # small per-shape buffers (tail, [CLS] index arrays)
@@ -525,6 +527,38 @@ class DrlClassifier(nn.Module):
                 setattr(G[l], f, self._g(k))
         self._layer_structs = (P, G)
         return self._layer_structs
+
+    def _layer_arrays_f32(self):
+        """carel_layer_params with every weight pointing into the fp32 master buffer (carel_encoder_forward_f32)."""
+        P, _ = self._layer_arrays()
+        n = self.cfg.layers
+        F = (L.LayerParams * n)()
+        for l in range(n):
+            for f, _t in L.LayerParams._fields_:
+                setattr(F[l], f, getattr(P[l], f))
+            p = f"encoder.encoder.layer.{l}."
+            for f, k in dict(qkv_w="attention.self.query.weight", out_w="attention.output.dense.weight", ffn1_w="intermediate.dense.weight",
+                             ffn2_w="output.dense.weight").items():
+                setattr(F[l], f, self._w(p + k))
+        return F
+
+    def _run_encoder_fp32(self, c):
+        """The fp32 debug forward: returns the final hidden states f32 [Bp*S, 768] (dense rows)."""
+        lib = L.load()
+        dev = self._flat.device
+        key = ("f32", c.Bp, c.S)
+        buf = self._ws.get(key)
+        if buf is None:
+            buf = SimpleNamespace(work=torch.zeros(lib.carel_encoder_f32_work_bytes(c.Bp, c.S), device=dev, dtype=torch.uint8),
+                                  x=torch.zeros((c.Bp * c.S, H), device=dev, dtype=torch.float32),
+                                  dummy=SimpleNamespace(act=torch.zeros(256, device=dev, dtype=torch.uint8), scratch=None))
+            self._ws[key] = buf
+        ea = self._encoder_args(c.ids, c.att, c.tt, buf.dummy, c.Bp, c.S, True, False, 0, 0, None, None)
+        F = self._layer_arrays_f32()
+        ea.layers = C.cast(F, C.POINTER(L.LayerParams))
+        L.check(lib.carel_encoder_forward_f32(C.byref(ea), buf.work.data_ptr(), buf.x.data_ptr(), L.current_stream()), "carel_encoder_forward_f32")
+        ea._keep = F
+        return ea, buf.x
 
     def _workspace(self, B, S, inference):
         key = (B, S, bool(inference))
@@ -736,13 +770,21 @@ class DrlClassifier(nn.Module):
             self._adam_hook._join()          # weight updates still in flight on the auxiliary stream
         self._refresh_shadow()
         train_drop = self.training          # dropout follows module mode (model.train() / .eval()), like nn.Dropout
-        ws = self._workspace(c.Bp, c.S, inference=not training)
-        c.cls = self._cls_info(c.B, c.Bp, c.S, c.pack, self._flat.device)
-        ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset, c.pack, c.cls)
         lib = L.load()
         st = L.current_stream()
-        L.check(lib.carel_encoder_forward(C.byref(ea), st), "carel_encoder_forward")
-        x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
+        if self.debug_fp32:
+            if training:
+                raise L.CarelError("debug_fp32 is a forward-only measurement mode: call forward_terms() / forward() under torch.no_grad()")
+            train_drop = False
+            c.pack, c.cls, ws = None, None, None
+            ea, x_f32 = self._run_encoder_fp32(c)
+            x_last_ptr = x_f32.data_ptr()
+        else:
+            ws = self._workspace(c.Bp, c.S, inference=not training)
+            c.cls = self._cls_info(c.B, c.Bp, c.S, c.pack, self._flat.device)
+            ea = self._encoder_args(c.ids, c.att, c.tt, ws, c.Bp, c.S, not training, train_drop, c.seed, c.row_offset, c.pack, c.cls)
+            L.check(lib.carel_encoder_forward(C.byref(ea), st), "carel_encoder_forward")
+            x_last_ptr = lib.carel_encoder_x_last(C.byref(ea))
         W, G = self._tail_weights()
         xl = SimpleNamespace(data_ptr=lambda: x_last_ptr)
         klw = ops.kl_anneal_weight(c.iteration, self.opt)

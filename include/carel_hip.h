@@ -29,7 +29,7 @@ extern "C" {
 #define CAREL_ERR_HIP (-3)    /* a HIP runtime call or launch failed    */
 
 /* ABI version of this header; carel_abi_version() must return the same number. */
-#define CAREL_ABI_VERSION 3
+#define CAREL_ABI_VERSION 4
 
 int carel_abi_version(void);
 /* Checks that `device` is a gfx950 part and records nothing else.  ref: `model.to(device)` :932 */
@@ -285,6 +285,14 @@ int64_t carel_encoder_scratch_bytes(int32_t batch, int32_t seq_len);
 /* device pointer (inside act) of the final hidden states, f32 [B*S, 768] */
 void* carel_encoder_x_last(const carel_encoder_args* args);
 int carel_encoder_forward(const carel_encoder_args* args, void* stream);
+/* fp32 DEBUG forward (forward only, dropout off, dense batches): the same graph with every stored value in fp32 -- linears on the
+ * f32-input matrix cores (carel_sgemm_f32), attention, GELU and LayerNorm in fp32 -- so that a difference from the fp32 reference
+ * (BertModel.forward, drl_classifier_ec_mmd_final_mul.py:202-206) is kernel error, not bf16 rounding (tests assert <= 1e-5 against
+ * the reference's own fp32 outputs).  Here args->layers[i].*_w point to F32 weights (same shapes); args->act / scratch / n_cls are
+ * not used.  work: carel_encoder_f32_work_bytes(batch, seq_len) bytes; x_out: f32 [batch*seq_len, 768] final hidden states.
+ * seq_len <= 128.  ~20x slower than carel_encoder_forward: a measurement tool, not a product path. */
+int64_t carel_encoder_f32_work_bytes(int32_t batch, int32_t seq_len);
+int carel_encoder_forward_f32(const carel_encoder_args* args, void* work, void* x_out_f32, void* stream);
 int carel_encoder_backward_layer(const carel_encoder_args* args, int32_t layer, void* stream);
 int carel_encoder_backward_embeddings(const carel_encoder_args* args, void* stream);
 

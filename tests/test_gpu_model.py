@@ -115,6 +115,40 @@ def test_forward_terms_vs_golden_and_bf16_oracle(golden_dir, name):
     assert abs(float(out["loss"]) - float(ref["loss"])) <= tol * scale, (float(out["loss"]), float(ref["loss"]), scale)
 
 
+TOL_FP32_DEBUG = 1e-5
+
+
+@pytest.mark.parametrize("name", ["zh_small", "zh_ragged", "zh_s64", "en_small", "zh_full12"])
+def test_fp32_debug_mode_matches_the_reference_fp32_outputs(golden_dir, name):
+    """"<= 1e-5 (fp32 debug mode)".  model.debug_fp32 runs the encoder through carel_encoder_forward_f32 (fp32 MFMA
+    linears, fp32 attention / GELU / LayerNorm; the tail is fp32 anyway): every term, the total and the latents must then match the
+    golden vectors -- outputs of the reference's own classes in fp32 -- to 1e-5, i.e. what the bf16 path differs by is bf16 rounding."""
+    cfg, opt = CASES[name]
+    z, batch = load(golden_dir, name)
+    it0 = int(z["meta"][8])
+    model, _ = build(cfg, opt, int(z["meta"][5]))
+    model.train()
+    model.debug_fp32 = True
+    model.set_noise(torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"]))
+    out = model.forward_terms(*call(model, batch, it0))
+    worst = 0.0
+    for k in ("pooled", "mu_e", "lv_e", "mu_c", "lv_c"):
+        e = relnorm(out[k], torch.from_numpy(z[k]))
+        worst = max(worst, e)
+        assert e < TOL_FP32_DEBUG, (k, e)
+    for k in TERMS:
+        r = float(z["t_" + k])
+        e = abs(float(out[k]) - r) / max(abs(r), 1e-3)
+        worst = max(worst, e)
+        assert e <= TOL_FP32_DEBUG, (k, float(out[k]), r)
+    scale = sum(abs(WEIGHTS[k] * float(z["t_" + k])) for k in TERMS)
+    assert abs(float(out["loss"]) - float(z["losses"][0])) <= TOL_FP32_DEBUG * scale
+    print("fp32 debug mode, %s: worst relative difference %.2e" % (name, worst))
+    # and it is a forward-only mode: a training forward refuses loudly
+    with pytest.raises(Exception, match="forward-only"):
+        model(*call(model, batch, it0))
+
+
 @pytest.mark.parametrize("shape", ["A", "B"])
 def test_bench_configuration_elbo_within_1e_3_of_cpu_fp32(shape):
     """The north-star tolerance at the north-star configuration (BASELINE.json configs[1]): B = 64, S = 128, 12 layers,

@@ -2,7 +2,7 @@
 // A [8192][3072] bf16 output is written tile by tile (256 x 192 per workgroup of 512 threads, 512 tiles on 256 workgroups x 2):
 //   mode 0: as gemm_pp's epilogue -- a wave instruction = 16 rows x 64 contiguous bytes (lane -> row l & 15, 16-B piece l >> 4)
 //   mode 1: whole rows -- a wave instruction = 8 rows x 128 contiguous bytes
-//   mode 2: a wave instruction = 4 rows x 256 contiguous bytes
+//   mode 2: a wave instruction = 4 rows x 256 contiguous bytes (the tile row is 384 B: a full and a half-populated instruction)
 //   mode 3: a wave instruction = 2 rows x 384 B (the tile's full row: 24 lanes per row; 48 of 64 lanes active)
 // NOUT = 1 or 2 output arrays (the GELU epilogue writes two).  Build: hipcc -O3 --offload-arch=gfx950 -o tools/ubench/store_pattern ...
 #include <hip/hip_runtime.h>
@@ -30,13 +30,13 @@ __global__ __launch_bounds__(512) void store_k(unsigned short* o0, unsigned shor
       constexpr int SEG = MODE == 1 ? 128 : MODE == 2 ? 256 : 384;      // contiguous bytes per row per instruction
       constexpr int LPR = SEG / 16;                                     // lanes per row
       constexpr int RPI = MODE == 3 ? 2 : 64 / LPR;                     // rows per instruction
-      constexpr int CPR = 384 / SEG;                                    // instructions per row span
+      constexpr int CPR = (384 + SEG - 1) / SEG;                        // instructions per row span (the last one partly populated: 384 = 1.5 x 256)
       // the wave owns 32 rows of the tile (8 waves x 32 = 256)
       const bool act = lane < RPI * LPR;
       for (int r = 0; r < 32; r += RPI)
         for (int c = 0; c < CPR; ++c) {
           const long off = base + (long)(wave * 32 + r + lane / LPR) * N + (c * SEG + (lane % LPR) * 16) / 2;
-          if (act) { *(uint4*)(o0 + off) = v; if (NOUT == 2) *(uint4*)(o1 + off) = v; }
+          if (act && c * SEG + (lane % LPR) * 16 < 384) { *(uint4*)(o0 + off) = v; if (NOUT == 2) *(uint4*)(o1 + off) = v; }
         }
     }
   }
