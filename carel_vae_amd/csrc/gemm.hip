@@ -506,7 +506,15 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (; i < n; i += stride) {
     float4 a = *(const float4*)(slabs + i);
-    for (int z = 1; z < splits; ++z) {
+    int z = 1;
+    for (; z + 3 < splits; z += 4) {        // four slabs requested before the first add (same order of additions: same bits)
+      float4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *(const float4*)(slabs + (long)(z + u) * n + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+    }
+    for (; z < splits; ++z) {
       const float4 b = *(const float4*)(slabs + (long)z * n + i);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
