@@ -394,9 +394,10 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * layer; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
   at.cu_seqlens = a->cu_seqlens;
   at.rel_bias_dist = a->rel_bias_dist; at.d_rel_bias_dist = a->d_rel_bias_dist;
-  if (a->tok_row) {
+  if (a->tok_row && layer + 1 == a->n_layers) {
     // packed: the attention backward writes only rows that belong to a sample; the filler rows up to the next multiple
-    // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows
+    // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows.  Once per backward pass
+    // (its first call is the last layer): nothing else writes those rows between the layers of one pass
     hipError_t he = hipMemsetAsync(s.dqkv + (size_t)(T - 128) * 3 * EH * 2, 0, (size_t)128 * 3 * EH * 2, (hipStream_t)stream);
     if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
   }

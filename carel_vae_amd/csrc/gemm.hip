@@ -444,6 +444,7 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   return s;
 }
 
+static int g_pp_split = 1;       // carel_gemm_set_variant(140 / 141): internally split NT / NN GEMMs on the 128x128 kernel / on the ping-pong kernel where it fits
 static int g_pp_min_tiles = 192; // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles
 static int g_big_auto = 0;       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
 static bool big_auto(const GemmParams& p, int splits) {
@@ -489,8 +490,24 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     if (sp > 1) {
       GemmParams q = p;
       q.K = p.K / sp; q.outf = p.splitk_ws; q.ldc = p.N; q.colsum_part = nullptr;
-      hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI_SLAB_F32>), dim3(p.tiles_m * p.tiles_n, 1, sp), dim3(256), 0, s, q);
+      // the slices on the ping-pong kernel where its tiles x slices fit one round (packed ECPE batches, ~1.8 k rows: 56 tiles x 4 slices of
+      // 12 K tiles each run in ~13 us against ~20 us for 84 x 4 workgroups of the 128x128 kernel with its barrier + vmcnt(0) per K step);
+      // same K partition, same order of additions inside a slice: the same bits (tests/test_gpu_gemm.py)
+      int pp_npn = 0;
+      if (!AT && g_pp_split && p.N % 96 == 0 && p.M > 128 && (p.K / sp) % 64 == 0 && p.K / sp >= 256) {
+        const long t1 = (long)((p.M + 255) / 256) * (p.N / 96) * sp;
+        if (t1 <= 256) pp_npn = 1;
+        else if (p.N % 192 == 0 && t1 / 2 <= 256) pp_npn = 2;
+      }
       const long chunks = (long)p.M * (p.N >> 3);
+      if (pp_npn) {
+        q.K = p.K;                       // the ping-pong kernel slices K by gridDim.z itself
+        int rc = gemm_pp_launch_slab(q, BT, pp_npn, sp, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL((slab_epilogue_kernel<EPI>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, p, (const float*)p.splitk_ws, sp);
+        return check_launch("gemm_pp_kernel split-K + slab_epilogue_kernel");
+      }
+      hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI_SLAB_F32>), dim3(p.tiles_m * p.tiles_n, 1, sp), dim3(256), 0, s, q);
       hipLaunchKernelGGL((slab_epilogue_kernel<EPI>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, p, (const float*)p.splitk_ws, sp);
       return check_launch("gemm_kernel split-K + slab_epilogue_kernel");
     }
@@ -629,6 +646,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }
   if (v >= 100 && v <= 116) { gemm_pp_wgrad_force(v - 100); return CAREL_OK; }         // ping-pong weight gradient: split-K factor forced (0 = heuristic)
   if (v == 130 || v == 131) { g_auto_split_min_k = v == 130 ? 1536 : 768; return CAREL_OK; }
+  if (v == 140 || v == 141) { g_pp_split = v - 140; return CAREL_OK; }
   if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles
   if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
   g_gemm_variant = v;

@@ -223,5 +223,6 @@ int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
+int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipStream_t s);   // NT / NN, `splits` K slices -> fp32 slabs at p.outf
 
 }  // namespace carel

@@ -80,9 +80,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   {
     const int tiles = p.tiles_m * p.tiles_n;
     // position in dispatch order (x fastest, then z); workgroups are dealt to the XCDs round-robin in that order
-    const int flat = (int)blockIdx.x + (int)blockIdx.z * tiles, nwg = tiles * (int)gridDim.z;
+    // (row-major-A forms with an internal K split, gridDim.z > 1: every K slice walks the same tile map; kz = blockIdx.z)
+    const int flat = AT ? (int)blockIdx.x + (int)blockIdx.z * tiles : (int)blockIdx.x, nwg = AT ? tiles * (int)gridDim.z : tiles;
     const int xcd = flat & 7, qq = nwg >> 3, rr = nwg & 7;
     const int item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (flat >> 3);   // contiguous chunk per XCD
+    if (!AT) kz = (int)blockIdx.z;
     if (AT) {
       // weight gradient: items ordered (K slice, N tile, M tile) -- an XCD's ~nwg/8 workgroups share ONE K slice of both operands
       // (or two neighbouring ones) and a few tile columns, instead of touching every slice (PMC: 180 MB fetched per launch for 63 MB
@@ -571,6 +573,20 @@ int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s) {
   if (npn == 1) return g_pp_wide ? launch_pp<1, true, true, EPI_SLAB_F32, 0, true>(p, splits, s) : launch_pp<1, true, true, EPI_SLAB_F32>(p, splits, s);
   if (npn == 2) return g_pp_wide ? launch_pp<2, true, true, EPI_SLAB_F32, 0, true>(p, splits, s) : launch_pp<2, true, true, EPI_SLAB_F32>(p, splits, s);
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_tn: npn = %d not built", npn);
+}
+
+// Row-major-A forms with an internal K split (small token counts: 56-112 tiles would leave most CUs idle): `splits` K slices of the
+// same tile grid into fp32 slabs [splits][M][N] at p.outf; the caller runs slab_epilogue_kernel over them.  Each slice adds its K tiles
+// in the same order as the 128x128 kernel's slices: the same bits.
+int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipStream_t s) {
+  if (!bt) {
+    if (npn == 1) return launch_pp<1, false, false, EPI_SLAB_F32, 0, true>(p, splits, s);
+    if (npn == 2) return launch_pp<2, false, false, EPI_SLAB_F32, 0, true>(p, splits, s);
+  } else {
+    if (npn == 1) return launch_pp<1, false, true, EPI_SLAB_F32, 0, true>(p, splits, s);
+    if (npn == 2) return launch_pp<2, false, true, EPI_SLAB_F32, 0, true>(p, splits, s);
+  }
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch_slab: npn = %d not built", npn);
 }
 
 #ifdef CAREL_GEMM_ABLATE

@@ -293,6 +293,8 @@ int carel_encoder_forward(const carel_encoder_args* args, void* stream);
  * seq_len <= 128.  ~20x slower than carel_encoder_forward: a measurement tool, not a product path. */
 int64_t carel_encoder_f32_work_bytes(int32_t batch, int32_t seq_len);
 int carel_encoder_forward_f32(const carel_encoder_args* args, void* work, void* x_out_f32, void* stream);
+/* One layer of the backward pass.  Call for layer = n_layers-1 down to 0 after a training forward: a pass STARTS with the last layer
+ * (with token packing that call also clears the filler rows of the shared dqkv scratch, which the later calls of the pass rely on). */
 int carel_encoder_backward_layer(const carel_encoder_args* args, int32_t layer, void* stream);
 int carel_encoder_backward_embeddings(const carel_encoder_args* args, void* stream);
 

@@ -220,6 +220,40 @@ def test_internal_split_k_with_workspace_matches_single_pass():
     assert rel_err(o2, o1) < 1e-6 and rel_err(o2, A2.double() @ W2.double() + r.double()) < TOL
 
 
+@pytest.mark.parametrize("M", [1792, 1920, 640])
+def test_internal_split_on_the_ping_pong_kernel_is_bitwise_the_128_tile_split(M):
+    """Packed ECPE batches (~1.8 k rows): the K slices of an internally split NT / NN GEMM run on the ping-pong kernel (hook 141, the
+    default) where tiles x slices fit one round, on the 128x128 kernel otherwise (hook 140).  Same K partition, same order of additions:
+    bit-identical results, for every epilogue the encoder uses on that path, including a row count that is not a multiple of 256."""
+    lib = L.load()
+    N = 768
+    ws = torch.empty(8 * M * N, device="cuda")
+    r, b = _rand((M, N), 1, 44), _rand((N,), 0.1, 45)
+    rowmap = None
+    cases = [("NT", L.EPI_BIAS_DROP_RESID, 3072, dict(bias=b, resid=r, drop=(7, 5, 0, 0.1))),
+             ("NN", L.EPI_ADD_F32, 3072, dict(resid=r)), ("NN", L.EPI_ADD_F32, 2304, dict(resid=r)),
+             ("NN", L.EPI_BIAS_BF16, 3072, dict())]
+    for form, epi, K, kw in cases:
+        A = _rand((M, K), 1, 41).bfloat16()
+        W = (_rand((N, K), 0.05, 42) if form == "NT" else _rand((K, N), 0.05, 43)).bfloat16()
+        outs = []
+        for hook in (140, 141):
+            L.check(lib.carel_gemm_set_variant(hook))
+            try:
+                of = torch.zeros((M, N), device="cuda")
+                ob = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+                gemm(A, W, L.GEMM_NT if form == "NT" else L.GEMM_NN, epi, M, N, K, out_f32=of, out_bf16=ob, splitk_ws=ws, **kw)
+                outs.append((of.clone(), ob.clone()))
+            finally:
+                L.check(lib.carel_gemm_set_variant(141))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (form, epi, K)
+        ref = (A.double() @ (W.double().t() if form == "NT" else W.double()))
+        if epi == L.EPI_ADD_F32:
+            assert rel_err(outs[1][0], ref + r.double()) < TOL
+        if epi == L.EPI_BIAS_BF16:
+            assert rel_err(outs[1][1], ref) < TOL_BF16
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Ping-pong kernel (gemm_pp.hip: 256 x 96n tiles, two wave groups alternating load / MFMA segments, LDS-DMA in flight
 # across raw barriers behind counted vmcnt waits).  Variant 3 forces it; variant 1 forces the 128x128 kernel.  Both
