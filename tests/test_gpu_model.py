@@ -149,6 +149,37 @@ def test_fp32_debug_mode_matches_the_reference_fp32_outputs(golden_dir, name):
         model(*call(model, batch, it0))
 
 
+def test_mpnet_encoder_under_the_model_bf16_and_fp32_debug_vs_cpu_fp32_oracle():
+    """The MPNet encoder (relative-position attention bias, RoBERTa-style position ids, no token types:
+    en_ec_sentence_transformer.py:22) under DrlClassifier, ECPE-like ragged batch: the bf16 path within the bf16 tolerances of the CPU
+    fp32 oracle (whose MPNet branch is pinned to transformers.MPNetModel, tests/test_oracle_triplet.py) and the fp32 debug path within
+    1e-5 -- the fp32 attention kernel's bias-by-distance branch included."""
+    cfg = O.EncoderConfig(layers=2, vocab_size=1200, max_pos=514, type_vocab=1, ln_eps=1e-5, variant="mpnet", pad_id=1, rel_pos=True)
+    opt = O.Opt(pair_bow_dim=257, dropout=0.0)
+    mcfg = M.encoder_config("mpnet", vocab_size=cfg.vocab_size, layers=cfg.layers, hidden_dropout=0.0, attn_dropout=0.0)
+    model = M.DrlClassifier(M.make_opt(**vars(opt)), mcfg)
+    P = O.init_params(cfg, opt, seed=11)
+    model.load_state_dict(P)
+    model.to("cuda").train()
+    batch = O.synthetic_batch(16, 64, cfg, opt.pair_bow_dim, seed=5, shape="B")
+    ids, att = batch["input_ids"], batch["attention_masks"]
+    ids[(ids == cfg.pad_id) & (att == 1)] = 2               # the pad id only where the mask says padding
+    g = torch.Generator().manual_seed(7)
+    eps_e, eps_c = torch.randn(opt.ec_dim, generator=g), torch.randn(opt.ec_dim, generator=g)
+    ref = O.forward_terms(P, batch, 3, cfg, opt, eps_e, eps_c)
+    model.set_noise(eps_e, eps_c)
+    out = model.forward_terms(*call(model, batch, 3))
+    check_fp32_parity(out, ref)
+    model.debug_fp32 = True
+    model.set_noise(eps_e, eps_c)
+    out32 = model.forward_terms(*call(model, batch, 3))
+    for k in ("pooled", "mu_e", "lv_e", "mu_c", "lv_c"):
+        assert relnorm(out32[k], ref[k]) < TOL_FP32_DEBUG, k
+    for k in TERMS:
+        r = float(ref[k])
+        assert abs(float(out32[k]) - r) <= TOL_FP32_DEBUG * max(abs(r), 1e-3), (k, float(out32[k]), r)
+
+
 @pytest.mark.parametrize("shape", ["A", "B"])
 def test_bench_configuration_elbo_within_1e_3_of_cpu_fp32(shape):
     """The north-star tolerance at the north-star configuration (BASELINE.json configs[1]): B = 64, S = 128, 12 layers,
