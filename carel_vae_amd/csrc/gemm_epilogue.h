@@ -40,6 +40,7 @@ struct GemmParams {
   float* colsum_part;       // optional [tiles_m][N]: per-row-tile column sums of the epilogue output (bias gradient)
   int split_tile_factor;    // internal split-K heuristic: the caller runs this many equal GEMMs side by side (1 = just this one)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
+  int gelu_lut;             // ping-pong kernel, GELU epilogues: 1 = table lookup (default), 0 = erf / exp arithmetic (tuning hook 160 / 161)
   int pp_xr, pp_bc;         // ping-pong kernel, NT / NN: the 8 XCDs tile the grid as pp_xr x (8 / pp_xr) rectangles, each walked in
                             // column blocks of pp_bc tiles (so that a round of 32 tiles per XCD is compact); pp_xr = 0: plain chunks
 };
@@ -134,9 +135,39 @@ __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col,
   if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) { in.r0 = *(const float4*)(p.resid + off); in.r1 = *(const float4*)(p.resid + off + 4); }
   if (epi_is_dgelu(EPI)) in.a = *(const uint4*)(p.aux + off);
 }
+// GELU by table (ping-pong kernel): the activation is evaluated on the bf16-ROUNDED pre-activation, so gelu(u) and gelu'(u), both
+// rounded to bf16, are functions of 16 bits.  The table holds them (low / high half of a word) for every bf16 u with
+// 2^-16 <= |u| < 16 -- 20 exponents x 128 mantissas x 2 signs = 5 120 words, 20 KiB, filled once per process by the same device
+// functions the arithmetic path uses, so both paths give the same bits -- and is copied into the LDS behind the staging buffers at
+// kernel start.  An 8-column group with any lane outside that range (|u| < 1.5e-5, |u| >= 16, NaN) takes the arithmetic path for the
+// whole wave (< 1 % of the groups on N(0, 1) pre-activations).  The erf + exp arithmetic was what bounded this epilogue:
+// FFN1 forward 8192 x 3072 x 768: 41-43 us with the bias -> bf16 epilogue, 55-58 with GELU, one output or two
+// (tools/bench_ffn1_epilogue.py).
+constexpr int LUT_EXP_LO = 111, LUT_NEXP = 20, LUT_HALF = LUT_NEXP * 128, LUT_WORDS = 2 * LUT_HALF, LUT_BYTES = LUT_WORDS * 4;
+__device__ __forceinline__ bool gelu_lut8(const uint32_t* lut, const uint4 o, uint4& g, uint4& d) {
+  const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+  uint32_t idx[8];
+  bool ok = true;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint32_t h = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+    const uint32_t i = (h & 0x7fffu) - (uint32_t)(LUT_EXP_LO << 7);
+    ok = ok && i < (uint32_t)LUT_HALF;
+    idx[e] = i + (h >> 15) * (uint32_t)LUT_HALF;
+  }
+  if (!__all(ok)) return false;                 // wave-uniform: the whole wave computes this group
+  uint32_t t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = lut[idx[e]];
+  g = uint4{(t[0] & 0xffffu) | (t[1] << 16), (t[2] & 0xffffu) | (t[3] << 16), (t[4] & 0xffffu) | (t[5] << 16), (t[6] & 0xffffu) | (t[7] << 16)};
+  d = uint4{(t[0] >> 16) | (t[1] & 0xffff0000u), (t[2] >> 16) | (t[3] & 0xffff0000u), (t[4] >> 16) | (t[5] & 0xffff0000u), (t[6] >> 16) | (t[7] & 0xffff0000u)};
+  return true;
+}
+
 // after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
+// lut: the GELU table in LDS (ping-pong kernel) or null (arithmetic)
 template <int EPI>
-__device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col) {
+__device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col, const uint32_t* lut = nullptr) {
   const long off = row * p.ldc + col;
   if (epi_has_bias(EPI)) {
     if (p.bias) {
@@ -149,22 +180,31 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
   } else if (EPI == EPI_BIAS_GELU) {
     const uint4 o = pack8(v);
     if (p.out0) *(uint4*)(p.out0 + off) = o;            // block-uniform; null in inference (half the epilogue's bytes)
-    float u[8];
-    unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
+    uint4 gq, dq;
+    if (!(lut && gelu_lut8(lut, o, gq, dq))) {
+      float u[8];
+      unpack8(o, u);            // GELU of the bf16-rounded pre-activation that backward reads back
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
-    *(uint4*)(p.out1 + off) = pack8(u);
-  } else if (EPI == EPI_BIAS_GELU_DG) {
-    float u[8], d[8];
-    unpack8(pack8(v), u);     // both on the bf16-rounded pre-activation (what the reference's backward would see saved in bf16)
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      f32x2 g, dg;
-      gelu_erf_both2(f32x2{u[e], u[e + 1]}, g, dg);
-      u[e] = g.x; u[e + 1] = g.y; d[e] = dg.x; d[e + 1] = dg.y;
+      for (int e = 0; e < 8; e += 2) { const f32x2 g = gelu_erf2(f32x2{u[e], u[e + 1]}); u[e] = g.x; u[e + 1] = g.y; }
+      gq = pack8(u);
     }
-    *(uint4*)(p.out0 + off) = pack8(d);
-    *(uint4*)(p.out1 + off) = pack8(u);
+    *(uint4*)(p.out1 + off) = gq;
+  } else if (EPI == EPI_BIAS_GELU_DG) {
+    const uint4 o = pack8(v); // both on the bf16-rounded pre-activation (what the reference's backward would see saved in bf16)
+    uint4 gq, dq;
+    if (!(lut && gelu_lut8(lut, o, gq, dq))) {
+      float u[8], d[8];
+      unpack8(o, u);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 g, dg;
+        gelu_erf_both2(f32x2{u[e], u[e + 1]}, g, dg);
+        u[e] = g.x; u[e + 1] = g.y; d[e] = dg.x; d[e + 1] = dg.y;
+      }
+      gq = pack8(u); dq = pack8(d);
+    }
+    *(uint4*)(p.out0 + off) = dq;
+    *(uint4*)(p.out1 + off) = gq;
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r0 = in.r0, r1 = in.r1;
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
@@ -219,6 +259,7 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s);   
 void gemm_pp_force_npn(int n);
 void gemm_pp_wide_variant(int on);
 void gemm_pp_xcd_rect(int on);
+void gemm_pp_gelu_lut(int on);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);

@@ -33,12 +33,41 @@ namespace carel {
 
 namespace {
 
+// the GELU table (gemm_epilogue.h: gelu_lut8): word i = bf16 gelu(u) | bf16 gelu'(u) << 16 for the i-th bf16 u of the covered range
+__device__ uint32_t g_gelu_lut[LUT_WORDS];
+__global__ void gelu_lut_fill_kernel() {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= LUT_WORDS) return;
+  const uint32_t h = (uint32_t)((i % LUT_HALF) + (LUT_EXP_LO << 7)) | (i >= LUT_HALF ? 0x8000u : 0u);
+  float u[8], d[8];
+  unpack8(uint4{h | (h << 16), h | (h << 16), h | (h << 16), h | (h << 16)}, u);
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {             // the arithmetic path of epi_out8, verbatim
+    f32x2 g, dg;
+    gelu_erf_both2(f32x2{u[e], u[e + 1]}, g, dg);
+    u[e] = g.x; u[e + 1] = g.y; d[e] = dg.x; d[e + 1] = dg.y;
+  }
+  g_gelu_lut[i] = (pack8(u).x & 0xffffu) | (pack8(d).x << 16);
+}
+// filled on first use, once per device per process (a device-wide synchronise that one time: other streams may launch GEMMs right after)
+static int gelu_lut_ready() {
+  static bool done[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return set_error(CAREL_ERR_HIP, "gemm_pp: hipGetDevice failed");
+  if (done[dev]) return CAREL_OK;
+  hipLaunchKernelGGL(gelu_lut_fill_kernel, dim3((LUT_WORDS + 255) / 256), dim3(256), 0, 0);
+  if (hipDeviceSynchronize() != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp: GELU table fill failed");
+  done[dev] = true;
+  return CAREL_OK;
+}
+
 template <int V> struct IC { static constexpr int value = V; };
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+static int g_pp_gelu_lut = 1;    // tuning hook (carel_gemm_set_variant(160 / 161)): GELU epilogues by erf / exp arithmetic / by table lookup
 static int g_pp_xcd_rect = 1;    // tuning hook (carel_gemm_set_variant(120 / 121)): XCD tile map of the NT / NN forms: row-major chunks / rectangles
 constexpr int PP_A_BYTES = 32768;
 #ifndef CAREL_PP_MPRIO
@@ -200,6 +229,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
+  // GELU epilogues: the table goes into the LDS behind the staging buffers by 20 LDS-DMA pieces issued BEFORE every operand copy (vmcnt
+  // retires in order: the counted waits of the schedule are unchanged, and the first of them already covers the table)
+  constexpr bool LUT = epi_is_gelu(EPI) && !AT;
+  const uint32_t* lut_lds = (LUT && p.gelu_lut) ? (const uint32_t*)(smem + G::LDS) : nullptr;
+  if (LUT && p.gelu_lut) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int piece = wave * 3 + k;                          // wave-uniform
+      if (piece * 1024 < LUT_BYTES) {
+        __builtin_amdgcn_global_load_lds((const void*)((const char*)g_gelu_lut + piece * 1024 + lane * 16), (CAREL_LDS void*)(smem + G::LDS + piece * 1024), 16, 0, 0);
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
   // ---- prologue: the units the steady-state schedule would have issued before phase 0 ------------------------------
   static_for<S::NPRO>([&](auto I) {
     constexpr int i = decltype(I)::value;
@@ -399,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       }
       const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
       if (ok) {
-        epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col);
+        epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds);
         if (epi_is_dgelu(EPI)) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
@@ -448,13 +491,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
 int launch_pp(GemmParams p, int splits, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
+  constexpr int LDS_BYTES = G::LDS + ((epi_is_gelu(EPI) && !AT) ? LUT_BYTES : 0);
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  if (epi_is_gelu(EPI)) { const int rc = gelu_lut_ready(); if (rc) return rc; }
   static bool attr = false;      // per process; setting it again is harmless if two threads race
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
+  p.gelu_lut = g_pp_gelu_lut;
   p.pp_xr = 0; p.pp_bc = 1;
   if (!AT && g_pp_xcd_rect) {
     // XCD rectangles: the partition xr x (8 / xr) of the tile grid whose rectangles stage the fewest operand rows (R x 256 of A plus
@@ -474,7 +521,7 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
       p.pp_bc = bc;
     }
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), G::LDS, s, p);
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), LDS_BYTES, s, p);
   return check_launch("gemm_pp_kernel");
 }
 
@@ -492,6 +539,7 @@ int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
 
 void gemm_pp_wide_variant(int on) { g_pp_wide = on ? 1 : 0; }
 void gemm_pp_xcd_rect(int on) { g_pp_xcd_rect = on ? 1 : 0; }
+void gemm_pp_gelu_lut(int on) { g_pp_gelu_lut = on ? 1 : 0; }
 static int g_pp_force_npn = 0;     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
 void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
 

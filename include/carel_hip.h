@@ -11,7 +11,8 @@
  *   - plain-old-data argument structs, no torch types; row-major tensors;
  *   - every call only ENQUEUES work on `stream` (void* = hipStream_t): no device allocation, no host sync.  Process-wide
  *     state the library does keep: the thread-local error string; per device, three library-owned streams and ten events
- *     created on first use (overlap_wgrad / forward chains, see carel_encoder_args); the tuning hooks set through
+ *     created on first use (overlap_wgrad / forward chains, see carel_encoder_args); a 20-KiB table of gelu / gelu' by bf16 input in
+ *     device memory, filled by the first GELU GEMM of the process (that one call synchronises the device); the tuning hooks set through
  *     carel_gemm_set_variant; the carel_profile_gemm event log.  None of it changes results;
  *   - return 0 on success, a negative CAREL_ERR_* otherwise; carel_last_error() gives the message;
  *   - "bf16" = raw bfloat16 bits (uint16_t); "f32" = IEEE float.
@@ -106,7 +107,9 @@ int32_t carel_gemm_wgrad_splits(int32_t M, int32_t N, int64_t T);
  * 30/31 = automatic use of the old 256x192 tile off/on; 20..24 XCD tile layouts of the 128x128 kernel; 70+n = ping-pong tile width
  * 96n forced (0 = heuristic); 90/91 = ping-pong schedule with fine (12-MFMA) / wide (24-MFMA, default) phases; 100+s = weight-gradient
  * split-K factor of the ping-pong kernel forced to s (0 = heuristic); 120/121 = its XCD tile map: row-major chunks / rectangles
- * (default); 130/131 = internal split-K for K >= 1536 only / also for the K = 768 one-row-tile GEMMs (default); 11..19, 61..68 timing
+ * (default); 130/131 = internal split-K for K >= 1536 only / also for the K = 768 one-row-tile GEMMs (default); 140/141 = the K slices
+ * of an internally split NT / NN GEMM on the 128x128 kernel / on the ping-pong kernel where they fit one round (default); 160/161 = the
+ * ping-pong kernel's GELU epilogues by erf / exp arithmetic / by table lookup (default; the same bits); 11..19, 61..68 timing
  * ablations (wrong results; only in a -DCAREL_GEMM_ABLATE build).  None of the non-ablation settings changes results beyond the fp32
  * summation order of split-K. */
 int carel_gemm_set_variant(int32_t variant);

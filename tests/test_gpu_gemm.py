@@ -330,6 +330,43 @@ def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, wide):
             assert torch.equal(res[3][k], res[1][k]), (k, float((res[3][k].float() - res[1][k].float()).abs().max()))
 
 
+def test_gelu_table_of_the_ping_pong_epilogue_equals_the_arithmetic_on_every_bf16_value():
+    """The ping-pong kernel's GELU epilogues look gelu(u) / gelu'(u) up in a table indexed by the bf16 bits of u (gemm_epilogue.h,
+    gelu_lut8); the 128x128 kernel evaluates erf and exp.  A GEMM whose pre-activations run through EVERY finite bf16 value (one-hot A
+    rows pick one B entry each) must give identical bits from both, for both GELU epilogues -- in-range values (table) and the rest
+    (the arithmetic fall-back inside the ping-pong kernel) alike."""
+    M, N, K = 256, 384, 256
+    A = torch.zeros((M, K)); A[torch.arange(M), torch.arange(M) % K] = 1.0
+    bits = ((torch.arange(K).view(K, 1) * N + torch.arange(N).view(1, N)) & 0xFFFF).to(torch.int32)
+    ex = (bits >> 7) & 0xFF
+    bits = torch.where((ex == 0xFF) | (ex == 0), torch.zeros_like(bits), bits)              # no Inf / NaN patterns; the MFMA flushes bf16 denormals
+    vals = (bits << 16).view(torch.float32)                                                  # [K, N]: the bf16 value with those bits
+    assert torch.unique(bits).numel() == 65536 - 4 * 128 + 1                                 # every normal bf16 value, and zero
+    A, W = A.cuda().bfloat16(), vals.t().contiguous().cuda().bfloat16()                      # NT: W is [N, K]
+    assert torch.equal(W.float().t().cpu(), vals)
+    res = {}
+    for v in (1, 3):
+        with _variant(v):
+            u, g = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out_bf16=u, out2_bf16=g)
+            dg, g2 = torch.empty_like(u), torch.empty_like(u)
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU_DG, M, N, K, out_bf16=dg, out2_bf16=g2)
+            res[v] = (u, g, dg, g2)
+    assert torch.equal(res[3][0].view(torch.int16).cpu(), vals.bfloat16().view(torch.int16))  # the pre-activations really are those values
+    for a, b, name in zip(res[3], res[1], ("u", "gelu", "gelu'", "gelu (with gelu')")):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), name
+    L.check(L.load().carel_gemm_set_variant(160))             # the ping-pong kernel with the table switched off: same bits again
+    try:
+        with _variant(3):
+            dg, g2 = torch.empty_like(res[3][0]), torch.empty_like(res[3][0])
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU_DG, M, N, K, out_bf16=dg, out2_bf16=g2)
+    finally:
+        L.check(L.load().carel_gemm_set_variant(161))
+    assert torch.equal(dg.view(torch.int16), res[3][2].view(torch.int16)) and torch.equal(g2.view(torch.int16), res[3][3].view(torch.int16))
+    ref = torch.nn.functional.gelu(vals.double())
+    assert float((res[3][1].double().cpu() - ref).abs().max() / 1.0) < 0.07 and rel_err(res[3][1], ref.float()) < TOL_BF16   # and they are GELU
+
+
 @pytest.mark.parametrize("wide", [1, 0])
 def test_pp_race_screen_repeated_launches(wide):
     """20 launches of each production shape on fresh random data, compared with the first launch bit for bit while a
