@@ -51,6 +51,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over each aligned group of 16 lanes, result in all 16: four DPP adds (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror) instead of four ds_bpermute round trips.  Every stage adds two group sums that are uniform within their groups, so the
+// result has the bits of the xor-butterfly (1, 2, 4, 8) it replaces.
+__device__ __forceinline__ float row16_sum(float v) {
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true)); x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true)); x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true)); x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -474,8 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     for (int q = 0; q < NF / 2; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float t = cs[q][e];
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        const float t = row16_sum(cs[q][e]);         // (24 values x 4 ds_bpermute cost 3.7 us per tile: tools/bench_epilogues.py)
         if ((lane & 15) == 0) sc[wr * BN + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8 + e] = t;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // raw barriers: a __syncthreads here would also drain the stores
