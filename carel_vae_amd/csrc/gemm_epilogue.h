@@ -139,26 +139,37 @@ __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col,
 // rounded to bf16, are functions of 16 bits.  The table holds them (low / high half of a word) for every bf16 u with
 // 2^-16 <= |u| < 16 -- 20 exponents x 128 mantissas x 2 signs = 5 120 words, 20 KiB, filled once per process by the same device
 // functions the arithmetic path uses, so both paths give the same bits -- and is copied into the LDS behind the staging buffers at
-// kernel start.  An 8-column group with any lane outside that range (|u| < 1.5e-5, |u| >= 16, NaN) takes the arithmetic path for the
+// kernel start.  Finite |u| >= 16 needs no table (gelu = u or -0.0, gelu' = 1 or 0: what the arithmetic gives once exp(-u^2 / 2)
+// underflows).  An 8-column group with any lane outside both ranges (|u| < 1.5e-5, Inf, NaN) takes the arithmetic path for the
 // whole wave (< 1 % of the groups on N(0, 1) pre-activations).  The erf + exp arithmetic was what bounded this epilogue:
 // FFN1 forward 8192 x 3072 x 768: 41-43 us with the bias -> bf16 epilogue, 55-58 with GELU, one output or two
 // (tools/bench_ffn1_epilogue.py).
 constexpr int LUT_EXP_LO = 111, LUT_NEXP = 20, LUT_HALF = LUT_NEXP * 128, LUT_WORDS = 2 * LUT_HALF, LUT_BYTES = LUT_WORDS * 4;
 __device__ __forceinline__ bool gelu_lut8(const uint32_t* lut, const uint4 o, uint4& g, uint4& d) {
   const uint32_t w[4] = {o.x, o.y, o.z, o.w};
-  uint32_t idx[8];
-  bool ok = true;
+  uint32_t idx[8], hb[8];
+  bool ok = true, big_any = false;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const uint32_t h = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
-    const uint32_t i = (h & 0x7fffu) - (uint32_t)(LUT_EXP_LO << 7);
-    ok = ok && i < (uint32_t)LUT_HALF;
-    idx[e] = i + (h >> 15) * (uint32_t)LUT_HALF;
+    const uint32_t a = h & 0x7fffu;
+    const uint32_t i = a - (uint32_t)(LUT_EXP_LO << 7);
+    const bool in = i < (uint32_t)LUT_HALF;
+    // finite |u| >= 16: exp(-u^2 / 2) underflows to 0 and erf is +-1 in fp32, so the arithmetic gives gelu = u / -0.0 and gelu' = 1 / +0.0
+    const bool big = a - (uint32_t)((LUT_EXP_LO + LUT_NEXP) << 7) < (uint32_t)((255 - LUT_EXP_LO - LUT_NEXP) << 7);
+    ok = ok && (in || big);
+    big_any = big_any || big;
+    idx[e] = in ? i + (h >> 15) * (uint32_t)LUT_HALF : 0u;
+    hb[e] = big ? ((h & 0x8000u) ? 0x00008000u : (0x3F800000u | h)) : 0u;       // the word the table would hold (never 0 for a big u)
   }
   if (!__all(ok)) return false;                 // wave-uniform: the whole wave computes this group
   uint32_t t[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) t[e] = lut[idx[e]];
+  if (__any(big_any)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = hb[e] ? hb[e] : t[e];
+  }
   g = uint4{(t[0] & 0xffffu) | (t[1] << 16), (t[2] & 0xffffu) | (t[3] << 16), (t[4] & 0xffffu) | (t[5] << 16), (t[6] & 0xffffu) | (t[7] << 16)};
   d = uint4{(t[0] >> 16) | (t[1] & 0xffff0000u), (t[2] >> 16) | (t[3] & 0xffff0000u), (t[4] >> 16) | (t[5] & 0xffff0000u), (t[6] >> 16) | (t[7] & 0xffff0000u)};
   return true;
