@@ -181,10 +181,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   for (int kt = 0; kt < 4; ++kt) {
     if (kt < nkt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __expf(x[kt][r] - m);
-        lsum += e;
-        x[kt][r] = e * dropout_mult(p.drop, ebase + kt * 32 + acc32_row(r, lane));
+      for (int r = 0; r < 16; r += 2) {          // keys acc32_row(r), acc32_row(r + 1) are an aligned pair: one hash (ebase, S and the offset are even)
+        const float e0 = __expf(x[kt][r] - m), e1 = __expf(x[kt][r + 1] - m);
+        lsum += e0; lsum += e1;
+        float d0 = 1.0f, d1 = 1.0f;
+        if (p.drop.thresh) {
+          const uint32_t hsh = dropout_hash2(p.drop, ebase + kt * 32 + acc32_row(r, lane));
+          d0 = dropout_pick(p.drop, hsh, 0u); d1 = dropout_pick(p.drop, hsh, 1u);
+        }
+        x[kt][r] = e0 * d0; x[kt][r + 1] = e1 * d1;
       }
     }
   }
@@ -304,6 +309,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         sa = mfma32(frag32_row(qimg, qt * 32, s), kf[s], sa);     // S[q][k]
         dp = mfma32(frag32_row(doimg, qt * 32, s), vf[s], dp);    // dP[q][k]
       }
+      // dropout decisions: keys 2j and 2j + 1 -- neighbouring lanes -- share one hash per query.  Even lanes hash this lane pair's queries
+      // r = 0..7, odd lanes r = 8..15, and the halves are swapped with one DPP move each: 8 hashes per lane instead of 16
+      uint32_t hown[8], hoth[8];
+      const uint32_t odd = (uint32_t)lane & 1u;
+      if (CAREL_ATTN_ABLATE != 1 && p.drop.thresh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qh = qt * 32 + (j & 3) + 8 * ((j >> 2) + 2 * (int)odd) + 4 * hh;        // = acc32_row(j + 8 * odd, lane)
+          hown[j] = dropout_hash2(p.drop, (uint32_t)((((long)b * NH + h) * S + qh) * S + (key & ~1)));
+          hoth[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[j], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the neighbour's
+        }
+      }
       f32x16 pd, dsv;                                             // dropped probabilities, dS
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -312,7 +329,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         float sc = sa[r] * 0.125f;
         if (REL) sc += relb[127 + key - q];
         const float pr = live ? (CAREL_ATTN_ABLATE == 3 ? (sc + madd - lse[q]) : __expf(sc + madd - lse[q])) : 0.f;
-        const float dm = CAREL_ATTN_ABLATE == 1 ? 1.0f : dropout_mult(p.drop, (uint32_t)((((long)b * NH + h) * S + q) * S + key));
+        const float dm = (CAREL_ATTN_ABLATE == 1 || !p.drop.thresh) ? 1.0f
+                         : dropout_pick(p.drop, ((uint32_t)(r >> 3) == odd) ? hown[r & 7] : hoth[r & 7], odd);
         pd[r] = live ? pr * dm : 0.f;
         const float ds_raw = live ? pr * (dp[r] * dm - delta[q]) : 0.f;  // d loss / d score
         dsv[r] = ds_raw * 0.125f;                                        // includes the 1/sqrt(d) of the q.k part of the scores

@@ -40,9 +40,18 @@ struct Dropout {          // passed by value to kernels
   float scale;            // 1/(1-p)
   uint32_t idx_offset;    // added to the linear element index (DP shard offset)
 };
+// Element j = idx + idx_offset is kept iff the 16-bit half (j & 1) of mix32((j >> 1) ^ key) is >= the upper 16 bits of the threshold:
+// two consecutive elements share one hash (two quarter-rate v_mul_lo_u32 each; the attention kernels take 25 M decisions per layer and
+// direction and were spending ~4 400 cycles per wave on them).  dropout_mult = one element; dropout_hash2 + dropout_pick = the pair.
+__device__ __forceinline__ float dropout_pick(const Dropout& d, uint32_t h, uint32_t odd) {
+  return ((odd ? (h >> 16) : (h & 0xffffu)) >= (d.thresh >> 16)) ? d.scale : 0.0f;
+}
+__device__ __forceinline__ uint32_t dropout_hash2(const Dropout& d, uint32_t idx) {      // hash of the pair that holds element idx
+  return mix32(((idx + d.idx_offset) >> 1) ^ d.key);
+}
 __device__ __forceinline__ float dropout_mult(const Dropout& d, uint32_t idx) {
   if (d.thresh == 0u) return 1.0f;
-  return (mix32((idx + d.idx_offset) ^ d.key) >= d.thresh) ? d.scale : 0.0f;
+  return dropout_pick(d, dropout_hash2(d, idx), (idx + d.idx_offset) & 1u);
 }
 
 // ---------------------------------------------------------------- reductions (wave = 64 lanes)

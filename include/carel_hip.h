@@ -39,8 +39,9 @@ int carel_init(int device);
 const char* carel_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Counter-based dropout.  keep(element) = mix32((idx + idx_offset) ^ mix32(seed + site*0x9E3779B9))
- * >= floor(p * 2^32); kept values are scaled by 1/(1-p).  p <= 0 disables.  `site` numbers the
+ * Counter-based dropout.  With j = idx + idx_offset and h = mix32((j >> 1) ^ mix32(seed + site*0x9E3779B9)), element j is kept iff
+ * the 16-bit half (j & 1) of h is >= floor(p * 2^32) >> 16 (two consecutive elements share one 32-bit hash: the attention kernels take
+ * 25 M decisions per layer and direction); kept values are scaled by 1/(1-p).  p <= 0 disables.  `site` numbers the
  * dropout layer (0 embeddings; 1+3l attention probabilities, 2+3l attention-output, 3+3l FFN-output of
  * encoder layer l; 100/101/102 the three classifier-input dropouts, ref :468 :485 :503).
  * Replaces nn.Dropout inside HF BertEmbeddings/BertSelfAttention/BertSelfOutput/BertOutput and

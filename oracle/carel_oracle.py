@@ -131,8 +131,12 @@ def dropout_threshold(p: float) -> int:
 def dropout_keep(seed: int, site: int, idx: np.ndarray, p: float) -> np.ndarray:
     """Boolean keep-mask for linear element indices `idx` (uint32) at dropout `site`."""
     key = _mix32(np.array([(seed + site * 0x9E3779B9) & 0xFFFFFFFF], dtype=np.uint32))[0]
-    h = _mix32(idx.astype(np.uint32) ^ key)
-    return h >= np.uint32(dropout_threshold(p))
+    # two consecutive elements share one hash: element j takes the 16-bit half (j & 1) of mix32((j >> 1) ^ key) against the upper
+    # 16 bits of the threshold (csrc/carel_common.h dropout_mult)
+    j = idx.astype(np.uint32)
+    h = _mix32((j >> np.uint32(1)) ^ key)
+    piece = np.where((j & np.uint32(1)) != 0, h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return piece >= np.uint32(dropout_threshold(p) >> 16)
 
 
 def dropout_scale_mask(seed: Optional[int], site: int, shape, p: float, row_offset: int = 0,
