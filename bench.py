@@ -416,6 +416,8 @@ def main():
         step(a.warmup + a.steps + i)
     torch.cuda.synchronize()
     ev_timed = read_gemm_events()
+    ov_empty, ov_pair = C.c_double(), C.c_double()
+    L.check(lib.carel_profile_gemm_overheads(C.byref(ov_empty), C.byref(ov_pair)))
     L.check(lib.carel_profile_gemm(0, 0))
     model.overlap_wgrad = not a.no_overlap
     model._adam_hook = hook
@@ -505,6 +507,13 @@ def main():
                 "mfma_util_pmc": mfma_util, "mfma_util_source": "STATIC: profiles/%s (tools/pmc_mfma.sh), committed with this code" % PMC_MFMA_CSV,
                 "launches_per_step": n_t / nprof, "avg_launch_us": 1e3 * ms_t / n_t, "alg_gflop_per_launch": fl_t / n_t / 1e9,
                 "gemm_ms_per_step": ms_t / nprof,
+                # how the HIP-event figure relates to rocprofv3's: avg_launch_us = (event bracket around the launch) - (bracket around an EMPTY
+                # kernel), i.e. kernel time over an empty kernel's (~1.5 us un-profiled); avg_launch_us_upper = bracket - (two event records
+                # alone): the whole interval the stream spends on the launch, dispatch gap included.  Under rocprofv3 every kernel -- the
+                # empty one too: 3.5 us -- reads ~2 us longer; the committed kernel_stats.csv average sits at or above the upper figure.
+                "event_calibration_us": {"empty_kernel_bracket": ov_empty.value, "event_pair": ov_pair.value},
+                "avg_launch_us_upper": 1e3 * ms_t / n_t + ov_empty.value - ov_pair.value,
+                "frac_lower": (fl_t / n_t) / ((1e3 * ms_t / n_t + ov_empty.value - ov_pair.value) * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
                 "note": "per-kernel durations from a serial replay of the step (wgrad_side_stream off); the timed region overlaps them",
                 "whole_step_frac_of_peak": (world * a.batch * FLOP_PER_PAIR * a.steps / dt) / (world * PEAK_BF16_TFLOPS * 1e12)}
 

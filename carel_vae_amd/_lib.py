@@ -186,6 +186,7 @@ SIGNATURES = {
     "carel_gemm_set_variant": (C.c_int, [C.c_int32]),
     "carel_profile_gemm": (C.c_int, [C.c_int32, C.c_int32]),
     "carel_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "carel_profile_gemm_overheads": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "carel_mean_pool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_mean_pool_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

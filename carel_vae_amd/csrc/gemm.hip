@@ -558,6 +558,8 @@ struct GemmProf {
   std::vector<double> flops;
   size_t used = 0;
   std::vector<hipEvent_t> cal;     // 16 start/stop pairs around an empty kernel: the bracket's own cost
+  std::vector<hipEvent_t> cal2;    // 16 start/stop pairs with nothing in between: what the two event records alone cost
+  double last_empty_us = 0.0, last_pair_us = 0.0;
   bool calibrated = false;
 } g_prof;
 __global__ void prof_empty_kernel() {}
@@ -571,6 +573,10 @@ struct ProfScope {
         (void)hipEventRecord(g_prof.cal[i], s);
         hipLaunchKernelGGL(prof_empty_kernel, dim3(1), dim3(64), 0, s);
         (void)hipEventRecord(g_prof.cal[i + 1], s);
+      }
+      for (size_t i = 0; i + 1 < g_prof.cal2.size(); i += 2) {
+        (void)hipEventRecord(g_prof.cal2[i], s);
+        (void)hipEventRecord(g_prof.cal2[i + 1], s);
       }
     }
     active = true;
@@ -588,11 +594,14 @@ struct ProfScope {
 extern "C" int carel_profile_gemm(int enable, int max_launches) {
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : g_prof.cal) (void)hipEventDestroy(e);
-  g_prof.ev.clear(); g_prof.cal.clear(); g_prof.flops.clear(); g_prof.used = 0; g_prof.on = false; g_prof.calibrated = false;
+  for (hipEvent_t e : g_prof.cal2) (void)hipEventDestroy(e);
+  g_prof.ev.clear(); g_prof.cal.clear(); g_prof.cal2.clear(); g_prof.flops.clear(); g_prof.used = 0; g_prof.on = false; g_prof.calibrated = false;
   if (!enable) return CAREL_OK;
   if (max_launches < 1) return set_error(CAREL_ERR_ARG, "carel_profile_gemm: max_launches must be positive");
   g_prof.ev.resize((size_t)max_launches * 2);
-  g_prof.cal.resize(32);
+  g_prof.cal.resize(32); g_prof.cal2.resize(32);
+  for (auto& e : g_prof.cal2)
+    if (hipEventCreate(&e) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm: hipEventCreate failed");
   for (auto& e : g_prof.ev)
     if (hipEventCreate(&e) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm: hipEventCreate failed");
   for (auto& e : g_prof.cal)
@@ -615,6 +624,13 @@ extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, in
       if (hipEventSynchronize(g_prof.cal[i + 1]) == hipSuccess && hipEventElapsedTime(&t, g_prof.cal[i], g_prof.cal[i + 1]) == hipSuccess) c.push_back(t);
     }
     if (!c.empty()) { std::sort(c.begin(), c.end()); overhead = c[c.size() / 2]; }
+    g_prof.last_empty_us = overhead * 1e3;
+    std::vector<float> c2;
+    for (size_t i = 0; i + 1 < g_prof.cal2.size(); i += 2) {
+      float t = 0.f;
+      if (hipEventSynchronize(g_prof.cal2[i + 1]) == hipSuccess && hipEventElapsedTime(&t, g_prof.cal2[i], g_prof.cal2[i + 1]) == hipSuccess) c2.push_back(t);
+    }
+    if (!c2.empty()) { std::sort(c2.begin(), c2.end()); g_prof.last_pair_us = c2[c2.size() / 2] * 1e3; }
   }
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
     if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_profile_gemm_read: event sync failed");
@@ -624,6 +640,15 @@ extern "C" int carel_profile_gemm_read(double* total_ms, double* total_flops, in
   }
   *total_ms = ms; *total_flops = fl; *launches = (int64_t)(g_prof.used / 2);
   g_prof.used = 0; g_prof.flops.clear();
+  return CAREL_OK;
+}
+
+// The two calibration medians of the last carel_profile_gemm_read (us): an event pair around an EMPTY kernel (what _read subtracts from
+// every bracket) and an event pair with nothing in between.  bracket - empty = kernel time over an empty kernel's; bracket - pair = the
+// whole interval the stream spends on the launch, i.e. what `rocprofv3 --kernel-trace` reports as the duration plus the dispatch gap.
+extern "C" int carel_profile_gemm_overheads(double* empty_kernel_bracket_us, double* event_pair_us) {
+  if (!empty_kernel_bracket_us || !event_pair_us) return set_error(CAREL_ERR_ARG, "carel_profile_gemm_overheads: null output");
+  *empty_kernel_bracket_us = g_prof.last_empty_us; *event_pair_us = g_prof.last_pair_us;
   return CAREL_OK;
 }
 

@@ -119,6 +119,9 @@ int carel_gemm_set_variant(int32_t variant);
  * (ms), the summed algorithmic flops (2*M*N*K) and the launch count, then resets the log. */
 int carel_profile_gemm(int32_t enable, int32_t max_launches);
 int carel_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches);
+/* the two calibration medians of the last read-out, us: an event pair around an empty kernel (what _read subtracts from every
+ * bracket), and an event pair with nothing in between */
+int carel_profile_gemm_overheads(double* empty_kernel_bracket_us, double* event_pair_us);
 /* out[n] (+)= sum_z slabs[z][n];  n multiple of 4 */
 int carel_slab_reduce_f32(const void* slabs, void* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
 
