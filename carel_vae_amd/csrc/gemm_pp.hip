@@ -84,8 +84,13 @@ template <int NPN, bool BT> struct PPGeom {
 // WIDE: the schedule PPSchedW<NPN> -- one phase per B part with BOTH M halves (24 MFMAs per matrix segment instead of 12, half the
 // barriers per K tile; the A fragments of both halves are read in phase 0 and kept: +16 registers), every wave drains its LDS reads
 // before the barrier that ends its load segment (so a slot may be restaged ONE phase after its last read; tools/gemm_sched.py war = 1)
+// The first ten arguments repeat the fields of `p` that the prologue needs before its first LDS-DMA instruction: as plain scalar kernel
+// arguments they are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16, carel_vae_amd/build.py; a by-value
+// struct is not), so the address arithmetic does not wait for the first s_load round trip of a cold CU.
 template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const bf16_t* B_, long lda_, long ldb_, int M_, int K_, int tiles_m_,
+                                                         int tiles_n_, int pp_xr_, int pp_bc_, GemmParams p) {
+  p.A = A_; p.B = B_; p.lda = lda_; p.ldb = ldb_; p.M = M_; p.K = K_; p.tiles_m = tiles_m_; p.tiles_n = tiles_n_; p.pp_xr = pp_xr_; p.pp_bc = pp_bc_;
   static_assert(!AT || BT, "the A^T form (weight gradient) has both operands K-strided");
   using S = std::conditional_t<WIDE, PPSchedW<NPN>, PPSched<NPN>>;
   using G = PPGeom<NPN, BT>;
@@ -520,7 +525,8 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
       p.pp_bc = bc;
     }
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), LDS_BYTES, s, p.A, p.B, p.lda,
+                     p.ldb, p.M, p.K, p.tiles_m, p.tiles_n, p.pp_xr, p.pp_bc, p);
   return check_launch("gemm_pp_kernel");
 }
 
