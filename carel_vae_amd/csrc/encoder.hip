@@ -356,11 +356,11 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream))) return rc;
   if ((rc = group_done(0)) || (rc = wait_group(1))) return rc;
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_MUL_BF16, 1, s.du, nullptr, nullptr, nullptr,
-                      nullptr, la.u, 0, 0, 0, 0.f, stream, s.part2))) return rc;
-  // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1
+                      nullptr, la.u, 0, 0, 0, 0.f, stream, nullptr))) return rc;
+  // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1, and the FFN1 bias gradient (column sums of du) from the same GEMM: its ones-vector
+  // MFMAs are free there (43.2 vs 43.1 us, tools/bench_wgrad_colsum.py), the fused column sums of the data-gradient epilogue cost 3.9 us
   if ((rc = fork())) return rc;
-  if ((rc = carel_partial_reduce_f32(s.part2, g.ffn1_b, EI, (int)(R / 128), 0, wstream))) return rc;
-  if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream))) return rc;
+  if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream, g.ffn1_b))) return rc;
   if ((rc = group_done(1))) return rc;
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
                       nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0)))) return rc;
