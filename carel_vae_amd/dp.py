@@ -19,20 +19,29 @@ import torch.distributed as dist
 
 
 class _Pending:
-    """One bucket's collective.  `wait()` is what the consumer of the averaged gradients calls on ITS stream: it makes
-    that stream wait for the collective (RCCL: stream-side; gloo: host-side) and, with a reduced-precision wire format,
-    widens the result back into the fp32 gradient range.  Idempotent."""
+    """One bucket's collective.  `wait()` is what a consumer of the averaged gradients calls on ITS stream: it makes
+    that stream wait for the collective (RCCL: `work.wait()` orders only the stream it is called on; gloo: host-side) and,
+    with a reduced-precision wire format, for the widening of the result back into the fp32 gradient range.  It may be
+    called from several streams (the auxiliary stream of the layer's fused Adam update, then the main stream at the end of
+    backward): EVERY call orders its own stream; only the widening copy itself runs once, on the first stream that waits,
+    and later callers wait for the event recorded behind it."""
 
     def __init__(self, work, view, wire):
-        self.work, self.view, self.wire, self.done = work, view, wire, False
+        self.work, self.view, self.wire = work, view, wire
+        self.widened, self.event = False, None
 
     def wait(self):
-        if self.done:
+        self.work.wait()                    # always: a stream that has not waited itself is not ordered after the collective
+        if self.wire is None:
             return
-        self.work.wait()
-        if self.wire is not None:
+        if not self.widened:
             self.view.copy_(self.wire)
-        self.done = True
+            self.widened = True
+            if self.view.is_cuda:
+                self.event = torch.cuda.Event()
+                self.event.record()
+        elif self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
 
 
 class FlatGradReducer:
@@ -86,7 +95,7 @@ class DataParallel:
     """Attach to a DrlClassifier: `dp = DataParallel(model)`; then train as usual (same forward / backward /
     optimiser calls).  Every rank must call forward with the same local batch size."""
 
-    def __init__(self, model, group=None, global_batch_terms=True, wire_dtype=None):
+    def __init__(self, model, group=None, global_batch_terms=True, wire_dtype=None, embed_chunks=4):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (init_process_group) before DataParallel")
         self.model, self.group = model, group
@@ -103,7 +112,19 @@ class DataParallel:
         dist.broadcast(seed, src=0, group=group)
         self._noise_seed, self._noise_gen = int(seed.item()), None
         model._shadow_versions = None
-        self.reducer = FlatGradReducer(model._flat_grad, self._buckets(model), group, wire_dtype=wire_dtype)
+        buckets = self._buckets(model)
+        # The embedding bucket (16.2 M floats for BERT-base, a sixth of the payload) is complete only when backward is: nothing is
+        # left to hide its all-reduce behind.  It therefore travels in `embed_chunks` pieces, so that the Adam update of piece k
+        # (FusedAdam(fuse_into_backward=True): auxiliary stream) runs while piece k + 1 is on the links.
+        lo, hi = buckets.pop("embeddings")
+        n = max(1, int(embed_chunks))
+        cuts = [lo + ((hi - lo) * i // n) // 64 * 64 for i in range(n)] + [hi]
+        self._embed_names = []
+        for i in range(n):
+            if cuts[i + 1] > cuts[i]:
+                buckets[f"embeddings{i}"] = (cuts[i], cuts[i + 1])
+                self._embed_names.append(f"embeddings{i}")
+        self.reducer = FlatGradReducer(model._flat_grad, buckets, group, wire_dtype=wire_dtype)
         self._gather = None        # the all-gather's receive buffer, allocated once (same size every step)
 
     @staticmethod
@@ -178,8 +199,15 @@ class DataParallel:
         update of that layer) needs before it reads the gradients -- the same under RCCL and gloo."""
         return self.reducer.reduce(f"layer{layer}")
 
-    def backward_done(self):
-        self.reducer.reduce("embeddings")
+    def backward_done(self, adam_hook=None):
+        """End of backward: the embedding pieces go out back to back; with a fused optimiser each piece's update follows its
+        own all-reduce on the auxiliary stream.  Then the MAIN stream waits for every collective of the step (also those an
+        auxiliary-stream consumer has already waited for: that wait ordered the auxiliary stream only), so whatever reads
+        `.grad` / the flat gradient buffer after backward() -- a stock optimiser, gradient clipping, a norm -- is ordered."""
+        for name in self._embed_names:
+            work = self.reducer.reduce(name)
+            if adam_hook is not None and work is not None:
+                adam_hook._range_ready(self.reducer.buckets[name], after=work)
         self.reducer.wait()
 
     def reduce_scalar_mean(self, t):

@@ -819,7 +819,7 @@ class DrlClassifier(nn.Module):
             self._dp.tail_done()
         self._backward_encoder(ea, accumulate)
         if self._dp is not None:
-            self._dp.backward_done()
+            self._dp.backward_done(None if accumulate else self._adam_hook)
         if accumulate:
             self._flat_grad.add_(prev)
         self._bind_grads()
@@ -1034,7 +1034,12 @@ class FusedAdam:
     def _layer_ready(self, layer, after=None):
         """Called by the model's backward when encoder layer `layer` has all its gradients on the main stream; under
         DataParallel `after` is the work handle of the layer's gradient all-reduce (RCCL), which the update waits for."""
-        lo, hi = self._layer_ranges[layer]
+        self._range_ready(self._layer_ranges[layer], after)
+
+    def _range_ready(self, rng, after=None):
+        """Update the flat range [lo, hi) on the auxiliary stream, after the main stream's work so far (`after` None) or after the
+        collective behind the handle `after` (its wait() orders the auxiliary stream only)."""
+        lo, hi = rng
         if after is not None:
             with torch.cuda.stream(self._aux):
                 after.wait()                 # stream-side wait: the auxiliary stream blocks until the collective is done

@@ -70,14 +70,15 @@ def generate_self_train_data(test_docs_pair_size, test_df, test_loader, model, s
                 prob_dict[index] = prob
                 srt = sorted(prob_dict.items(), key=lambda x: x[1], reverse=True)
                 top = predicted_df.iloc[srt[0][0]]
-                pos_pair, pos_emotion = top["pair"], top["emotion"]
+                pos_pair = top["pair"]
                 if strategy == "random":
+                    pos_emotion = top["emotion"]
                     if len(srt) == 1:
                         continue
                     other = predicted_df.iloc[srt[randint(1, len(srt) - 1)][0]]
                     neg_pair, neg_emotion = other["pair"], other["emotion"]
-                else:
-                    neg_pair = predicted_df.iloc[srt[-1][0]]["pair"]
+                else:               # "extreme" carries no emotion column values (ref :789-793 leaves both None), and a one-pair
+                    neg_pair = predicted_df.iloc[srt[-1][0]]["pair"]     # document yields that pair as positive AND negative
         curr += doc_pair_size
         if pos_pair is not None and neg_pair is not None:
             rows.append((pos_pair, 1, pos_emotion))

@@ -42,10 +42,13 @@ def _worker(rank, world, port, q):
         total = o + 96
         model = SimpleNamespace(_flat=torch.full((total,), float(rank + 1)), _flat_grad=torch.full((total,), float(rank + 1)),
                                 _offs=offs, cfg=SimpleNamespace(layers=n_layers), _dp=None, _shadow_versions=1)
-        dp = DataParallel(model)
+        dp = DataParallel(model, embed_chunks=2)
         ok_bcast = bool((model._flat == 1.0).all()) and model._shadow_versions is None     # replicas start identical
         b = dp.reducer.buckets
-        ok_buckets = b["embeddings"] == (0, 64) and b["layer0"] == (64, 192) and b["layer1"] == (192, 320) and b["tail"] == (320, total)
+        # the embedding range travels in pieces (64-element aligned cuts; here 64 floats -> one cut at 0: the first piece is empty and dropped)
+        emb = sorted(v for k, v in b.items() if k.startswith("embeddings"))
+        ok_buckets = (emb[0][0] == 0 and emb[-1][1] == 64 and all(x[1] == y[0] for x, y in zip(emb, emb[1:]))
+                      and b["layer0"] == (64, 192) and b["layer1"] == (192, 320) and b["tail"] == (320, total))
         e, c = dp.broadcast_noise(torch.full((24,), float(rank)), torch.full((24,), 10.0 + rank))
         ok_noise = bool((e == 0).all() and (c == 10).all())
         # collective-free noise: every rank draws the same vectors from a generator seeded by rank 0's broadcast seed
@@ -87,8 +90,11 @@ def _worker(rank, world, port, q):
         lo1, hi1 = dp.reducer.buckets["layer1"]
         ok_avg = h1 is not None and bool(torch.allclose(model._flat_grad[lo1:hi1], torch.full((hi1 - lo1,), 1.5)))
         h0 = dp.layer_done(0)
-        dp.backward_done()
-        ok_avg = ok_avg and h0.done and bool(torch.allclose(model._flat_grad, torch.full((total,), (1.0 + 2.0) / 2)))
+        # a fused optimiser's hook sees every embedding piece with its handle (FusedAdam._range_ready); the pieces tile the range
+        seen = []
+        hook = SimpleNamespace(_range_ready=lambda rng, after=None: (after.wait(), seen.append(rng)))
+        dp.backward_done(hook)
+        ok_avg = ok_avg and seen == emb and dp.reducer.pending == [] and bool(torch.allclose(model._flat_grad, torch.full((total,), (1.0 + 2.0) / 2)))
         # reduced-precision wire format: bf16 on the wire, fp32 result, within bf16 rounding of the exact average
         flat2 = (torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1)
         red2 = FlatGradReducer(flat2, {"all": (0, 1000)}, wire_dtype=torch.bfloat16)
@@ -114,3 +120,46 @@ def test_two_rank_gloo_data_parallel_plumbing():
         assert p.exitcode == 0
     for r in res:
         assert all(r[1:]), r
+
+
+class _FakeWork:
+    """Stands in for a c10d Work: records which 'stream' (a label the test sets) each wait() was called on."""
+    current = "main"
+
+    def __init__(self):
+        self.waited_on = []
+
+    def wait(self):
+        self.waited_on.append(_FakeWork.current)
+        return True
+
+
+def test_pending_orders_every_stream_that_waits_and_widens_once():
+    """with RCCL, work.wait() orders only the stream it is called on.  The layer's fused Adam update waits on the
+    auxiliary stream; the main stream's wait at the end of backward must still reach the collective (no once-only flag), while the
+    bf16-wire widening copy runs exactly once."""
+    from carel_vae_amd.dp import _Pending, FlatGradReducer
+    w = _FakeWork()
+    view = torch.zeros(8)
+    p = _Pending(w, view, None)
+    _FakeWork.current = "aux"; p.wait()
+    _FakeWork.current = "main"; p.wait()
+    assert w.waited_on == ["aux", "main"]
+    # wire format: the copy back into the fp32 range happens on the first wait only (a second copy would be harmless but is 2x traffic)
+    w2 = _FakeWork()
+    wire = torch.arange(8, dtype=torch.bfloat16)
+    copies = []
+    class V:                       # a view that counts copy_ calls
+        is_cuda = False
+        def copy_(self, src): copies.append(src); view.copy_(src)
+    p2 = _Pending(w2, V(), wire)
+    _FakeWork.current = "aux"; p2.wait()
+    _FakeWork.current = "main"; p2.wait()
+    assert w2.waited_on == ["aux", "main"] and len(copies) == 1 and torch.equal(view, wire.float())
+    # FlatGradReducer.wait() waits for every pending handle, including ones a consumer already waited for
+    red = FlatGradReducer.__new__(FlatGradReducer)
+    a, b = _Pending(_FakeWork(), view, None), _Pending(_FakeWork(), view, None)
+    _FakeWork.current = "aux"; a.wait()
+    red.pending = [a, b]
+    _FakeWork.current = "main"; red.wait()
+    assert a.work.waited_on == ["aux", "main"] and b.work.waited_on == ["main"] and red.pending == []

@@ -5,6 +5,7 @@ import sys
 import random
 
 import pandas as pd
+import pytest
 import torch
 import torch.nn as nn
 
@@ -196,3 +197,37 @@ def test_mpnet_host_logic_bucket_map_and_state_dict_names():
     assert len(names) == len(set(names)) and "pooler.dense.weight" not in names and "embeddings.token_type_embeddings.weight" not in names
     # the string constructor of the reference scripts selects the architecture (weights are never fetched)
     assert S.SentenceTransformer("sentence-transformers/all-mpnet-base-v2", seed=0).mpnet
+
+
+def _golden_selftrain():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selftrain.json")))
+
+
+@pytest.mark.parametrize("idx", range(9))
+def test_generate_self_train_data_equals_the_reference_function(idx):
+    """pinned to the reference's own generate_self_train_data (ref :734-799; fixtures by
+    tests/golden/gen_golden_selftrain.py): three strategies x {rounded predictions as the reference's model returns them, fractional
+    scores, all-zero scores}, same `random.seed` -- same rows in the same order, incl. the emotion column ("extreme" and "threshold"
+    leave it None, :789-793) and the one-pair documents ("random" skips them, "extreme" emits the pair twice)."""
+    c = _golden_selftrain()["self_train"][idx]
+    n = len(c["scores"])
+    df = pd.DataFrame({"pair": c["pairs"], "label": [0] * n, "emotion": c["emotions"]})
+    z = torch.zeros((n, 4), dtype=torch.long)
+    loader = [{"input_ids": z, "attention_masks": z + 1, "token_type_ids": z}]
+
+    class Fixed:
+        def eval(self): pass
+        def get_pair_preds(self, ids, att, tt): return [[float(s)] for s in c["scores"]]
+    random.seed(c["seed"])
+    out = T.generate_self_train_data(c["sizes"], df, loader, Fixed(), c["strategy"], device="cpu")
+    assert list(out.columns) == c["columns"]
+    rows = [[r["pair"], int(r["label"]), None if r["emotion"] is None or pd.isna(r["emotion"]) else int(r["emotion"])] for _, r in out.iterrows()]
+    assert rows == c["rows"], c["name"]
+
+
+def test_prf1_equals_sklearn_fixtures():
+    """ref :868-870 (sklearn precision / recall / f1, average="binary", zero_division -> 0.0): values generated with sklearn."""
+    for m in _golden_selftrain()["metrics"]:
+        p, r, f = T._prf1([[v] for v in m["labels"]], [[float(v)] for v in m["preds"]])
+        assert abs(p - m["precision"]) < 1e-12 and abs(r - m["recall"]) < 1e-12 and abs(f - m["f1"]) < 1e-12, m
