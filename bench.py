@@ -29,9 +29,19 @@ def log(msg):
 
 T_START = time.time()
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC_CSV = "r02_pmc_hbm_traffic.csv"      # regenerated every round for the final code (tools/pmc_traffic.sh)
-PMC_MFMA_CSV = "r02_pmc_mfma_util.csv"           # (tools/pmc_mfma.sh)
+PMC_TRAFFIC_CSV = "r03_pmc_hbm_traffic.csv"      # regenerated every round for the final code (tools/pmc_traffic.sh)
+PMC_MFMA_CSV = "r03_pmc_mfma_util.csv"           # (tools/pmc_mfma.sh)
 FLOP_PER_PAIR = 67.05e9       # fwd+bwd algorithmic FLOPs per clause pair
+
+
+ATTN_FLOP_PER_PAIR = 3 * 12 * 50.33e6          # QK^T + PV of 12 layers, fwd + bwd, at S = 128; scales with (l / 128)^2
+LINEAR_FLOP_PER_PAIR = FLOP_PER_PAIR - ATTN_FLOP_PER_PAIR      # everything else scales with l / 128
+
+
+def effective_flops(lengths):
+    """SURVEY 8(d), shape-B: algorithmic FLOPs of one step counted on ATTENDED tokens only, so that skipping padding cannot inflate a
+    utilisation figure: linear layers scale with l / 128 per pair, attention with (l / 128)^2."""
+    return sum(LINEAR_FLOP_PER_PAIR * (l / 128.0) + ATTN_FLOP_PER_PAIR * (l / 128.0) ** 2 for l in lengths)
 
 
 def parse():
@@ -188,6 +198,61 @@ def english_leg(dev, batch_size, steps):
                    "one GPU" % batch_size)
     del model, opts
     torch.cuda.empty_cache()
+    return out
+
+
+def ablation_leg(dev, batch_size, steps, cfg_vocab):
+    """Config 5 (BASELINE.json configs[4]): the same training step with the HSIC head (drl_classifier_ec_hsic.py:253: HSIC added
+    unweighted, one-logit BCE emotion head) and with the VI / CLUB head (drl_classifier_ec_vi.py:759-774: approximation-net step with
+    its own Adam(lr 3e-3) between forward and the main backward, then the CLUB upper bound x beta) -- dense shape-A batches, the
+    headline's encoder kernels.  The MMD head is the headline itself."""
+    from carel_vae_amd import drl_classifier as M
+    from carel_vae_amd.data import synthetic_ecpe_batch
+    out = {}
+    for name, kw in (("hsic", dict(disentangle="hsic", emotion_head="bce", e_num_class=1)), ("vi", dict(disentangle="vi", emotion_head="bce", e_num_class=1))):
+        opt = M.make_opt(**kw)
+        model = M.DrlClassifier(opt, M.encoder_config("zh"), seed=0).to(dev)
+        model.train()
+        bb, ll = [], []
+        for i in range(4):
+            b = synthetic_ecpe_batch(batch_size, 128, cfg_vocab, opt.pair_bow_dim, seed=401 + i, shape="A", binary_emotion=True)
+            ll.append(b["attention_masks"].sum(1).tolist())
+            bb.append({k: v.to(dev) for k, v in b.items()})
+        if name == "vi":
+            aprx_params, _ = model.get_params()
+            aprx_opt = torch.optim.Adam(aprx_params, lr=opt.aprx_lr)
+        main_opt = M.FusedAdam(model, lr=opt.vae_lr)
+
+        def step(i):
+            b = bb[i % 4]
+            args = (b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"], b["bow_reps"], i % 41)
+            if name == "vi":                                    # the reference's two-phase step, line for line (:759-774)
+                e_emb, c_emb, aprx_loss, loss = model(*args, seq_lengths=ll[i % 4])
+                aprx_opt.zero_grad()
+                aprx_loss.backward(retain_graph=True)
+                aprx_opt.step()
+                loss = loss + 0.5 * model.get_ec_upper_loss(e_emb, c_emb)
+            else:
+                loss = model(*args, seq_lengths=ll[i % 4])
+            main_opt.zero_grad()
+            loss.backward()
+            main_opt.step()
+            return loss
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(3 + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": batch_size * steps / dt, "unit": "clause-pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                     "final_loss": float(loss.detach())}
+        log("ablation leg %s: %.3f ms/step" % (name, 1e3 * dt / steps))
+        del model, main_opt
+        torch.cuda.empty_cache()
+    out["note"] = ("config 5: dense shape-A step (B=%d, S=128, dropout on, fused HIP Adam) with opt.disentangle = hsic / vi (+ 1-logit BCE emotion head); "
+                   "vi = two-phase step with torch.optim.Adam(lr 3e-3) on the approximation net and beta = 0.5; mmd = the headline" % batch_size)
     return out
 
 
@@ -403,24 +468,62 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.detach())
     log("timed region done: %.3f ms/step" % (1e3 * dt / a.steps))
+    # ---- SURVEY 8(d)'s step definition: "H2D of a ready batch -> fwd -> bwd -> (all-reduce) -> Adam", with the reference's running-loss
+    # read-back (:845-851; every 10 steps here as in carel_vae_amd.training.train).  `value` keeps inputs resident (the contract of this
+    # bench); this leg prints the other number beside it: every step copies its batch from page-locked host memory (7 tensors, ~6.3 MB,
+    # stream-ordered non_blocking copies) and every 10th step reads the loss back.
+    host_batches = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in batches]
+    h2d_steps = a.steps
+
+    def step_h2d(i):
+        hb = host_batches[i % len(host_batches)]
+        b = {k: v.to(dev, non_blocking=True) for k, v in hb.items()}
+        loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"],
+                     b["bow_reps"], i % 41, seq_lengths=lengths[i % len(host_batches)])
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        return loss
+    for i in range(3):
+        step_h2d(i)
+    sync()
+    t_h = time.perf_counter()
+    running = 0.0
+    for i in range(h2d_steps):
+        loss = step_h2d(i)
+        if i % 10 == 9:
+            running += float(loss.detach())          # D2H sync, as the reference's running_loss += loss.item() (every step there)
+    sync()
+    dth = time.perf_counter() - t_h
+    if world > 1:
+        t = torch.tensor([dth], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dth = float(t.item())
+    with_h2d = {"value": world * a.batch * h2d_steps / dth, "unit": "clause-pairs/s", "ms_per_step": 1e3 * dth / h2d_steps, "steps": h2d_steps,
+                "note": "same step with the H2D copy of a ready (page-locked) batch inside every step and a loss read-back every 10 steps"}
+    log("with H2D + loss read-back: %.3f ms/step" % (1e3 * dth / h2d_steps))
     # roofline leg: the SAME step, 3 more times, with HIP events bracketing every GEMM launch on its stream.  It is kept
     # out of the timed region because the event markers between kernels cost ~5 % of step time (no kernel overlap at the
     # boundaries), and it runs the kernels SERIALLY (weight gradients back on the main stream): with two streams the
     # brackets of concurrent kernels overlap and a per-kernel duration stops meaning anything.  The per-launch average
     # agrees with `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-overlap --no-ecpe` (profiles/).
     nprof = 3
-    model.overlap_wgrad = False
-    hook, model._adam_hook = model._adam_hook, None
-    L.check(lib.carel_profile_gemm(1, 200 * nprof))
-    for i in range(nprof):
-        step(a.warmup + a.steps + i)
-    torch.cuda.synchronize()
-    ev_timed = read_gemm_events()
-    ov_empty, ov_pair = C.c_double(), C.c_double()
-    L.check(lib.carel_profile_gemm_overheads(C.byref(ov_empty), C.byref(ov_pair)))
-    L.check(lib.carel_profile_gemm(0, 0))
-    model.overlap_wgrad = not a.no_overlap
-    model._adam_hook = hook
+
+    def gemm_event_replay(first_step):
+        model.overlap_wgrad = False
+        hook, model._adam_hook = model._adam_hook, None
+        L.check(lib.carel_profile_gemm(1, 260 * nprof))
+        for i in range(nprof):
+            step(first_step + i)
+        torch.cuda.synchronize()
+        ev = read_gemm_events()
+        ov_e, ov_p = C.c_double(), C.c_double()
+        L.check(lib.carel_profile_gemm_overheads(C.byref(ov_e), C.byref(ov_p)))
+        L.check(lib.carel_profile_gemm(0, 0))
+        model.overlap_wgrad = not a.no_overlap
+        model._adam_hook = hook
+        return ev, ov_e.value, ov_p.value
+    ev_timed, ov_empty_v, ov_pair_v = gemm_event_replay(a.warmup + a.steps)
     pairs_per_s = world * a.batch * a.steps / dt
 
     # ---- secondary line: the same step on ECPE-shaped batches (SURVEY 8(d) shape-B: ~77 % padding), padding skipped ----
@@ -449,6 +552,16 @@ def main():
         ecpe = {"value": world * a.batch * nb / dtb, "unit": "clause-pairs/s", "ms_per_step": 1e3 * dtb / nb, "steps": nb,
                 "attended_tokens_per_pair": sum(sum(l) for l in ll) / (len(ll) * a.batch),
                 "note": "same step, ECPE-shaped lengths; padded positions are not run through the encoder (results identical)"}
+        # the roofline fraction of this leg is computed from EFFECTIVE-token FLOPs (attended tokens only)
+        eff = sum(effective_flops(ll[i % 4]) for i in range(nb))            # this rank's nb steps
+        ev_b, ov_e_b, ov_p_b = gemm_event_replay(0)
+        ecpe["roofline"] = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": world * eff / dtb / 1e12,
+                            "frac": world * eff / dtb / 1e12 / (world * PEAK_BF16_TFLOPS),
+                            "effective_gflop_per_pair": eff / (nb * a.batch) / 1e9,
+                            "note": "whole step: effective-token algorithmic FLOPs (linear x l/128, attention x (l/128)^2 per pair; dense = "
+                                    "67.05 GFLOP/pair) / step time.  gemm_kernels: the GEMM launches of the same step replayed serially with HIP "
+                                    "events; their FLOPs count the launched shapes (packed rows rounded up to 128)",
+                            "gemm_kernels": gemm_roofline(ev_b, ov_e_b, ov_p_b) if ev_b[2] else None}
         batches, lengths = keep
         log("ECPE-shaped leg: %.3f ms/step" % (1e3 * dtb / nb))
 
@@ -474,17 +587,30 @@ def main():
 
     # ---- config 4: the English three-space adversarial model (drl_classifier_en.py), one GPU ----
     english = None
-    pipeline = sentence = None
+    pipeline = sentence = ablation = None
     if not a.no_ecpe and rank == 0 and world == 1:
         pipeline = input_pipeline_leg(dev, model, optim, a.batch)
         english = english_leg(dev, a.batch, max(5, a.steps // 2))
         sentence = sentence_transformer_leg(dev, max(5, a.steps // 2))
+        ablation = ablation_leg(dev, a.batch, max(5, a.steps // 2), cfg.vocab_size)
 
     # ---- roofline of the dominant kernel family ----
     roof = None
     ms_t, fl_t, n_t = ev_timed
+
+    def gemm_roofline(ev, ov_e, ov_p):
+        """achieved / frac from the CONSERVATIVE launch time: event bracket around the launch minus a bare event pair, i.e. the whole
+        interval the stream spends on the launch, dispatch gap included -- the figure that agrees with the rocprofv3 kernel_stats
+        average committed under profiles/ (within ~3 %).  *_kernel_only: bracket minus the bracket around an EMPTY
+        kernel (kernel time over an empty kernel's), the optimistic end of the same measurement."""
+        ms, fl, n = ev
+        us_lo = 1e3 * ms / n                               # bracket - empty-kernel bracket (subtracted inside the library)
+        us_hi = us_lo + ov_e - ov_p                        # bracket - event pair
+        return {"achieved": fl / n / (us_hi * 1e-6) / 1e12, "frac": fl / n / (us_hi * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
+                "avg_launch_us": us_hi, "avg_launch_us_kernel_only": us_lo, "frac_kernel_only": fl / n / (us_lo * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
+                "launches_per_step": n / nprof, "alg_gflop_per_launch": fl / n / 1e9, "gemm_ms_per_step": us_hi * n / nprof * 1e-3,
+                "event_calibration_us": {"empty_kernel_bracket": ov_e, "event_pair": ov_p}}
     if n_t:
-        ach = fl_t / (ms_t * 1e-3) / 1e12
         traffic = None
         try:        # HBM traffic per GEMM launch from the committed PMC summary (rocprofv3 --pmc passes, see DESIGN.md section 5)
             for line in open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_CSV)):
@@ -501,21 +627,13 @@ def main():
         except (OSError, ValueError, IndexError):
             pass
         roof = {"bound": "mfma", "kernel": "carel::gemm_pp_kernel + carel::gemm_kernel (every bf16 MFMA GEMM launch of the step: fwd NT, dgrad NN, wgrad TN)",
-                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic,
                 "traffic_unit": "bytes per launch, HBM/fabric side",
                 "traffic_source": "STATIC: profiles/%s, committed with this code (rocprofv3 --pmc FETCH_SIZE x2 and --pmc WRITE_SIZE, separate passes of the serial dense run, tools/pmc_traffic.sh; algorithmic operand+output bytes average ~40e6); achieved / frac / avg_launch_us are measured live" % PMC_TRAFFIC_CSV,
                 "mfma_util_pmc": mfma_util, "mfma_util_source": "STATIC: profiles/%s (tools/pmc_mfma.sh), committed with this code" % PMC_MFMA_CSV,
-                "launches_per_step": n_t / nprof, "avg_launch_us": 1e3 * ms_t / n_t, "alg_gflop_per_launch": fl_t / n_t / 1e9,
-                "gemm_ms_per_step": ms_t / nprof,
-                # how the HIP-event figure relates to rocprofv3's: avg_launch_us = (event bracket around the launch) - (bracket around an EMPTY
-                # kernel), i.e. kernel time over an empty kernel's (~1.5 us un-profiled); avg_launch_us_upper = bracket - (two event records
-                # alone): the whole interval the stream spends on the launch, dispatch gap included.  Under rocprofv3 every kernel -- the
-                # empty one too: 3.5 us -- reads ~2 us longer; the committed kernel_stats.csv average sits at or above the upper figure.
-                "event_calibration_us": {"empty_kernel_bracket": ov_empty.value, "event_pair": ov_pair.value},
-                "avg_launch_us_upper": 1e3 * ms_t / n_t + ov_empty.value - ov_pair.value,
-                "frac_lower": (fl_t / n_t) / ((1e3 * ms_t / n_t + ov_empty.value - ov_pair.value) * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
                 "note": "per-kernel durations from a serial replay of the step (wgrad_side_stream off); the timed region overlaps them",
                 "whole_step_frac_of_peak": (world * a.batch * FLOP_PER_PAIR * a.steps / dt) / (world * PEAK_BF16_TFLOPS * 1e12)}
+        roof.update(gemm_roofline(ev_timed, ov_empty_v, ov_pair_v))
 
     out = {"metric": "clause-pairs/sec (training step)", "value": pairs_per_s, "unit": "clause-pairs/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_median": median_ms,
@@ -529,7 +647,7 @@ def main():
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
                       "wgrad_side_stream": bool(model.overlap_wgrad), "forward_chains": bool(model.overlap_wgrad and model.forward_chains),
                       "adam_in_backward": bool(getattr(optim, "_aux", None) is not None)},
-           "roofline": roof, "ecpe_shaped": ecpe, "inference": infer, "english_adversarial": english, "input_pipeline": pipeline,
+           "roofline": roof, "with_h2d_and_loss_readback": with_h2d, "ecpe_shaped": ecpe, "ablation_heads": ablation, "inference": infer, "english_adversarial": english, "input_pipeline": pipeline,
            "sentence_transformer": sentence, "final_loss": final_loss}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         def hip_loss(P0, batch, eps_e, eps_c, ocfg2, oopt, fp32=False):

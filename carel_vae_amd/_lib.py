@@ -287,8 +287,21 @@ def check(rc, what=""):
         raise CarelError("%s failed (%d): %s" % (what or "carel call", rc, msg))
 
 
+_INITED = set()
+
+
+def ensure_init(device=None):
+    """carel_init(device) once per device per process (the library's per-device immutable state: the GELU table)."""
+    import torch
+    d = torch.cuda.current_device() if device is None else int(device)
+    if d not in _INITED:
+        check(load().carel_init(d), "carel_init")
+        _INITED.add(d)
+
+
 def current_stream():
     import torch
+    ensure_init()
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -47,7 +47,24 @@ def _compile(src, force):
     return obj, True
 
 
+def _flags_changed():
+    """The object cache is keyed on the compile flags too (an ablation build with CAREL_EXTRA_FLAGS must not survive into a normal
+    build: ADVICE r02): a stamp file holds the flags of the objects on disk."""
+    import hashlib
+    stamp = os.path.join(CSRC, ".flags_stamp")
+    h = hashlib.sha1(" ".join(FLAGS + [k + ":" + " ".join(v) for k, v in sorted(FILE_FLAGS.items())]).encode()).hexdigest()
+    try:
+        old = open(stamp).read().strip()
+    except OSError:
+        old = None
+    if old != h:
+        open(stamp, "w").write(h + "\n")
+        return old is not None or any(f.endswith(".o") for f in os.listdir(CSRC))
+    return False
+
+
 def build(force=False, verbose=True):
+    force = _flags_changed() or force
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), srcs))

@@ -34,7 +34,7 @@ extern "C" int carel_init(int device) {
   if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_init: hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return set_error(CAREL_ERR_HIP, "carel_init: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
-  return CAREL_OK;
+  return gemm_pp_init_device(device);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

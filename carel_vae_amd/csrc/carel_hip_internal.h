@@ -10,6 +10,7 @@ namespace carel {
 
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+int gemm_pp_init_device(int device);      // gemm_pp.hip: fills the GELU table (carel_init)
 // 768-wide row gather / scatter by int32 index (ln.hip); either of the f32 / bf16 pairs may be null
 int gather_rows(const void* in_f32, const void* in_bf16, const void* idx, int n, void* out_f32, void* out_bf16, hipStream_t stream);
 int scatter_rows(const void* in_f32, const void* in_bf16, const void* idx, int n, void* out_f32, void* out_bf16, hipStream_t stream);

@@ -41,6 +41,7 @@ struct GemmParams {
   int split_tile_factor;    // internal split-K heuristic: the caller runs this many equal GEMMs side by side (1 = just this one)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
   int gelu_lut;             // ping-pong kernel, GELU epilogues: 1 = table lookup (default), 0 = erf / exp arithmetic (tuning hook 160 / 161)
+  int epi_prefetch;         // ping-pong kernel: request the epilogue's residual / aux inputs before the main loop (tuning hook 170 / 171)
   int pp_xr, pp_bc;         // ping-pong kernel, NT / NN: the 8 XCDs tile the grid as pp_xr x (8 / pp_xr) rectangles, each walked in
                             // column blocks of pp_bc tiles (so that a round of 32 tiles per XCD is compact); pp_xr = 0: plain chunks
 };
@@ -48,8 +49,17 @@ struct GemmParams {
 // ---------------------------------------------------------------------------------------------
 // Epilogue for 4 consecutive columns (col..col+3) of C row `row`, accumulator values v.
 // ---------------------------------------------------------------------------------------------
+// The inputs of the 4-column epilogue (f32 residual or bf16 aux values of the same 4 elements), so that a kernel can request them
+// long before the accumulators are final (gemm_pp.hip asks for a whole tile's inputs before its main loop).
+struct EpiIn4 { float4 r; uint2 a; };
 template <int EPI>
-__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
+__device__ __forceinline__ void epi_in4(const GemmParams& p, long row, long col, EpiIn4& in) {
+  const long off = row * p.ldc + col;
+  if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) in.r = *(const float4*)(p.resid + off);
+  if (epi_is_dgelu(EPI)) in.a = *(const uint2*)(p.aux + off);
+}
+template <int EPI>
+__device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const EpiIn4& in, long row, long col) {
   const long off = row * p.ldc + col;
   if (epi_has_bias(EPI)) {
     if (p.bias) {
@@ -74,7 +84,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     *(uint2*)(p.out0 + off) = uint2{pack2bf(da.x, da.y), pack2bf(db.x, db.y)};
     *(uint2*)(p.out1 + off) = uint2{pack2bf(ga.x, ga.y), pack2bf(gb.x, gb.y)};
   } else if (EPI == EPI_BIAS_DROP_RESID) {
-    const float4 r = *(const float4*)(p.resid + off);
+    const float4 r = in.r;
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o;
     o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
@@ -83,21 +93,21 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     o.w = v[3] * dropout_mult(p.drop, e + 3) + r.w;
     *(float4*)(p.outf + off) = o;
   } else if (EPI == EPI_DGELU_BF16) {
-    const uint2 a = *(const uint2*)(p.aux + off);
+    const uint2 a = in.a;
     const float u0 = bf2f((bf16_t)(a.x & 0xffff)), u1 = bf2f((bf16_t)(a.x >> 16));
     const float u2 = bf2f((bf16_t)(a.y & 0xffff)), u3 = bf2f((bf16_t)(a.y >> 16));
     uint2 o = {pack2bf(v[0] * gelu_erf_grad(u0), v[1] * gelu_erf_grad(u1)),
                pack2bf(v[2] * gelu_erf_grad(u2), v[3] * gelu_erf_grad(u3))};
     *(uint2*)(p.out0 + off) = o;
   } else if (EPI == EPI_MUL_BF16) {
-    const uint2 a = *(const uint2*)(p.aux + off);
+    const uint2 a = in.a;
     uint2 o = {pack2bf(v[0] * bf2f((bf16_t)(a.x & 0xffff)), v[1] * bf2f((bf16_t)(a.x >> 16))),
                pack2bf(v[2] * bf2f((bf16_t)(a.y & 0xffff)), v[3] * bf2f((bf16_t)(a.y >> 16)))};
     *(uint2*)(p.out0 + off) = o;
   } else if (EPI == EPI_ADD_F32) {
     float4 o = {v[0], v[1], v[2], v[3]};
     if (p.resid) {
-      const float4 r = *(const float4*)(p.resid + off);
+      const float4 r = in.r;
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     *(float4*)(p.outf + off) = o;
@@ -105,6 +115,13 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row
     float4 o = {v[0], v[1], v[2], v[3]};
     *(float4*)(p.outf + (long)blockIdx.z * p.M * p.ldc + off) = o;
   }
+}
+// epi_store = the two steps back to back; every kernel's results are those of this one code path
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
+  EpiIn4 in;
+  epi_in4<EPI>(p, row, col, in);
+  epi_out4<EPI>(p, v, in, row, col);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -267,10 +284,12 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s);   
 #endif
 // weight-gradient form (A^T B into fp32 slabs; p.K = the WHOLE contraction length, dealt to `splits` z slices as evenly
 // as possible -- the slices need not be equal, so any split factor works)
+int gemm_pp_init_device(int device);     // carel_init: per-device immutable state (the GELU table)
 void gemm_pp_force_npn(int n);
 void gemm_pp_wide_variant(int on);
 void gemm_pp_xcd_rect(int on);
 void gemm_pp_gelu_lut(int on);
+void gemm_pp_epi_prefetch(int on);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);

@@ -24,6 +24,7 @@
 //   B_j   NT: 96 weight rows x 64 k = 12 KiB ROW image (second instruction half-populated)
 //         NN: 64 k-rows x 96 columns in a 256-B-pitch COL image = 16 KiB (12 of 16 chunks per row populated)
 //   image row r of B_j <-> tile column (r / 48) * 48*NPN + j*48 + r % 48, i.e. each wave's columns are contiguous.
+#include <atomic>
 #include <utility>
 #include "gemm_epilogue.h"
 
@@ -49,16 +50,15 @@ __global__ void gelu_lut_fill_kernel() {
   }
   g_gelu_lut[i] = (pack8(u).x & 0xffffu) | (pack8(d).x << 16);
 }
-// filled on first use, once per device per process (a device-wide synchronise that one time: other streams may launch GEMMs right after)
+// Filled by carel_init(device), once per device per process (capi.hip calls gemm_pp_init_device): the fill is enqueued on the null
+// stream and carel_init synchronises it -- initialisation may; no GEMM call ever synchronises.  A GELU-epilogue launch on a device
+// that was never initialised fails loudly instead of filling lazily (a lazy fill would need a device-wide synchronise inside a call).
+static std::atomic<int> g_lut_state[16];       // 0 = never filled, 1 = filled
 static int gelu_lut_ready() {
-  static bool done[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return set_error(CAREL_ERR_HIP, "gemm_pp: hipGetDevice failed");
-  if (done[dev]) return CAREL_OK;
-  hipLaunchKernelGGL(gelu_lut_fill_kernel, dim3((LUT_WORDS + 255) / 256), dim3(256), 0, 0);
-  if (hipDeviceSynchronize() != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp: GELU table fill failed");
-  done[dev] = true;
-  return CAREL_OK;
+  if (g_lut_state[dev].load(std::memory_order_acquire) == 1) return CAREL_OK;
+  return set_error(CAREL_ERR_ARG, "gemm_pp: carel_init(%d) has not been called on this device (it fills the GELU table of the fused FFN1 epilogue)", dev);
 }
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -68,6 +68,7 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 static int g_pp_gelu_lut = 1;    // tuning hook (carel_gemm_set_variant(160 / 161)): GELU epilogues by erf / exp arithmetic / by table lookup
+static int g_pp_epi_prefetch = 1;   // tuning hook (carel_gemm_set_variant(170 / 171)): epilogue inputs requested at the end / before the main loop
 static int g_pp_xcd_rect = 1;    // tuning hook (carel_gemm_set_variant(120 / 121)): XCD tile map of the NT / NN forms: row-major chunks / rectangles
 constexpr int PP_A_BYTES = 32768;
 #ifndef CAREL_PP_MPRIO
@@ -88,7 +89,7 @@ template <int NPN, bool BT> struct PPGeom {
 // arguments they are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16, carel_vae_amd/build.py; a by-value
 // struct is not), so the address arithmetic does not wait for the first s_load round trip of a cold CU.
 template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const bf16_t* B_, long lda_, long ldb_, int M_, int K_, int tiles_m_,
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_pp_kernel(const bf16_t* A_, const bf16_t* B_, long lda_, long ldb_, int M_, int K_, int tiles_m_,
                                                          int tiles_n_, int pp_xr_, int pp_bc_, GemmParams p) {
   p.A = A_; p.B = B_; p.lda = lda_; p.ldb = ldb_; p.M = M_; p.K = K_; p.tiles_m = tiles_m_; p.tiles_n = tiles_n_; p.pp_xr = pp_xr_; p.pp_bc = pp_bc_;
   static_assert(!AT || BT, "the A^T form (weight gradient) has both operands K-strided");
@@ -248,12 +249,50 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
       }
     }
   }
+  // ---- epilogue geometry (needed early: the epilogue's INPUTS are requested before the main loop) -----------------------
+  const int rho = lane >> 4;
+  constexpr int NQ = NF / 2;
+  auto row_of = [&](int b) { return m0 + (AT ? (b >> 1) * 128 + wr * 32 : wr * 64 + (b >> 1) * 32) + (b & 1) * 16 + (lane & 15); };
+  // Epilogue inputs ahead of the main loop.  The residual rows / saved gelu'(u) values an epilogue combines with the accumulators do
+  // not depend on them, and in a training step they are COLD (written a forward pass ago, or by a kernel ~100 MB of traffic ago):
+  // requested after the last K tile they cost one exposed HBM round trip per row block, and the odd third fragment of the 96-column
+  // tile used to load -> wait -> store four times in a row (tools/bench_gemm_cold.py: +3.0 .. +5.4 us per launch for cold inputs).
+  // So the first PB row blocks' inputs are requested right behind the prologue's DMA units and sit in registers through the main loop
+  // (NPN 1: all four blocks, 48 registers; NPN 2: all four for the bf16 aux values of the FFN2 data gradient, 48 registers, two for f32 residuals).  vmcnt retires in issue order, so every counted wait that targets a
+  // PROLOGUE unit grows by the NE load instructions issued after it: the prologue's own wait and the waits of K tile 0 (all of which
+  // target prologue units -- checked by tools/gemm_sched.py, first_tile_waits_target_prologue); from tile 1 on the waits target units
+  // issued after these loads and are unchanged, i.e. the inputs get one K tile of flight before anything waits for them.  Rows past M
+  // are clamped (never stored), so the instruction count is static.
+  constexpr bool HAS_IN = EPI == EPI_BIAS_DROP_RESID || EPI == EPI_ADD_F32 || epi_is_dgelu(EPI);
+  constexpr int PB = (HAS_IN && !AT && WIDE && DBG == 0) ? (NPN == 1 ? 4 : NPN == 2 ? (epi_is_dgelu(EPI) ? 4 : 2) : 0) : 0;    // (bf16 aux: 4 registers per 8 columns)
+  constexpr int NE = PB * (NQ * (epi_is_dgelu(EPI) ? 1 : 2) + (NF & 1));
+  static_assert(NE == 0 || (S::NTAIL >= 1 && NE + 16 <= 63), "vmcnt is a 6-bit counter");
+  const bool pre = PB > 0 && p.epi_prefetch && (EPI != EPI_ADD_F32 || p.resid != nullptr) && nk > S::NTAIL;      // wave-uniform
+  EpiIn8 pin[PB > 0 ? PB : 1][NQ > 0 ? NQ : 1];
+  EpiIn4 pin4[PB > 0 ? PB : 1];
   // ---- prologue: the units the steady-state schedule would have issued before phase 0 ------------------------------
   static_for<S::NPRO>([&](auto I) {
     constexpr int i = decltype(I)::value;
     issue(IC<S::pro_unit[i]>{}, a_ptr, b_ptr, S::pro_tile[i], S::pro_tile[i] % ST);
   });
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::PRO_WAIT) : "memory");
+  if constexpr (PB > 0) {
+    if (pre) {
+      static_for<PB>([&](auto BB) {
+        constexpr int b = decltype(BB)::value;
+        long row = row_of(b);
+        if (row > (long)p.M - 1) row = (long)p.M - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) epi_in8<EPI>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, pin[b][q]);
+        if constexpr (NF & 1) epi_in4<EPI>(p, row, n0 + wc * WN + (NF - 1) * 16 + rho * 4, pin4[b]);
+      });
+      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::PRO_WAIT + NE) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::PRO_WAIT) : "memory");
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::PRO_WAIT) : "memory");
+  }
   __builtin_amdgcn_s_barrier();
   if (wc == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind group 0
 
@@ -261,8 +300,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
   bool first_tile = true;                                      // (ablation builds only)
   // one K tile; R = 0: steady state, R = r > 0: r tiles remain including this one (tail vmcnt tables, no issue past K)
   int tile_no = 0;                                             // (DBG 9: in-kernel stamps of one steady-state K tile, workgroup 0)
-  auto tile = [&](auto RR) {
-    constexpr int R = decltype(RR)::value;
+  auto tile = [&](auto RR, auto XX) {
+    constexpr int R = decltype(RR)::value, XW = decltype(XX)::value;      // XW: load instructions in flight that are NEWER than every unit this tile waits for
     const char* st = smem + sidx * STAGE;
     const bool stamp = DBG == 9 && blockIdx.x == 0 && tile_no == (nk >> 1) && (wave == 0 || wave == 4);
     static_for<NP>([&](auto PP) {
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
         if constexpr (!(IL && P == 0 && e < 2)) issue_e(IC<e>{});
       });
       if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[2] = __builtin_amdgcn_s_memtime(); }       // DMA issued
-      if constexpr (S::wait[R][P] >= 0 && DBG != 1 && DBG != 7 && DBG != 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P]) : "memory");
+      if constexpr (S::wait[R][P] >= 0 && DBG != 1 && DBG != 7 && DBG != 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::wait[R][P] + XW) : "memory");
       if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[3] = __builtin_amdgcn_s_memtime(); }       // counted vmcnt wait over
       if constexpr (WIDE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads complete before the barrier: war = 1
       if (DBG == 9) { __builtin_amdgcn_sched_barrier(0); ts[4] = __builtin_amdgcn_s_memtime(); }       // fragments landed
@@ -378,8 +417,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
   };
   unsigned long long t_loop0 = 0;
   if (DBG == 9) { t_loop0 = __builtin_amdgcn_s_memtime(); rt[1] = __builtin_amdgcn_s_memrealtime(); }
-  for (int t = 0; t < nk - S::NTAIL; ++t) tile(IC<0>{});
-  static_for<S::NTAIL>([&](auto I) { tile(IC<S::NTAIL - decltype(I)::value>{}); });
+  int t_first = 0;
+  if constexpr (NE > 0) {
+    if (pre) { tile(IC<0>{}, IC<NE>{}); t_first = 1; }         // K tile 0: its waits target prologue units, older than the NE input loads
+  }
+  for (int t = t_first; t < nk - S::NTAIL; ++t) tile(IC<0>{}, IC<0>{});
+  static_for<S::NTAIL>([&](auto I) { tile(IC<S::NTAIL - decltype(I)::value>{}, IC<0>{}); });
   if (wc == 0) __builtin_amdgcn_s_barrier();                   // both groups have now passed the same number of barriers
   if (DBG == 9) rt[2] = __builtin_amdgcn_s_memrealtime();
   if (DBG == 9 && p.splitk_ws && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
@@ -406,8 +449,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
   // Row blocks b = (h, i) of 16 rows; the inputs (residual / pre-GELU rows) of block b + 1 are requested before block b is
   // stored, the bias once per column group up front: no load ever queues behind a store of its own wave (see epi_in8).
   if (EPI == EPI_SLAB_F32) p.outf += ((long)kz - (long)blockIdx.z) * p.M * p.ldc;      // the shared epilogue indexes slabs by blockIdx.z
-  const int rho = lane >> 4;
-  constexpr int NQ = NF / 2;
   float cs[NQ > 0 ? NQ : 1][8];
 #pragma unroll
   for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q)
@@ -416,7 +457,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
   float bias8[NQ > 0 ? NQ : 1][8];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) epi_bias8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, bias8[q]);
-  auto row_of = [&](int b) { return m0 + (AT ? (b >> 1) * 128 + wr * 32 : wr * 64 + (b >> 1) * 32) + (b & 1) * 16 + (lane & 15); };
   // (npn 3 with a residual / aux input has no registers for two blocks of inputs: load and use block by block there;
   // the encoder never runs that combination -- N = 2304 is the bias-only QKV projection)
   constexpr bool PIPE = NPN < 3 || EPI == EPI_BIAS_BF16 || epi_is_gelu(EPI) || EPI == EPI_SLAB_F32;
@@ -428,12 +468,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
       for (int q = 0; q < NQ; ++q) epi_in8<EPI>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, dst[q]);
     }
   };
-  if (PIPE) load_block(0, in[0]);
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (PIPE) { if (b + 1 < 4) load_block(b + 1, in[(b + 1) & 1]); }
-    else load_block(b, in[0]);
-    const int h = b >> 1, i = b & 1;
+  // blocks below PB already hold their inputs (requested before the main loop) when `pre`
+  if (PIPE && !(pre && PB > 0)) load_block(0, in[0]);
+  static_for<4>([&](auto BB) {
+    constexpr int b = decltype(BB)::value;
+    if constexpr (PIPE) { if (b + 1 < 4 && !(pre && b + 1 < PB)) load_block(b + 1, in[(b + 1) & 1]); }
+    else { if (!(pre && b < PB)) load_block(b, in[0]); }
+    constexpr int h = b >> 1, i = b & 1;
     const long row = row_of(b);
     const bool ok = row < (long)p.M;
 #pragma unroll
@@ -447,20 +488,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* A_, const
       }
       const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
       if (ok) {
-        epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds);
+        bool done = false;         // (no struct copy / select here: a copied EpiIn8 ends up in scratch memory)
+        if constexpr (b < PB) { if (pre) { epi_out8<EPI>(p, v, bias8[q], pin[b][q], row, col, lut_lds); done = true; } }
+        if (!done) epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds);
         if (epi_is_dgelu(EPI)) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
         }
       }
     }
-  }
+  });
   if constexpr (NF & 1) {      // the odd last fragment: 4 columns per lane, after all paired stores
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    static_for<4>([&](auto BB) {
+      constexpr int b = decltype(BB)::value;
       const long row = row_of(b);
-      if (row < (long)p.M) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, n0 + wc * WN + (NF - 1) * 16 + rho * 4);
-    }
+      if (row < (long)p.M) {
+        const long col = n0 + wc * WN + (NF - 1) * 16 + rho * 4;
+        bool done = false;
+        if constexpr (b < PB) { if (pre) { epi_out4<EPI>(p, acc[b >> 1][b & 1][NF - 1], pin4[b], row, col); done = true; } }
+        if (!done) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, col);
+      }
+    });
   }
   if (DBG == 9) {
     rt[3] = __builtin_amdgcn_s_memrealtime();                  // every store of this wave issued
@@ -506,6 +554,7 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
   }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = p.N / (96 * NPN);
   p.gelu_lut = g_pp_gelu_lut;
+  p.epi_prefetch = g_pp_epi_prefetch;
   p.pp_xr = 0; p.pp_bc = 1;
   if (!AT && g_pp_xcd_rect) {
     // XCD rectangles: the partition xr x (8 / xr) of the tile grid whose rectangles stage the fewest operand rows (R x 256 of A plus
@@ -542,9 +591,23 @@ int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
 
 }  // namespace
 
+int gemm_pp_init_device(int device) {
+  if (device < 0 || device >= 16) return set_error(CAREL_ERR_ARG, "carel_init: device index %d out of range", device);
+  if (g_lut_state[device].load(std::memory_order_acquire) == 1) return CAREL_OK;
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_init: hipGetDevice failed");
+  if (cur != device && hipSetDevice(device) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_init: hipSetDevice(%d) failed", device);
+  hipLaunchKernelGGL(gelu_lut_fill_kernel, dim3((LUT_WORDS + 255) / 256), dim3(256), 0, 0);
+  const hipError_t e = hipDeviceSynchronize();
+  if (cur != device) (void)hipSetDevice(cur);
+  if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_init: GELU table fill failed: %s", hipGetErrorString(e));
+  g_lut_state[device].store(1, std::memory_order_release);     // two racing initialisers both fill the same values: harmless
+  return CAREL_OK;
+}
 void gemm_pp_wide_variant(int on) { g_pp_wide = on ? 1 : 0; }
 void gemm_pp_xcd_rect(int on) { g_pp_xcd_rect = on ? 1 : 0; }
 void gemm_pp_gelu_lut(int on) { g_pp_gelu_lut = on ? 1 : 0; }
+void gemm_pp_epi_prefetch(int on) { g_pp_epi_prefetch = on ? 1 : 0; }
 static int g_pp_force_npn = 0;     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
 void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
 

@@ -33,7 +33,11 @@ extern "C" {
 #define CAREL_ABI_VERSION 4
 
 int carel_abi_version(void);
-/* Checks that `device` is a gfx950 part and records nothing else.  ref: `model.to(device)` :932 */
+/* Checks that `device` is a gfx950 part and fills the library's only per-device state, immutable afterwards: the 20-KiB GELU table of
+ * the fused FFN1 epilogue (one small kernel + one hipDeviceSynchronize -- the ONLY host synchronisation in the library; no other call
+ * synchronises).  Must be called once per device per process before the first carel_gemm_bf16 / carel_encoder_* call on it (those
+ * fail with CAREL_ERR_ARG otherwise); calling it again is a no-op.  The host mirror does it when a model is moved to the device
+ * (carel_vae_amd._lib.ensure_init).  ref: `model.to(device)` :932 */
 int carel_init(int device);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* carel_last_error(void);

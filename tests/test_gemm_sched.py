@@ -54,3 +54,16 @@ def test_every_unit_is_two_dma_instructions_and_lds_fits():
 def test_committed_tables_match_generator():
     inc = os.path.join(ROOT, "carel_vae_amd", "csrc", "gemm_pp_sched.inc")
     assert open(inc).read() == G.header()
+
+
+def test_epilogue_input_loads_ride_behind_the_prologue_without_moving_any_retirement():
+    """gemm_pp.hip (round 3) requests its epilogue inputs between the prologue's DMA units and K tile 0's and widens the prologue wait and
+    tile 0's waits by their instruction count: instruction-level replay -- every unit retires at the same wait as without the loads,
+    and no wait of tile 0 retires a load (they get a K tile of flight)."""
+    for npn, st in G.WIDE_CONFIGS.items():
+        s = G.make(npn, st, None, True, 1)
+        for nk in (3, 4, 5, 6, 7, 12, 13, 36, 48):
+            if nk <= 2:
+                continue
+            for ne in (6, 12, 24):
+                assert G.first_tile_waits_target_prologue(s, nk, ne)

@@ -440,3 +440,49 @@ def test_wgrad_splits_helper_matches_what_the_kernels_accept():
                     gemm(dY, X, L.GEMM_TN, L.EPI_SLAB_F32, M, N, T, splits=s, out_f32=slabs)
                     if T <= 1664 and v != 1:
                         assert rel_err(slabs.sum(0), dY.double().t() @ X.double()) < TOL
+
+
+@pytest.mark.parametrize("M", [8192, 1000, 8000 - 37])
+def test_pp_epilogue_inputs_requested_before_the_main_loop_same_bits(M):
+    """Round 3: the ping-pong kernel requests the residual rows / saved gelu'(u) values of its epilogue right behind the prologue's DMA
+    units (all four row blocks at N = 768, two at N = 3072) and widens the counted vmcnt waits of K tile 0 by those loads
+    (tools/gemm_sched.py: first_tile_waits_target_prologue).  With the hook off (170) the inputs are loaded after the main loop as in
+    round 2: identical bits for every epilogue with inputs, at the production shapes and at ragged M (clamped rows, guard rows
+    untouched); each against fp64 as well.  Several launches per setting on fresh buffers: a wait that was widened one tile too long
+    would read a stale LDS stage in some of them."""
+    lib = L.load()
+    cases = [("out NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, 768, 768), ("ffn2 NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, 768, 3072),
+             ("ffn1 dgrad NN", L.GEMM_NN, L.EPI_ADD_F32, 768, 3072), ("qkv dgrad NN", L.GEMM_NN, L.EPI_ADD_F32, 768, 2304),
+             ("ffn2 dgrad NN", L.GEMM_NN, L.EPI_MUL_BF16, 3072, 768), ("ffn2 dgrad erf NN", L.GEMM_NN, L.EPI_DGELU_BF16, 3072, 768),
+             ("short K NT", L.GEMM_NT, L.EPI_BIAS_DROP_RESID, 768, 256)]
+    for name, form, epi, N, K in cases:
+        A = _rand((M, K), 1, 61).bfloat16()
+        B = (_rand((N, K), 0.05, 62) if form == L.GEMM_NT else _rand((K, N), 0.05, 62)).bfloat16()
+        bias, resid, aux = _rand((N,), 0.1, 63), _rand((M, N), 1, 64), _rand((M, N), 1.0, 65).bfloat16()
+        outs = {}
+        for hook in (171, 170):
+            L.check(lib.carel_gemm_set_variant(hook))
+            try:
+                with _variant(3, 1):
+                    for rep in range(3):
+                        of = torch.full((M + 8, N), 7.0, device="cuda")
+                        ob = torch.full((M + 8, N), 7.0, device="cuda", dtype=torch.bfloat16)
+                        kw = dict(out_f32=of, out_bf16=ob)
+                        if epi == L.EPI_BIAS_DROP_RESID: kw.update(bias=bias, resid=resid, drop=(9, 5, 3 * N, 0.1))
+                        elif epi == L.EPI_ADD_F32: kw.update(resid=resid)
+                        else: kw.update(aux=aux, colsum_part=torch.empty(((M + 127) // 128, N), device="cuda"))
+                        gemm(A, B, form, epi, M, N, K, **kw)
+                        o = of if epi in (L.EPI_BIAS_DROP_RESID, L.EPI_ADD_F32) else ob
+                        assert torch.equal(o[M:].float(), torch.full((8, N), 7.0, device="cuda")), (name, hook, "guard rows written")
+                        if (hook, 0) in outs:
+                            assert torch.equal(o[:M], outs[(hook, 0)]), (name, hook, rep)
+                        else:
+                            outs[(hook, 0)] = o[:M].clone()
+            finally:
+                L.check(lib.carel_gemm_set_variant(171))
+        assert torch.equal(outs[(171, 0)], outs[(170, 0)]), (name, float((outs[(171, 0)].float() - outs[(170, 0)].float()).abs().max()))
+        prod = A.double() @ (B.double().t() if form == L.GEMM_NT else B.double())
+        if epi == L.EPI_ADD_F32:
+            assert rel_err(outs[(171, 0)], prod + resid.double()) < TOL
+        elif epi == L.EPI_MUL_BF16:
+            assert rel_err(outs[(171, 0)], prod * aux.double()) < TOL_BF16

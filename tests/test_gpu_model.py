@@ -583,7 +583,10 @@ def test_bench_shape_backward_and_adam_vs_oracle(shape):
     torch.cuda.synchronize()
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     P1, out, grads = O.train_step({k: v.clone() for k, v in P.items()}, batch, 3, cfg, opt, O.AdamState(), eps_e, eps_c)
-    assert abs(float(loss) - float(out["loss"])) <= 1e-3 * abs(float(out["loss"]))
+    # (with two layers the total is a near-cancellation of its weighted terms -- -0.65 against a scale of ~100 -- so it is held on the
+    # terms' scale here, like every golden case; the 1e-3 on the total itself is asserted at 12 layers in the test above)
+    scale = sum(abs(WEIGHTS[k] * float(out[k])) for k in TERMS)
+    assert abs(float(loss) - float(out["loss"])) <= TOL_LOSS_OVER_SCALE * scale, (float(loss), float(out["loss"]), scale)
     worst = {}
     for k, gr in grads.items():
         assert k in got_grads, k

@@ -10,6 +10,8 @@ from carel_vae_amd import _lib as L
 from tests.gpu_util import gemm
 
 lib = L.load()
+for v in os.environ.get("VARIANTS", "").split(","):
+    if v: L.check(lib.carel_gemm_set_variant(int(v)))       # e.g. VARIANTS=170: epilogue inputs requested after the main loop (round 2)
 T = int(os.environ.get("T", 8192))
 NSETS = int(os.environ.get("NSETS", 12))
 shapes = [("fwd QKV   NT", L.GEMM_NT, L.EPI_BIAS_BF16, T, 2304, 768),
@@ -52,14 +54,16 @@ for name, form, epi, M, N, K in shapes:
         if part == "A": A = s[0]
         if part == "B": B = s[1]
         if part == "E": kw = s[2]
+        if part == "I": kw = dict(kw, resid=s[2]["resid"], aux=s[2]["aux"])                     # only the epilogue's INPUTS rotate
+        if part == "O": kw = dict(kw, out_bf16=s[2]["out_bf16"], out2_bf16=s[2]["out2_bf16"], out_f32=s[2]["out_f32"])   # only its OUTPUTS
         return lambda: gemm(A, B, form, epi, M, N, K, **kw)
     hot, cold = [], []
-    parts = {k: [] for k in "ABE"}
+    parts = {k: [] for k in "ABEIO"}
     for r in range(5):
         hot.append(timed(fns[:1])); cold.append(timed(fns))
         for k in parts: parts[k].append(timed([mk_part(s, k) for s in sets]))
     h, c = statistics.median(hot), statistics.median(cold)
-    extra = " | only A cold +%.1f, only B +%.1f, only epilogue buffers +%.1f" % tuple(statistics.median(parts[k]) - h for k in "ABE")
+    extra = " | only A cold +%.1f, only B +%.1f, only epilogue buffers +%.1f (inputs +%.1f, outputs +%.1f)" % tuple(statistics.median(parts[k]) - h for k in "ABEIO")
     tot["hot"] += h; tot["cold"] += c
     fl = 2.0 * M * N * K
     print("%-14s M=%5d N=%5d K=%5d | hot %6.1f us %5.0f TF | cold (%d sets) %6.1f us %5.0f TF | +%.1f us" % (name, M, N, K, h, fl / h / 1e6, NSETS, c, fl / c / 1e6, c - h) + extra, flush=True)

@@ -207,6 +207,42 @@ def check(s, nk):
     return True
 
 
+def first_tile_waits_target_prologue(s, nk=12, ne=12):
+    """gemm_pp.hip requests its epilogue's inputs (ne plain load instructions) between the prologue's DMA units and K tile 0's, and adds ne
+    to the prologue wait and to every counted wait of K tile 0.  vmcnt retires in issue order, so that is exact iff each of those waits
+    targets a unit issued in the PROLOGUE (older than the loads): then "everything but the newest w + ne instructions" still retires the
+    target and nothing newer.  Replayed here at instruction level: with the loads in the stream and the widened immediates, every unit is
+    retired by the same wait as without them (so RAW / WAR of check() carry over), and no wait of tile 0 retires a load."""
+    NP = s["NP"]
+    span = s["span"]
+    ev = program(s, nk)
+    w = wait_counts(s, nk)
+    first_read = next(k for k, e in enumerate(ev) if e[0] == "read")
+    stream = []            # instruction-level issue order: (kind, key); a unit is 2 instructions
+    retired_plain, retired_with = {}, {}
+    for with_loads in (False, True):
+        stream, retired = [], (retired_with if with_loads else retired_plain)
+        for k, e in enumerate(ev):
+            if k == first_read and with_loads:
+                stream += [("load", i) for i in range(ne)]
+            if e[0] == "issue":
+                stream += [("unit", (e[1], e[2]))] * 2
+            elif e[0] == "wait":
+                q = e[1]
+                n = w[q]
+                if n is None:
+                    continue
+                if with_loads and q < NP:
+                    n += ne
+                for item in stream[:max(0, len(stream) - n)]:
+                    retired.setdefault(item, q)
+    for key, q in retired_plain.items():
+        assert retired_with.get(key) == q, ("unit retires at a different wait with the input loads in flight", key, q, retired_with.get(key))
+    loads = [q for (kind, _), q in retired_with.items() if kind == "load"]
+    assert loads and min(loads) >= NP, ("a wait of tile 0 retires an input load", loads)
+    return True
+
+
 def describe(npn, stages, max_lead=None, wide=False, war=2):
     s = make(npn, stages, max_lead, wide, war)
     for nk in (4, 5, 6, 7, 12, 13, 36, 48):
