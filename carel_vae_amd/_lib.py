@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcarel_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CarelError(RuntimeError):
@@ -25,6 +25,14 @@ class GemmArgs(C.Structure):
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
                 ("drop_p", C.c_float), ("drop_row_map", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
                 ("colsum_a", C.c_void_p), ("colsum_part", C.c_void_p)]
+
+
+class GemmRowLnArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("lda", C.c_int64), ("ldb", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
+                ("bias", C.c_void_p), ("resid_f32", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("h_f32", C.c_void_p), ("x_f32", C.c_void_p), ("x_bf16", C.c_void_p), ("stats", C.c_void_p),
+                ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32), ("drop_p", C.c_float),
+                ("drop_row_map", C.c_void_p), ("w_packed", C.c_int32)]
 
 
 class MmdArgs(C.Structure):
@@ -182,6 +190,8 @@ SIGNATURES = {
     "carel_init": (C.c_int, [C.c_int]),
     "carel_last_error": (C.c_char_p, []),
     "carel_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "carel_gemm_rowln": (C.c_int, [C.POINTER(GemmRowLnArgs), C.c_void_p]),
+    "carel_gemm_rowln_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_gemm_wgrad_splits": (C.c_int32, [C.c_int32, C.c_int32, C.c_int64]),
     "carel_gemm_set_variant": (C.c_int, [C.c_int32]),
     "carel_profile_gemm": (C.c_int, [C.c_int32, C.c_int32]),

@@ -247,16 +247,37 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
       if ((rc = gather_rows(xa, la.ctx, a->cls_rows, (int)R, cxres, cctx, (hipStream_t)stream))) return rc;
       Actx = cctx; res1 = cxres; rmap = a->cls_orig_rows;
     }
+    // dense batches: linear + dropout + residual + LayerNorm as ONE kernel (gemm_rowln.hip: 32 complete rows per workgroup; the same bits
+    // as the GEMM followed by the stand-alone LayerNorm).  Packed ECPE batches and the [CLS]-only rows are too few rows to fill the chip
+    // with 32-row workgroups that each stream the whole weight matrix: they keep the two-kernel path.
+    const bool fuse_ln = gemm_rowln_wanted(R);
+    auto linear_ln = [&](const void* A, const void* W, int K, const void* bias, const void* resid, int site, const void* g, const void* bt,
+                         void* h, void* xf, void* xbf, void* st) -> int {
+      carel_gemm_rowln_args ra;
+      ra.A = A; ra.W = W; ra.lda = K; ra.ldb = K; ra.M = (int)R; ra.K = K; ra.bias = bias; ra.resid_f32 = resid; ra.gamma = g; ra.beta = bt; ra.eps = a->ln_eps;
+      ra.h_f32 = h; ra.x_f32 = xf; ra.x_bf16 = xbf; ra.stats = st;
+      ra.w_packed = 0;
+      ra.drop_seed = a->drop_seed; ra.drop_site = (uint32_t)site; ra.drop_idx_offset = hoff; ra.drop_p = a->hidden_dropout; ra.drop_row_map = rmap;
+      return carel_gemm_rowln(&ra, stream);
+    };
+    if (fuse_ln) {
+      if ((rc = linear_ln(Actx, w.out_w, EH, w.out_b, res1, 2 + 3 * i, w.ln1_g, w.ln1_b, a->inference ? nullptr : la.h1, xb, la.x1_bf16, la.st1))) return rc;
+    } else {
     if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
                         w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
     if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
+    }
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, a->inference ? nullptr : la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains | fixed))) return rc;
-    if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
     char* next_bf16 = nullptr;
     if (i + 1 < a->n_layers) next_bf16 = layer_act(l, base, i + 1, a->inference).xin_bf16 + (size_t)r0 * EH * 2;
+    if (fuse_ln && gemm_rowln_wanted_k(EI)) {
+      if ((rc = linear_ln(la.g, w.ffn2_w, EI, w.ffn2_b, xb, 3 + 3 * i, w.ln2_g, w.ln2_b, a->inference ? nullptr : la.h2, xa, next_bf16, la.st2))) return rc;
+    } else {
+    if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
+                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
     if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, xa, next_bf16, la.st2, stream))) return rc;
+    }
   }
   return CAREL_OK;
 }

@@ -663,6 +663,36 @@ static int gemm_shape_ok(int M, int N, int K, int splits, int form) {
   return 1;
 }
 
+// tuning hook (carel_gemm_set_variant(190 + m)): 0 = never fuse LayerNorm into the 768-wide linears (default: measured), 1 = out-projection and FFN2,
+// 2 = out-projection only
+static int g_rowln_mode = 0;
+static long g_rowln_min_rows = 6144;        // 192 workgroups of 32 rows: below that the chip is not filled
+namespace carel {
+int gemm_rowln_wanted(long rows) { return g_rowln_mode != 0 && rows >= g_rowln_min_rows; }
+int gemm_rowln_wanted_k(int K) { return g_rowln_mode == 1 || K <= 768; }
+}
+extern "C" int carel_gemm_rowln(const carel_gemm_rowln_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a) return set_error(CAREL_ERR_ARG, "carel_gemm_rowln: null args");
+  if (a->M < 1 || a->K < 128 || (a->K & 127)) return set_error(CAREL_ERR_SHAPE, "carel_gemm_rowln: M >= 1 and K a multiple of 128 (M=%d K=%d)", a->M, a->K);
+  if (!a->A || !a->W || !a->resid_f32 || !a->gamma || !a->beta) return set_error(CAREL_ERR_ARG, "carel_gemm_rowln: null operand");
+  if ((((uintptr_t)a->A | (uintptr_t)a->W | (uintptr_t)a->resid_f32 | (uintptr_t)a->gamma | (uintptr_t)a->beta | (uintptr_t)a->bias | (uintptr_t)a->h_f32 |
+        (uintptr_t)a->x_f32 | (uintptr_t)a->x_bf16) & 15) || (a->lda & 7) || a->lda < a->K || (!a->w_packed && ((a->ldb & 7) || a->ldb < a->K)))
+    return set_error(CAREL_ERR_ARG, "carel_gemm_rowln: operands must be 16-byte aligned, leading dimensions multiples of 8 and >= K");
+  RowLnParams p;
+  p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W; p.ldb = a->ldb; p.bias = (const float*)a->bias; p.resid = (const float*)a->resid_f32;
+  p.gamma = (const float*)a->gamma; p.beta = (const float*)a->beta; p.eps = a->eps;
+  p.h_out = (float*)a->h_f32; p.x_f32 = (float*)a->x_f32; p.x_bf16 = (bf16_t*)a->x_bf16; p.stats = (float*)a->stats; p.M = a->M; p.K = a->K;
+  p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset); p.drop_row_map = (const int*)a->drop_row_map;
+  ProfScope prof_scope(stream, 2.0 * (double)a->M * 768.0 * (double)a->K);
+  return gemm_rowln_launch(p, a->w_packed != 0, stream);
+}
+extern "C" int carel_gemm_rowln_pack(const void* W, int64_t ldb, int32_t K, void* out, void* stream) {
+  if (!W || !out || K < 128 || (K & 127) || ldb < K || (ldb & 7) || (((uintptr_t)W | (uintptr_t)out) & 15))
+    return set_error(CAREL_ERR_ARG, "carel_gemm_rowln_pack: bad arguments (K multiple of 128, ldb >= K multiple of 8, 16-byte aligned pointers)");
+  return gemm_rowln_pack(W, (long)ldb, K, out, (hipStream_t)stream);
+}
+
 extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
   if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
@@ -673,6 +703,8 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 130 || v == 131) { g_auto_split_min_k = v == 130 ? 1536 : 768; return CAREL_OK; }
   if (v == 140 || v == 141) { g_pp_split = v - 140; return CAREL_OK; }
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
+  if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
+  if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
   if (v == 170 || v == 171) { gemm_pp_epi_prefetch(v - 170); return CAREL_OK; }       // ping-pong kernel: epilogue inputs requested before the main loop off / on
   if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles
   if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
@@ -692,7 +724,7 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
   if (!a->A || !a->B) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: null operand");
   if (((uintptr_t)a->A | (uintptr_t)a->B) & 15 || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3))
     return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: operands must be 16-byte aligned, ld multiples of 8");
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.lda = a->lda; p.ldb = a->ldb;
   p.M = a->M; p.N = a->N; p.K = a->K / splits;
   p.out0 = (bf16_t*)a->out_bf16; p.out1 = (bf16_t*)a->out2_bf16; p.outf = (float*)a->out_f32; p.ldc = a->ldc;

@@ -231,7 +231,7 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
       }
       gq = pack8(u); dq = pack8(d);
     }
-    *(uint4*)(p.out0 + off) = dq;
+    *(uint4*)(p.out0 + off) = dq;       // (a streaming / non-temporal store of this backward-only output: measured, no effect -- tools/bench_gemm_chain.py)
     *(uint4*)(p.out1 + off) = gq;
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     const float4 r0 = in.r0, r1 = in.r1;
@@ -274,6 +274,23 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long r
   epi_in8<EPI>(p, row, col, in);
   epi_out8<EPI>(p, v, b, in, row, col);
 }
+
+// gemm_rowln.hip: 32-row x 768-column workgroups, GEMM + bias + dropout + residual + LayerNorm in one kernel
+struct RowLnParams {
+  const bf16_t* A; long lda;          // [M, K] row-major activations
+  const bf16_t* W; long ldb;          // [768, K] row-major weight (nn.Linear layout)
+  const float* bias;                  // [768]
+  const float* resid;                 // [M, 768] f32
+  const float* gamma; const float* beta; float eps;
+  float* h_out;                       // [M, 768] f32: dropout(A W^T + bias) + resid (what LayerNorm's backward reads); may be null
+  float* x_f32; bf16_t* x_bf16;       // LayerNorm output (either may be null)
+  float* stats;                       // [M, 2] mean, rstd; may be null
+  int M, K;
+  Dropout drop; const int* drop_row_map;
+};
+int gemm_rowln_launch(const RowLnParams& p, bool packed, hipStream_t s);
+int gemm_rowln_pack(const void* W, long ldb, int K, void* out, hipStream_t s);
+void gemm_rowln_dbg(int d);
 
 // gemm_pp.hip: the 256 x (96 * npn) ping-pong kernel for the NT / NN forms.  gemm_pp_pick returns npn (1..3) if the kernel
 // should run this problem, 0 otherwise; force = 1: whenever the shape allows, force = -n: grids of at least n tiles.

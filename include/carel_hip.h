@@ -30,7 +30,7 @@ extern "C" {
 #define CAREL_ERR_HIP (-3)    /* a HIP runtime call or launch failed    */
 
 /* ABI version of this header; carel_abi_version() must return the same number. */
-#define CAREL_ABI_VERSION 4
+#define CAREL_ABI_VERSION 5
 
 int carel_abi_version(void);
 /* Checks that `device` is a gfx950 part and fills the library's only per-device state, immutable afterwards: the 20-KiB GELU table of
@@ -126,6 +126,41 @@ int carel_profile_gemm_read(double* total_ms, double* total_flops, int64_t* laun
 /* the two calibration medians of the last read-out, us: an event pair around an empty kernel (what _read subtracts from every
  * bracket), and an event pair with nothing in between */
 int carel_profile_gemm_overheads(double* empty_kernel_bracket_us, double* event_pair_us);
+/* ------------------------------------------------------------------------------------------------
+ * Row-band GEMM with the sub-layer tail fused (ABI 5):
+ *     h = dropout(A W^T + bias) + resid ;  x = LayerNorm(h) * gamma + beta        for 768-wide outputs
+ * Replaces nn.Linear + nn.Dropout + residual add + nn.LayerNorm of HF BertSelfOutput / BertOutput (reached from
+ * drl_classifier_ec_mmd_final_mul.py:202-206) in ONE kernel: each workgroup owns 32 complete rows, so the pre-LayerNorm sum never
+ * makes a round trip through memory.  Bit-identical to carel_gemm_bf16(CAREL_EPI_BIAS_DROP_RESID) followed by carel_layernorm_fwd.
+ * Every workgroup streams the whole weight matrix from L2, so it pays only when M / 32 workgroups fill the chip (M >= ~6000 rows);
+ * the encoder uses it for dense batches and keeps the two-kernel path for packed ECPE batches.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_gemm_rowln_args {
+  const void* A;          /* bf16 [M, K], leading dimension lda (elements, multiple of 8) */
+  const void* W;          /* bf16 [768, K] (nn.Linear weight), leading dimension ldb; or, with w_packed = 1, the same matrix in the
+                             MFMA-operand order written by carel_gemm_rowln_pack (768 * K elements, ldb ignored): the weight stream is
+                             then contiguous per load instruction -- 3-4x the rate of the row-major layout */
+  int64_t lda, ldb;
+  int32_t M, K;           /* any M >= 1; K multiple of 128 */
+  const void* bias;       /* f32 [768] or NULL */
+  const void* resid_f32;  /* f32 [M, 768] */
+  const void* gamma;      /* f32 [768] */
+  const void* beta;       /* f32 [768] */
+  float eps;
+  void* h_f32;            /* out f32 [M, 768]: the pre-LayerNorm sum (what carel_layernorm_bwd reads), or NULL */
+  void* x_f32;            /* out f32 [M, 768] or NULL */
+  void* x_bf16;           /* out bf16 [M, 768] or NULL */
+  void* stats;            /* out f32 [M, 2] (mean, rstd) or NULL */
+  uint32_t drop_seed, drop_site, drop_idx_offset;
+  float drop_p;
+  const void* drop_row_map; /* optional int32 [M], as in carel_gemm_args */
+  int32_t w_packed;       /* 0: W row-major; 1: W packed by carel_gemm_rowln_pack */
+} carel_gemm_rowln_args;
+int carel_gemm_rowln(const carel_gemm_rowln_args* args, void* stream);
+/* out[768 * K] = W[768, K] (leading dimension ldb) re-ordered as [n / 16][k / 64][(k / 32) % 2][(k / 8) % 4][n % 16][k % 8]: what a
+ * wave of carel_gemm_rowln loads per instruction is then one contiguous KiB.  Run it whenever the weight changes (after an optimiser step). */
+int carel_gemm_rowln_pack(const void* W, int64_t ldb, int32_t K, void* out, void* stream);
+
 /* out[n] (+)= sum_z slabs[z][n];  n multiple of 4 */
 int carel_slab_reduce_f32(const void* slabs, void* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
 

@@ -486,3 +486,62 @@ def test_pp_epilogue_inputs_requested_before_the_main_loop_same_bits(M):
             assert rel_err(outs[(171, 0)], prod + resid.double()) < TOL
         elif epi == L.EPI_MUL_BF16:
             assert rel_err(outs[(171, 0)], prod * aux.double()) < TOL_BF16
+
+
+def _rowln(A, W, bias, resid, gamma, beta, eps, M, K, drop=(0, 0, 0, 0.0), want_h=True, packed=False):
+    import ctypes as C
+    a = L.GemmRowLnArgs()
+    if packed:
+        Wp = torch.empty(768 * K, device="cuda", dtype=torch.bfloat16)
+        L.check(L.load().carel_gemm_rowln_pack(W.data_ptr(), K, K, Wp.data_ptr(), L.current_stream()), "carel_gemm_rowln_pack")
+        # the documented order: [n / 16][k / 64][(k / 32) % 2][(k / 8) % 4][n % 16][k % 8]
+        ref = W.view(48, 16, K // 64, 2, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(-1)
+        assert torch.equal(Wp.view(torch.int16), ref.view(torch.int16))
+        W = Wp
+    a.w_packed = 1 if packed else 0
+    a.A, a.W, a.lda, a.ldb, a.M, a.K = A.data_ptr(), W.data_ptr(), K, K, M, K
+    a.bias, a.resid_f32, a.gamma, a.beta, a.eps = bias.data_ptr(), resid.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps
+    out = dict(h=torch.full((M + 4, 768), 7.0, device="cuda"), xf=torch.full((M + 4, 768), 7.0, device="cuda"),
+               xb=torch.full((M + 4, 768), 7.0, device="cuda", dtype=torch.bfloat16), st=torch.full((M + 4, 2), 7.0, device="cuda"))
+    a.h_f32 = out["h"].data_ptr() if want_h else None
+    a.x_f32, a.x_bf16, a.stats = out["xf"].data_ptr(), out["xb"].data_ptr(), out["st"].data_ptr()
+    a.drop_seed, a.drop_site, a.drop_idx_offset, a.drop_p = drop
+    a.drop_row_map = None
+    L.check(L.load().carel_gemm_rowln(C.byref(a), L.current_stream()), "carel_gemm_rowln")
+    return out
+
+
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("M,K", [(8192, 768), (8192, 3072), (6144 + 32 * 3 + 5, 768), (256, 256), (128, 2304)])
+def test_rowln_equals_gemm_then_layernorm_bitwise(M, K, packed):
+    """gemm_rowln.hip (round 3): linear + bias + dropout + residual + LayerNorm with 32 complete rows per workgroup, against the
+    two-kernel path it replaces in the dense encoder -- carel_gemm_bf16(CAREL_EPI_BIAS_DROP_RESID) on the ping-pong / 128x128 kernel, then
+    carel_layernorm_fwd: the pre-LayerNorm sum, the normalised rows (f32 and bf16) and the row statistics must be identical BIT FOR BIT
+    (same MFMA sequence per accumulator, the epilogue expression of epi_out8, the lane map and summation tree of ln_fwd_kernel), with
+    dropout on, for the row-major weight and for the packed operand order of carel_gemm_rowln_pack (checked against its documented index map); ragged M (rows past M clamped on load, never stored: guard rows stay untouched), K = one chunk, several chunks, a short
+    last chunk; and against fp64."""
+    lib = L.load()
+    A = _rand((M, K), 1, 71).bfloat16()
+    W = _rand((768, K), 0.05, 72).bfloat16()
+    bias, resid = _rand((768,), 0.1, 73), _rand((M, 768), 1, 74)
+    gamma, beta = 1.0 + _rand((768,), 0.1, 75), _rand((768,), 0.1, 76)
+    drop = (9, 5, 3 * 768, 0.1)
+    got = _rowln(A, W, bias, resid, gamma, beta, 1e-12, M, K, drop, packed=packed)
+    h = torch.empty((M, 768), device="cuda")
+    gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, 768, K, out_f32=h, bias=bias, resid=resid, drop=drop)
+    xf, xb, st = torch.empty((M, 768), device="cuda"), torch.empty((M, 768), device="cuda", dtype=torch.bfloat16), torch.empty((M, 2), device="cuda")
+    L.check(lib.carel_layernorm_fwd(h.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-12, M, 768, xf.data_ptr(), xb.data_ptr(), st.data_ptr(),
+                                    L.current_stream()))
+    assert torch.equal(got["h"][:M], h), float((got["h"][:M] - h).abs().max())
+    assert torch.equal(got["xf"][:M], xf), float((got["xf"][:M] - xf).abs().max())
+    assert torch.equal(got["xb"][:M].view(torch.int16), xb.view(torch.int16))
+    assert torch.equal(got["st"][:M], st)
+    for k in ("h", "xf", "st"):
+        assert bool((got[k][M:] == 7.0).all()), k + ": guard rows written"
+    assert bool((got["xb"][M:].float() == 7.0).all())
+    # without dropout against fp64, and the optional h output switched off
+    got0 = _rowln(A, W, bias, resid, gamma, beta, 1e-12, M, K, want_h=False, packed=packed)
+    ref_h = A.double() @ W.double().t() + bias.double() + resid.double()
+    ref = torch.nn.functional.layer_norm(ref_h, (768,), gamma.double(), beta.double(), 1e-12)
+    assert rel_err(got0["xf"][:M], ref) < 2e-5
+    assert bool((got0["h"] == 7.0).all())
