@@ -10,6 +10,8 @@ namespace carel {
 
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+int slab_reduce_multi(const void* slabs, void* out, int64_t n, const void* slabs2, void* out2, int64_t n2, int splits, const void* partials,
+                      int nparts, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);   // gemm.hip: weight slabs + bias partials + LayerNorm partials in one launch
 int gemm_rowln_wanted(long rows);         // gemm.hip: should a 768-wide linear + LayerNorm of this many rows run as the fused row-band kernel?
 int gemm_rowln_wanted_k(int K);           // ... also for this contraction length (tuning hook: the K = 3072 form can be switched off alone)
 int gemm_pp_init_device(int device);      // gemm_pp.hip: fills the GELU table (carel_init)

@@ -154,7 +154,11 @@ int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, in
 
 // dW[M,N] = A^T[M x T] * B[T x N]  (A = dY [T,M], B = X [T,N])  via split-K slabs.  With db != null the bias gradient
 // db[M] = column sums of dY comes out of the same GEMM (ones-vector MFMA) as [splits][M] partials behind the slabs.
-int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs, void* dW, void* stream, void* db = nullptr) {
+// lnp != null: the partials of the LayerNorm backward that produced dY are summed (-> dgamma, dbeta, dbias) by the SAME launch that reduces
+// the slabs (they are independent of the GEMM; one launch instead of three behind every weight gradient).
+struct LnPartials { const void* partials; long rows; void* dgamma; void* dbeta; void* dbias; };
+int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs, void* dW, void* stream, void* db = nullptr,
+               const LnPartials* lnp = nullptr) {
   const int splits = wgrad_splits(T, M, N);
   carel_gemm_args g;
   g.A = dY; g.B = X; g.lda = M; g.ldb = N; g.ldc = N; g.M = M; g.N = N; g.K = (int)T; g.form = CAREL_GEMM_TN; g.epilogue = CAREL_EPI_SLAB_F32;
@@ -166,13 +170,15 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
   if (splits == 1) {                 // one slab IS the result: write it (and the bias sums) in place, nothing to reduce
     g.out_f32 = dW;
     if (db) g.colsum_a = db;
-    return carel_gemm_bf16(&g, stream);
+    int rc = carel_gemm_bf16(&g, stream);
+    if (!rc && lnp) rc = layernorm_bwd_reduce(lnp->partials, lnp->rows, lnp->dgamma, lnp->dbeta, lnp->dbias, (hipStream_t)stream);
+    return rc;
   }
   int rc = carel_gemm_bf16(&g, stream);
   if (rc) return rc;
-  if ((rc = carel_slab_reduce_f32(slabs, dW, (int64_t)M * N, splits, 0, stream))) return rc;
-  if (db) rc = carel_slab_reduce_f32(cs, db, M, splits, 0, stream);
-  return rc;
+  return slab_reduce_multi(slabs, dW, (int64_t)M * N, cs, db, M, splits, lnp ? lnp->partials : nullptr,
+                           lnp ? carel_layernorm_bwd_blocks(lnp->rows) : 0, lnp ? lnp->dgamma : nullptr, lnp ? lnp->dbeta : nullptr,
+                           lnp ? lnp->dbias : nullptr, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -373,8 +379,8 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
   if ((rc = fork())) return rc;
-  if ((rc = layernorm_bwd_reduce(s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b, (hipStream_t)wstream))) return rc;
-  if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream))) return rc;
+  const LnPartials lp2{s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b};
+  if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream, nullptr, &lp2))) return rc;
   if ((rc = group_done(0)) || (rc = wait_group(1))) return rc;
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_MUL_BF16, 1, s.du, nullptr, nullptr, nullptr,
                       nullptr, la.u, 0, 0, 0, 0.f, stream, nullptr))) return rc;
@@ -392,8 +398,8 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
   void* dctx_rows = cls_only ? (void*)s.dqkv : (void*)s.dctx;     // compact result parks in the (still free) dqkv buffer
   if ((rc = fork())) return rc;
-  if ((rc = layernorm_bwd_reduce(s.part3, R, g.ln1_g, g.ln1_b, g.out_b, (hipStream_t)wstream))) return rc;
-  if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream))) return rc;
+  const LnPartials lp1{s.part3, R, g.ln1_g, g.ln1_b, g.out_b};
+  if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream, nullptr, &lp1))) return rc;
   if ((rc = group_done(2))) return rc;
   if (cls_only && (rc = wait_group(3))) return rc;             // the compact result parks in dqkv
   if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,

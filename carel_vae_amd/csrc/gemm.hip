@@ -13,6 +13,7 @@
 // The MFMA is issued with the operands swapped (a = B fragment, b = A fragment) so that each lane's 4
 // accumulator registers are 4 CONSECUTIVE columns of one C row -> 8/16-byte epilogue accesses.
 #include "gemm_epilogue.h"
+#include "reduce_device.h"
 
 namespace carel {
 
@@ -517,10 +518,9 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
 }
 
 // Sum `splits` fp32 slabs [splits][n] -> out[n] (+ optional accumulate into out)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits,
-                                   int accumulate) {
+__device__ __forceinline__ void slab_reduce_segment(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate, int nblk) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const long stride = (long)gridDim.x * blockDim.x * 4;
+  const long stride = (long)nblk * blockDim.x * 4;
   for (; i < n; i += stride) {
     float4 a = *(const float4*)(slabs + i);
     int z = 1;
@@ -540,6 +540,29 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
       a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
     }
     *(float4*)(out + i) = a;
+  }
+}
+// One launch reduces up to three things (same order of additions as separate launches: same bits):
+//   the weight-gradient slabs [splits][n] -> out;
+//   slabs2 != null: a small [splits][n2] array -> out2 -- the bias-gradient partials the weight-gradient GEMM leaves behind its slabs
+//     (they used to cost a launch of their own: 24 launches of ~5 us per step);
+//   pc.partials != null: the blocks past `nblk` sum the per-block partials of a LayerNorm backward into dgamma, dbeta and the bias gradient
+//     (partial_reduce_seg_kernel of ln.hip: the same device function) -- 72 latency-bound blocks that used to be a launch of their own
+//     in front of every FFN2 / out-projection weight gradient (24 per step).
+struct PartCols { const float* partials; SegOuts outs; int seg, n, nparts; };
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate,
+                                                          const float* __restrict__ slabs2, float* __restrict__ out2, long n2, int nblk, PartCols pc) {
+  __shared__ float lds[256];
+  if ((int)blockIdx.x < nblk) {
+    slab_reduce_segment(slabs, out, n, splits, accumulate, nblk);
+    if (slabs2) slab_reduce_segment(slabs2, out2, n2, splits, 0, nblk);
+    return;
+  }
+  int c;
+  const float t = partial_colsum16(pc.partials, pc.n, pc.nparts, lds, c, (int)blockIdx.x - nblk);
+  if (threadIdx.x < PR_COLS && c < pc.n) {
+    float* o = pc.outs.p[c / pc.seg];
+    if (o) o[c % pc.seg] = t;
   }
 }
 
@@ -820,6 +843,26 @@ extern "C" int carel_slab_reduce_f32(const void* slabs, void* out, long n, int s
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)slabs,
-                     (float*)out, n, splits, accumulate);
+                     (float*)out, n, splits, accumulate, (const float*)nullptr, (float*)nullptr, 0L, (int)blocks, PartCols{});
   return check_launch("slab_reduce_kernel");
+}
+namespace carel {
+// out[n] = sum_z slabs[z][n], optionally out2[n2] = sum_z slabs2[z][n2] (slabs2 may be null) and optionally the column sums of LayerNorm-backward
+// partials [nparts][3 * 768] -> (dgamma, dbeta, dbias) (partials may be null), all in ONE launch
+int slab_reduce_multi(const void* slabs, void* out, int64_t n, const void* slabs2, void* out2, int64_t n2, int splits, const void* partials,
+                      int nparts, void* dgamma, void* dbeta, void* dbias, hipStream_t stream) {
+  if (!slabs || !out || n <= 0 || (n & 3) || splits < 1 || (slabs2 && (!out2 || n2 <= 0 || (n2 & 3)))) return set_error(CAREL_ERR_ARG, "slab_reduce_multi: bad arguments");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  PartCols pc{};
+  int extra = 0;
+  if (partials) {
+    pc.partials = (const float*)partials; pc.outs.p[0] = (float*)dgamma; pc.outs.p[1] = (float*)dbeta; pc.outs.p[2] = (float*)dbias; pc.outs.p[3] = nullptr;
+    pc.seg = 768; pc.n = 3 * 768; pc.nparts = nparts;
+    extra = (3 * 768 + PR_COLS - 1) / PR_COLS;
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, stream, (const float*)slabs, (float*)out, (long)n, splits, 0,
+                     (const float*)slabs2, (float*)out2, (long)n2, (int)blocks, pc);
+  return check_launch("slab_reduce_kernel");
+}
 }

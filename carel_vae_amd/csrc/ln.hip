@@ -5,6 +5,7 @@
 // Reached from drl_classifier_ec_mmd_final_mul.py:202-206 (forward) and :841 (backward).
 #include "carel_hip_internal.h"
 #include "ln_device.h"
+#include "reduce_device.h"
 
 namespace carel {
 
@@ -286,47 +287,20 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
   if (a.type_vocab > 1) write_partials(lds, accT1, dst + 3 * H, lane, wave);
 }
 
-// out[c] (+)= sum_p partials[p][c]   (c < n, p < nparts): 16 columns x 16 row-lanes per block, fixed order
-// Column sums of partials [nparts][n]: PR_COLS columns x 8 part-lanes per block (128-byte segments, four loads in
-// flight per thread), fixed summation order.  Returns the sum in the threads of part-lane 0; c = column.
-constexpr int PR_COLS = 32;
-__device__ __forceinline__ float partial_colsum16(const float* __restrict__ partials, int n, int nparts, float* lds, int& c) {
-  const int cl = threadIdx.x & (PR_COLS - 1), rl = threadIdx.x / PR_COLS;      // rl in [0, 8)
-  c = blockIdx.x * PR_COLS + cl;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (c < n) {
-    int p = rl;
-    for (; p + 24 < nparts; p += 32) {
-      s0 += partials[(long)p * n + c]; s1 += partials[(long)(p + 8) * n + c];
-      s2 += partials[(long)(p + 16) * n + c]; s3 += partials[(long)(p + 24) * n + c];
-    }
-    for (; p < nparts; p += 8) s0 += partials[(long)p * n + c];
-  }
-  lds[threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  float t = 0.f;
-  if (rl == 0) {
-#pragma unroll
-    for (int r = 0; r < 256 / PR_COLS; ++r) t += lds[r * PR_COLS + cl];
-  }
-  return t;
-}
-
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
                                                              int n, int nparts, int accumulate) {
   __shared__ float lds[256];
   int c;
-  const float t = partial_colsum16(partials, n, nparts, lds, c);
+  const float t = partial_colsum16(partials, n, nparts, lds, c, (int)blockIdx.x);
   if (threadIdx.x < PR_COLS && c < n) out[c] = accumulate ? out[c] + t : t;
 }
 
 // same reduction, but column c goes to outs.p[c / seg][c % seg] (null pointers are skipped)
-struct SegOuts { float* p[4]; };
 __global__ __launch_bounds__(256) void partial_reduce_seg_kernel(const float* __restrict__ partials, SegOuts outs, int seg,
                                                                  int n, int nparts) {
   __shared__ float lds[256];
   int c;
-  const float t = partial_colsum16(partials, n, nparts, lds, c);
+  const float t = partial_colsum16(partials, n, nparts, lds, c, (int)blockIdx.x);
   if (threadIdx.x < PR_COLS && c < n) {
     float* o = outs.p[c / seg];
     if (o) o[c % seg] = t;
