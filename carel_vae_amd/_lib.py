@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcarel_hip.so")
+LIB_PATH = os.environ.get("CAREL_HIP_LIB") or os.path.join(_HERE, "libcarel_hip.so")     # CAREL_HIP_LIB: an experiment build (tools/ablate_*.sh, tools/ab_lib.sh)
 ABI_VERSION = 5
 
 
@@ -261,7 +261,7 @@ SIGNATURES = {
     "carel_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "carel_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "carel_relpos_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "carel_relpos_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "carel_relpos_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 _lib = None

@@ -12,7 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "libcarel_hip.so")
+# CAREL_BUILD_TAG=<tag>: an experiment build (ablation flags via CAREL_EXTRA_FLAGS) goes to libcarel_hip_<tag>.so with its own object
+# directory and never touches the product library; load it with CAREL_HIP_LIB=<path> (carel_vae_amd/_lib.py).
+TAG = os.environ.get("CAREL_BUILD_TAG", "")
+LIB = os.path.join(HERE, "libcarel_hip%s.so" % ("_" + TAG if TAG else ""))
+OBJDIR = os.path.join(CSRC, ".obj_" + TAG) if TAG else CSRC
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("CAREL_EXTRA_FLAGS", "").split()
@@ -33,7 +37,7 @@ def _headers_mtime():
 
 
 def _compile(src, force):
-    obj = os.path.join(CSRC, src[:-4] + ".o")
+    obj = os.path.join(OBJDIR, src[:-4] + ".o")
     srcp = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _headers_mtime())):
@@ -51,7 +55,7 @@ def _flags_changed():
     """The object cache is keyed on the compile flags too (an ablation build with CAREL_EXTRA_FLAGS must not survive into a normal
     build: ADVICE r02): a stamp file holds the flags of the objects on disk."""
     import hashlib
-    stamp = os.path.join(CSRC, ".flags_stamp")
+    stamp = os.path.join(OBJDIR, ".flags_stamp")
     h = hashlib.sha1(" ".join(FLAGS + [k + ":" + " ".join(v) for k, v in sorted(FILE_FLAGS.items())]).encode()).hexdigest()
     try:
         old = open(stamp).read().strip()
@@ -59,11 +63,12 @@ def _flags_changed():
         old = None
     if old != h:
         open(stamp, "w").write(h + "\n")
-        return old is not None or any(f.endswith(".o") for f in os.listdir(CSRC))
+        return old is not None or any(f.endswith(".o") for f in os.listdir(OBJDIR))
     return False
 
 
 def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
     force = _flags_changed() or force
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:

@@ -102,7 +102,8 @@ struct AttnParams {
   Dropout drop;             // element index ((b*NH + h)*S + q)*S + k
   const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
   const float* rel;         // MPNet relative-position bias by distance: [NH][256], entry 127 + (key - query); null = none
-  float* drel;              // bwd: its gradient, accumulated with atomics by every (sample, head, layer); same layout
+  float* drel;              // bwd: its gradient by distance, [B * NH][256]: row (sample, head) is read-modify-written by that workgroup alone (every
+                            // layer adds to it in stream order) -- no atomics anywhere, so the table gradient is bit-reproducible
 };
 
 #ifndef CAREL_ATTN_ABLATE
@@ -110,7 +111,7 @@ struct AttnParams {
 #endif
 constexpr float MASK_NEG = -3.4028234663852886e38f;   // torch.finfo(float32).min, as HF adds it
 constexpr int ATTN_BWD_LDS = 16384 + 16384 + 32768 + 1024;
-constexpr int ATTN_BWD_LDS_REL = ATTN_BWD_LDS + 2048;     // + bias by distance [256] + its gradient [256]
+constexpr int ATTN_BWD_LDS_REL = ATTN_BWD_LDS + 1024 + 4096;     // + bias by distance [256] + its gradient, one array per wave [4][256]
 
 // =========================================================================================== forward
 // REL: scores += rel[h][127 + key - query] (transformers MPNetAttention: `attention_scores += position_bias`, the bias shared by all
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   char* dsimg = smem + 32768;        // dS^T [k][q] bf16, 256-B rows
   float* lse = (float*)(smem + 65536);
   float* delta = lse + 128;
-  float* relb = (float*)(smem + ATTN_BWD_LDS);                  // REL: bias by distance, and the sums of dS over this (sample, head)
-  float* relg = relb + 256;
+  float* relb = (float*)(smem + ATTN_BWD_LDS);                  // REL: bias by distance, and the sums of dS by distance, one private array per wave
+  float* relg = relb + 256;                                     // [4][256]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / NH, h = blockIdx.x - b * NH;
   const int S = p.S;
@@ -253,7 +254,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   const bf16_t* obase = p.ctx + row0 * HID + h * HD;
   stage_att(qbase, QKV_LD, rows, qimg);
   stage_att(dobase, HID, rows, doimg);
-  if (REL) { relb[threadIdx.x] = p.rel[h * 256 + threadIdx.x]; relg[threadIdx.x] = 0.f; }
+  if (REL) {
+    relb[threadIdx.x] = p.rel[h * 256 + threadIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) relg[w * 256 + threadIdx.x] = 0.f;
+  }
   for (int k = threadIdx.x; k < rows; k += 256) lse[k] = k < len ? p.lse[((long)b * NH + h) * S + k] : 0.f;
   {  // delta[q] = sum_d dO[q][d] * O[q][d]; 2 threads per query, 32 d each
     const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
@@ -334,9 +339,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         pd[r] = live ? pr * dm : 0.f;
         const float ds_raw = live ? pr * (dp[r] * dm - delta[q]) : 0.f;  // d loss / d score
         dsv[r] = ds_raw * 0.125f;                                        // includes the 1/sqrt(d) of the q.k part of the scores
-        // the bias enters the scores unscaled: its gradient is the plain sum of dS over the diagonal key - query (within one
-        // instruction the 32 keys of a half-wave hit 32 different addresses)
-        if (REL && live) atomicAdd(relg + 127 + key - q, ds_raw);
+        // the bias enters the scores unscaled: its gradient is the plain sum of dS over the diagonal key - query.  Deterministic: each wave
+        // adds into its OWN array, and the two half-waves (same keys, queries 4 apart: lane l of the upper half would hit the address
+        // of lane l - 4 of the lower) take turns, so no two lanes of one instruction share an address -- plain read-add-write in a
+        // fixed order instead of LDS atomics (every other gradient of this library is bit-reproducible)
+        if (REL) {
+          float* mine = relg + wave * 256 + 127 + key - q;
+          if (hh == 0 && live) *mine += ds_raw;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (hh == 1 && live) *mine += ds_raw;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
       }
       // dS^T[k][q] -> LDS (4 consecutive q per register group)
 #pragma unroll
@@ -358,9 +371,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   }
   if (CAREL_ATTN_ABLATE == 2) return;
   __syncthreads();                           // every wave: dO image dead, dS^T complete
-  if (REL && threadIdx.x < 255) {
-    const float g = relg[threadIdx.x];
-    if (g != 0.f) atomicAdd(p.drel + h * 256 + threadIdx.x, g);
+  if (REL && threadIdx.x < 255) {                 // the four waves' sums in a fixed order, onto this (sample, head)'s own row
+    const float g = ((relg[threadIdx.x] + relg[256 + threadIdx.x]) + relg[512 + threadIdx.x]) + relg[768 + threadIdx.x];
+    p.drel[((long)b * NH + h) * 256 + threadIdx.x] += g;
   }
   stage_att(qbase + HID, QKV_LD, rows, doimg);  // K image for the dQ phase
   // (dK, dV stay in registers until the very end: stored here, the vmcnt(0) below -- which the K image needs -- would also wait for
@@ -453,11 +466,19 @@ __global__ void relpos_expand_kernel(const float* table, const int* bucket, floa
   const int h = blockIdx.x, i = threadIdx.x;
   dist[h * 256 + i] = i < 255 ? table[bucket[i] * NH + h] : 0.f;
 }
-__global__ void relpos_reduce_kernel(const float* ddist, const int* bucket, float* dtable, int accumulate) {   // -> dtable [32][NH]
-  const int h = blockIdx.x, bkt = threadIdx.x;                                // 32 threads
+// ddist [batch * NH][256] (one row per (sample, head), see AttnParams.drel) -> dtable [32][NH]: samples in order, distances in order
+__global__ __launch_bounds__(256) void relpos_reduce_kernel(const float* ddist, int batch, const int* bucket, float* dtable, int accumulate) {
+  __shared__ float bydist[256];
+  const int h = blockIdx.x, i = threadIdx.x;
   float s = 0.f;
-  for (int i = 0; i < 255; ++i) if (bucket[i] == bkt) s += ddist[h * 256 + i];
-  dtable[bkt * NH + h] = accumulate ? dtable[bkt * NH + h] + s : s;
+  for (int b = 0; b < batch; ++b) s += ddist[((long)b * NH + h) * 256 + i];
+  bydist[i] = s;
+  __syncthreads();
+  if (i < 32) {
+    float t = 0.f;
+    for (int d = 0; d < 255; ++d) if (bucket[d] == i) t += bydist[d];
+    dtable[i * NH + h] = accumulate ? dtable[i * NH + h] + t : t;
+  }
 }
 }  // namespace carel
 
@@ -466,8 +487,8 @@ extern "C" int carel_relpos_expand(const void* table, const void* bucket, void* 
   hipLaunchKernelGGL(relpos_expand_kernel, dim3(NH), dim3(256), 0, (hipStream_t)stream, (const float*)table, (const int*)bucket, (float*)dist);
   return check_launch("relpos_expand_kernel");
 }
-extern "C" int carel_relpos_reduce(const void* ddist, const void* bucket, void* dtable, int32_t accumulate, void* stream) {
-  if (!ddist || !bucket || !dtable) return set_error(CAREL_ERR_ARG, "carel_relpos_reduce: null tensor");
-  hipLaunchKernelGGL(relpos_reduce_kernel, dim3(NH), dim3(32), 0, (hipStream_t)stream, (const float*)ddist, (const int*)bucket, (float*)dtable, (int)accumulate);
+extern "C" int carel_relpos_reduce(const void* ddist, int32_t batch, const void* bucket, void* dtable, int32_t accumulate, void* stream) {
+  if (!ddist || !bucket || !dtable || batch < 1) return set_error(CAREL_ERR_ARG, "carel_relpos_reduce: null tensor or batch < 1");
+  hipLaunchKernelGGL(relpos_reduce_kernel, dim3(NH), dim3(256), 0, (hipStream_t)stream, (const float*)ddist, (int)batch, (const int*)bucket, (float*)dtable, (int)accumulate);
   return check_launch("relpos_reduce_kernel");
 }

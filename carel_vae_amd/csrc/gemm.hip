@@ -458,7 +458,10 @@ template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
-    const int npn = gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60) ? 1 : -g_pp_min_tiles);
+    // (a shape only the ping-pong kernel takes -- M not a multiple of 128 -- runs on it whatever the tile-count threshold says:
+    // gemm_shape_ok accepted it on that kernel's account)
+    const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
+    const int npn = gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60 || only_pp) ? 1 : -g_pp_min_tiles);
 #ifdef CAREL_GEMM_ABLATE
     if (npn && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 61 && g_gemm_variant <= 69) return gemm_pp_launch_dbg(p, npn, g_gemm_variant - 60, s);
 #endif
@@ -831,7 +834,11 @@ namespace carel {
 // the largest factor carel_gemm_wgrad_splits can return for this shape under ANY tuning-hook setting (buffer sizing)
 int gemm_wgrad_splits_max(int M, int N, long T) {
   const int a = gemm_pp_wgrad_splits(M, N, T), b = wgrad_splits_128(M, N, T);
-  return a > b ? a : b;
+  // hook 100 + s may force up to min(16, K tiles / 4) slices on the ping-pong kernel AFTER the slab buffer was sized
+  const long nk4 = (T >> 6) / 4;
+  const int c = (M % 256 == 0 && N % 96 == 0 && T % 64 == 0 && T >= 512) ? (int)(nk4 < 16 ? nk4 : 16) : 0;
+  const int ab = a > b ? a : b;
+  return ab > c ? ab : c;
 }
 }  // namespace carel
 

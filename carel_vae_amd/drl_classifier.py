@@ -628,15 +628,16 @@ class DrlClassifier(nn.Module):
         a.d_word_emb, a.d_pos_emb, a.d_type_emb = self._g(e + "word_embeddings.weight"), self._g(e + "position_embeddings.weight"), self._g(e + "token_type_embeddings.weight")
         a.d_emb_ln_g, a.d_emb_ln_b = self._g(e + "LayerNorm.weight"), self._g(e + "LayerNorm.bias")
         if getattr(c, "rel_pos", False):
-            r = self._rel_buffers()
+            r = self._rel_buffers(int(a.batch))
             L.check(L.load().carel_relpos_expand(self._w(REL_KEY), r.bucket.data_ptr(), r.dist.data_ptr(), L.current_stream()), "carel_relpos_expand")
             a.rel_bias_dist, a.d_rel_bias_dist = r.dist.data_ptr(), r.ddist.data_ptr()
         return a
 
-    def _rel_buffers(self):
+    def _rel_buffers(self, batch=1):
         """MPNet relative positions: bucket[i] = relative_position_bucket(i - 127) with the expression of transformers
         MPNetEncoder.relative_position_bucket (num_buckets 32, max_distance 128), the bias by distance [12, 256] made from the
-        learned table before every forward, and the gradient by distance the attention backward kernels accumulate into."""
+        learned table before every forward, and the gradient by distance, one row per (sample, head), that the attention backward
+        kernels add into without atomics (bit-reproducible; carel_relpos_reduce sums the samples in order)."""
         r = getattr(self, "_rel", None)
         dev = self._flat.device
         if r is None or r.bucket.device != dev:
@@ -649,6 +650,8 @@ class DrlClassifier(nn.Module):
             r = self._rel = SimpleNamespace(bucket=ret.to(torch.int32).to(dev).contiguous(),
                                             dist=torch.zeros((NH, 256), device=dev, dtype=torch.float32),
                                             ddist=torch.zeros((NH, 256), device=dev, dtype=torch.float32))
+        if r.ddist.shape[0] < batch * NH:
+            r.ddist = torch.zeros((batch * NH, 256), device=dev, dtype=torch.float32)
         return r
 
     @staticmethod
@@ -842,9 +845,11 @@ class DrlClassifier(nn.Module):
             if self._adam_hook is not None and not accumulate and (self._dp is None or work is not None):
                 self._adam_hook._layer_ready(l, after=work)
 
-        rel = self._rel_buffers() if getattr(self.cfg, "rel_pos", False) else None
+        rel = self._rel_buffers(int(ea.batch)) if getattr(self.cfg, "rel_pos", False) else None
         if rel is not None:
-            rel.ddist.zero_()
+            if rel.ddist.data_ptr() != ea.d_rel_bias_dist:
+                raise L.CarelError("internal: the relative-position gradient buffer was re-allocated between forward and backward")
+            rel.ddist[:int(ea.batch) * NH].zero_()
         lag = 1 if self.overlap_wgrad else 0     # with the side stream a layer completes one call late (include/carel_hip.h)
         for l in range(self.cfg.layers - 1, -1, -1):
             L.check(lib.carel_encoder_backward_layer(C.byref(ea), l, st), "carel_encoder_backward_layer")
@@ -855,7 +860,7 @@ class DrlClassifier(nn.Module):
             layer_ready(0)
         L.check(lib.carel_encoder_backward_embeddings(C.byref(ea), st), "carel_encoder_backward_embeddings")
         if rel is not None:      # fold the gradient by distance (every layer's attention backward added to it) into the table's buckets
-            L.check(lib.carel_relpos_reduce(rel.ddist.data_ptr(), rel.bucket.data_ptr(), self._g(REL_KEY), 0, st), "carel_relpos_reduce")
+            L.check(lib.carel_relpos_reduce(rel.ddist.data_ptr(), int(ea.batch), rel.bucket.data_ptr(), self._g(REL_KEY), 0, st), "carel_relpos_reduce")
 
     def _bind_grads(self):
         if self._grad_views is None:

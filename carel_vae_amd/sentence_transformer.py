@@ -19,6 +19,15 @@ bias is added inside the attention kernels (csrc/attention.hip, REL instantiatio
 folded into the 32 buckets), the embeddings have no token types, and the sentence embedding is L2-normalised (models.Normalize);
 the MPNet encoder restatement in oracle/carel_oracle.py is pinned to the installed transformers MPNetModel
 (tests/test_oracle_triplet.py).
+
+Two known deviations from what the reference's scripts most likely ran (both PARITY UNPINNED, stated here because they cannot be checked):
+  * optimiser: fit() defaults to torch.optim.AdamW semantics -- eps 1e-8, decoupled decay applied BEFORE the update.  The 2.x releases of
+    sentence-transformers of the reference's era (09/2021) defaulted to transformers.AdamW: eps 1e-6 and decay applied AFTER the update.
+    `optimizer_params={"eps": 1e-6}` selects that epsilon; the decay order differs by a factor (1 - lr * wd) on the update of one step
+    (2e-7 relative at the default lr 2e-5, wd 0.01).
+  * sequence length: max_seq_length defaults to 128 because the attention kernels hold one (sample, head) per workgroup with S <= 128;
+    all-mpnet-base-v2 ships max_seq_length 384.  ECPE clauses are far shorter (p99 70-89 tokens); a sentence that IS longer
+    is truncated by the tokenizer, and tokenize() warns once when that happens instead of truncating silently.
 """
 import ctypes as C
 import math
@@ -182,6 +191,11 @@ class SentenceTransformer(nn.Module):
         rows = [self.tokenizer.encode_plus(t, None, add_special_tokens=True, max_length=self.max_seq_length, padding="max_length",
                                            return_token_type_ids=True, truncation=True, return_attention_mask=True, return_tensors="pt")
                 for t in texts]
+        if not getattr(self, "_warned_truncation", False) and any(int(r["attention_mask"].sum()) >= self.max_seq_length for r in rows):
+            import warnings
+            warnings.warn("SentenceTransformer.tokenize: a sentence fills all %d positions and was probably truncated (the attention kernels "
+                          "cap the sequence at 128 tokens; all-mpnet-base-v2 itself allows 384)" % self.max_seq_length)
+            self._warned_truncation = True
         cat = lambda k: torch.cat([r[k].reshape(1, -1).to(torch.long) for r in rows], 0)
         return {"input_ids": cat("input_ids"), "attention_mask": cat("attention_mask"), "token_type_ids": cat("token_type_ids")}
 
@@ -317,6 +331,8 @@ class SentenceTransformer(nn.Module):
                 loader.collate_fn = self.smart_batching_collate
             except Exception:
                 pass
+        # optimizer_params: lr (2e-5) and eps (1e-8 = torch.optim.AdamW; the sentence-transformers 2.x default optimiser, transformers.AdamW,
+        # used 1e-6 -- module docstring)
         lr = float((optimizer_params or {}).get("lr", 2e-5))
         if steps_per_epoch is None:
             steps_per_epoch = len(loader)

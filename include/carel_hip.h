@@ -248,15 +248,16 @@ typedef struct carel_attn_args {
    * en_ec_sentence_transformer.py:22): f32 [heads][256], entry 127 + (key position - query position), made from the learned
    * [32 buckets][heads] table by carel_relpos_expand; NULL = no bias (BERT / RoBERTa). */
   const void* rel_bias_dist;
-  void* d_rel_bias_dist;       /* bwd, required with rel_bias_dist: f32 [heads][256], ACCUMULATED into (atomics); the caller zeroes
-                                  it once per step and folds it into the table gradient with carel_relpos_reduce */
+  void* d_rel_bias_dist;       /* bwd, required with rel_bias_dist: f32 [batch * heads][256], row (sample, head) ADDED to by that workgroup alone
+                                  (no atomics: bit-reproducible); the caller zeroes it once per step -- every layer adds to it -- and folds
+                                  it into the table gradient with carel_relpos_reduce */
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);
 int carel_attention_bwd(const carel_attn_args* args, void* stream);
 /* bucket: int32 [256], bucket[i] = relative_position_bucket(i - 127) (entry 255 unused), computed by the caller */
 int carel_relpos_expand(const void* table_f32_32xH, const void* bucket, void* dist_f32_Hx256, void* stream);
-int carel_relpos_reduce(const void* ddist_f32_Hx256, const void* bucket, void* dtable_f32_32xH, int32_t accumulate, void* stream);
+int carel_relpos_reduce(const void* ddist_f32_BHx256, int32_t batch, const void* bucket, void* dtable_f32_32xH, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-encoder orchestration over caller-owned buffers.  Replaces `self.encoder(...)` (ref :202-206;

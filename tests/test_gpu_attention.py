@@ -145,7 +145,7 @@ def test_relative_position_bias_forward_backward_and_table_gradient(packed):
     B = len(lens)
     table = (torch.randn((32, NH), generator=g) * 0.7).cuda()
     rp = O.mpnet_relative_position_bucket(torch.arange(-127, 129)).to(torch.int32).cuda().contiguous()      # entry i = distance i - 127
-    dist, ddist = torch.empty((NH, 256), device="cuda"), torch.zeros((NH, 256), device="cuda")
+    dist, ddist = torch.empty((NH, 256), device="cuda"), torch.zeros((B * NH, 256), device="cuda")     # gradient by distance: one row per (sample, head)
     L.check(lib.carel_relpos_expand(table.data_ptr(), rp.data_ptr(), dist.data_ptr(), L.current_stream()), "relpos expand")
     T = sum(lens)
     if packed:
@@ -180,7 +180,7 @@ def test_relative_position_bias_forward_backward_and_table_gradient(packed):
     L.check(lib.carel_attention_fwd(C.byref(a), L.current_stream()), "attn fwd rel")
     L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd rel")
     dtable = torch.empty((32, NH), device="cuda")
-    L.check(lib.carel_relpos_reduce(ddist.data_ptr(), rp.data_ptr(), dtable.data_ptr(), 0, L.current_stream()), "relpos reduce")
+    L.check(lib.carel_relpos_reduce(ddist.data_ptr(), B, rp.data_ptr(), dtable.data_ptr(), 0, L.current_stream()), "relpos reduce")
     torch.cuda.synchronize()
     keep_all = torch.from_numpy(O.dropout_keep(seed, site, np.arange(B * NH * S * S, dtype=np.uint64).astype(np.uint32), p).astype(np.float64) / (1 - p)).view(B, NH, S, S).cuda()
     tab = table.double().requires_grad_(True)
@@ -202,5 +202,23 @@ def test_relative_position_bias_forward_backward_and_table_gradient(packed):
     # a second backward ACCUMULATES into the distance buffer (every layer of the encoder adds to the same one)
     L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd rel 2")
     dtable2 = torch.empty((32, NH), device="cuda")
-    L.check(lib.carel_relpos_reduce(ddist.data_ptr(), rp.data_ptr(), dtable2.data_ptr(), 0, L.current_stream()), "relpos reduce")
+    L.check(lib.carel_relpos_reduce(ddist.data_ptr(), B, rp.data_ptr(), dtable2.data_ptr(), 0, L.current_stream()), "relpos reduce")
     assert rel_err(dtable2, 2 * dtable) < 1e-5
+    # bit-reproducible (the gradient by distance used to be summed with LDS and global atomics): five fresh backward passes,
+    # with a second stream keeping the memory system busy, give the same bits in the distance buffer, the table gradient and dqkv
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, device="cuda")
+    ref = None
+    for it in range(5):
+        ddist.zero_(); dqkv.zero_()
+        if it % 2:
+            with torch.cuda.stream(side):
+                junk.add_(1.0)
+        L.check(lib.carel_attention_bwd(C.byref(a), L.current_stream()), "attn bwd rel rep")
+        L.check(lib.carel_relpos_reduce(ddist.data_ptr(), B, rp.data_ptr(), dtable2.data_ptr(), 0, L.current_stream()), "relpos reduce")
+        cur = (ddist.clone(), dtable2.clone(), dqkv.clone())
+        if ref is None:
+            ref = cur
+            assert torch.equal(cur[1], dtable)
+        else:
+            assert all(torch.equal(x, y) for x, y in zip(cur, ref)), it
+    torch.cuda.synchronize()

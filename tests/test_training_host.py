@@ -184,6 +184,7 @@ def test_mpnet_host_logic_bucket_map_and_state_dict_names():
     want = O.mpnet_relative_position_bucket(torch.arange(-127, 129))
     assert torch.equal(rel.bucket.cpu().long(), want)
     assert rel.dist.shape == (12, 256) and rel.ddist.shape == (12, 256)
+    assert model._m._rel_buffers(batch=16).ddist.shape == (16 * 12, 256)      # the gradient by distance: one row per (sample, head)
     sd = model.state_dict()
     assert "encoder.relative_attention_bias.weight" in sd and sd["encoder.relative_attention_bias.weight"].shape == (32, 12)
     assert "encoder.layer.0.attention.attn.q.weight" in sd and "encoder.layer.0.attention.LayerNorm.bias" in sd
