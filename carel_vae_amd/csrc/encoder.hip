@@ -149,6 +149,10 @@ int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, in
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
   g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map; g.colsum_a = nullptr;
   g.splitk_ws = ws; g.splitk_ws_bytes = (int64_t)ws_bytes;
+  // the scratch block is zero-filled when it is allocated (carel_encoder_scratch_bytes: "zero it once") and its workspace's last 4 KiB are
+  // written by nobody else: pair split-K may keep its flags there.  Not for the second forward chain, whose workspace is the
+  // weight-gradient slab area.
+  g.splitk_ws_zeroed = (ws != nullptr && (split_tile_factor & 0xff) == 1) ? 1 : 0;
   return gemm_bf16_ex(&g, split_tile_factor, stream);
 }
 
@@ -164,7 +168,7 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
   g.A = dY; g.B = X; g.lda = M; g.ldb = N; g.ldc = N; g.M = M; g.N = N; g.K = (int)T; g.form = CAREL_GEMM_TN; g.epilogue = CAREL_EPI_SLAB_F32;
   g.splits = splits; g.out_bf16 = nullptr; g.out2_bf16 = nullptr; g.out_f32 = slabs; g.bias = nullptr; g.resid_f32 = nullptr; g.aux_bf16 = nullptr;
   g.drop_seed = 0; g.drop_site = 0; g.drop_idx_offset = 0; g.drop_p = 0.f; g.drop_row_map = nullptr; g.colsum_part = nullptr;
-  g.splitk_ws = nullptr; g.splitk_ws_bytes = 0;
+  g.splitk_ws = nullptr; g.splitk_ws_bytes = 0; g.splitk_ws_zeroed = 0;
   float* cs = db ? (float*)slabs + (size_t)splits * M * N : nullptr;
   g.colsum_a = cs;
   if (splits == 1) {                 // one slab IS the result: write it (and the bias sums) in place, nothing to reduce

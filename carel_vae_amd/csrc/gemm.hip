@@ -458,6 +458,7 @@ template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
+    if (p.pair_flags && p.ldc == p.N && !p.colsum_part && g_gemm_variant == 0 && gemm_pp_pick_pair(p, BT, EPI)) return gemm_pp_launch_pair(p, BT, EPI, s);
     // (a shape only the ping-pong kernel takes -- M not a multiple of 128 -- runs on it whatever the tile-count threshold says:
     // gemm_shape_ok accepted it on that kernel's account)
     const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
@@ -731,6 +732,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
+  if (v == 200 || v == 201) { gemm_pp_pair_enable(v - 200); return CAREL_OK; }        // pair split-K of the N = 768, K >= 1536 GEMMs off (default: measured slower) / on
   if (v == 170 || v == 171) { gemm_pp_epi_prefetch(v - 170); return CAREL_OK; }       // ping-pong kernel: epilogue inputs requested before the main loop off / on
   if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles
   if (v == 90 || v == 91) { gemm_pp_wide_variant(v - 90); return CAREL_OK; }           // wide-phase schedule of the ping-pong kernel (npn 2) off / on
@@ -760,6 +762,12 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
   p.split_tile_factor = split_tile_factor;
   p.xcd_n = (a->form == CAREL_GEMM_TN && g_xcd_n <= 1) ? 8 : g_xcd_n;   // wgrad: 1x8 patches measured best (tools/bench_gemm.py)
   p.splitk_ws = (float*)a->splitk_ws; p.splitk_ws_bytes = a->splitk_ws ? (size_t)a->splitk_ws_bytes : 0;
+  p.pair_flags = nullptr; p.pair_seq = 0;
+  if (a->splitk_ws && a->splitk_ws_zeroed && (size_t)a->splitk_ws_bytes > (size_t)(64 << 20) && ((uintptr_t)a->splitk_ws & 15) == 0 && (a->splitk_ws_bytes & 15) == 0) {
+    // the last 4 KiB of a zero-initialised workspace hold the pair split-K flags; every other user of the workspace sees it shorter
+    p.splitk_ws_bytes -= PP_PAIR_FLAG_BYTES;
+    p.pair_flags = (unsigned*)((char*)a->splitk_ws + p.splitk_ws_bytes);
+  }
   if (a->ldc != a->N) p.splitk_ws = nullptr;                    // the slab epilogue assumes a dense C
   if (a->colsum_part) p.splitk_ws = nullptr;                    // fused column sums live in the single-pass epilogue
   p.colsum_part = (float*)a->colsum_part; p.drop_row_map = (const int*)a->drop_row_map; p.colsum_a = (float*)a->colsum_a;

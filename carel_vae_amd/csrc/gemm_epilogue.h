@@ -41,6 +41,8 @@ struct GemmParams {
   int split_tile_factor;    // internal split-K heuristic: the caller runs this many equal GEMMs side by side (1 = just this one)
   int xcd_n;                // XCDs laid out as (8/xcd_n) x xcd_n over (M tiles, N tiles); 1 = row-major chunks
   int gelu_lut;             // ping-pong kernel, GELU epilogues: 1 = table lookup (default), 0 = erf / exp arithmetic (tuning hook 160 / 161)
+  unsigned* pair_flags;     // ping-pong kernel, pair split-K: [tiles][8 waves] flags in the reserved tail of splitk_ws (zero-initialised once by the caller)
+  unsigned pair_seq;        // ... the value that marks THIS launch's partial sums as written (a process-wide launch counter, never 0)
   int epi_prefetch;         // ping-pong kernel: request the epilogue's residual / aux inputs before the main loop (tuning hook 170 / 171)
   int pp_xr, pp_bc;         // ping-pong kernel, NT / NN: the 8 XCDs tile the grid as pp_xr x (8 / pp_xr) rectangles, each walked in
                             // column blocks of pp_bc tiles (so that a round of 32 tiles per XCD is compact); pp_xr = 0: plain chunks
@@ -311,6 +313,11 @@ int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
-int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipStream_t s);   // NT / NN, `splits` K slices -> fp32 slabs at p.outf
+int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipStream_t s);
+// pair split-K (two workgroups per 256 x 192 tile, each half of K; gemm_pp.hip): 1 if this problem should run that way
+int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi);
+int gemm_pp_launch_pair(const GemmParams& p, bool bt, int epi, hipStream_t s);
+void gemm_pp_pair_enable(int on);
+constexpr size_t PP_PAIR_FLAG_BYTES = 4096;   // NT / NN, `splits` K slices -> fp32 slabs at p.outf
 
 }  // namespace carel

@@ -88,7 +88,17 @@ template <int NPN, bool BT> struct PPGeom {
 // The first ten arguments repeat the fields of `p` that the prologue needs before its first LDS-DMA instruction: as plain scalar kernel
 // arguments they are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16, carel_vae_amd/build.py; a by-value
 // struct is not), so the address arithmetic does not wait for the first s_load round trip of a cold CU.
-template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
+// PAIR (pair split-K; NT / NN, gridDim.z == 2): the two workgroups of a tile take half of K each.  Slice 0 ("A") stores its raw
+// accumulators -- [tile][wave][register][lane], 1 KiB per instruction -- and then a per-wave flag (this launch's sequence number), and
+// exits; slice 1 ("B") waits for the flag of ITS wave index, adds A's partial sums to its own and runs the epilogue.  Why: the N = 768
+// outputs are 256 tiles of 256 x 96 at T = 8192 -- 70 FLOP per staged byte, L2 -> LDS-bound and LDS-bandwidth-bound;
+// as 128 tiles of 256 x 192 split in two along K they stage 36 % fewer bytes per FLOP and read 30 % fewer LDS bytes per FLOP, on all
+// 256 CUs.  Deadlock-free by construction: the wait is one-directional (A never waits) and workgroups are dispatched in order of
+// their flat index, x fastest, z slowest -- every A is on a CU (or finished) before the first B exists -- so it holds with other
+// kernels or other processes sharing the GPU.  All pair traffic is system-scope (write-through stores, cache-bypassing loads): it
+// does not rely on A and B sharing an XCD's L2.  The sum is (first half of K) + (second half): deterministic, but not the bits of the
+// one-workgroup order.
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_pp_kernel(const bf16_t* A_, const bf16_t* B_, long lda_, long ldb_, int M_, int K_, int tiles_m_,
                                                          int tiles_n_, int pp_xr_, int pp_bc_, GemmParams p) {
   p.A = A_; p.B = B_; p.lda = lda_; p.ldb = ldb_; p.M = M_; p.K = K_; p.tiles_m = tiles_m_; p.tiles_n = tiles_n_; p.pp_xr = pp_xr_; p.pp_bc = pp_bc_;
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int PB = (HAS_IN && !AT && WIDE && DBG == 0) ? (NPN == 1 ? 4 : NPN == 2 ? (epi_is_dgelu(EPI) ? 4 : 2) : 0) : 0;    // (bf16 aux: 4 registers per 8 columns)
   constexpr int NE = PB * (NQ * (epi_is_dgelu(EPI) ? 1 : 2) + (NF & 1));
   static_assert(NE == 0 || (S::NTAIL >= 1 && NE + 16 <= 63), "vmcnt is a 6-bit counter");
-  const bool pre = PB > 0 && p.epi_prefetch && (EPI != EPI_ADD_F32 || p.resid != nullptr) && nk > S::NTAIL;      // wave-uniform
+  const bool pre = PB > 0 && p.epi_prefetch && (EPI != EPI_ADD_F32 || p.resid != nullptr) && nk > S::NTAIL && !(PAIR && kz == 0);      // wave-uniform
   EpiIn8 pin[PB > 0 ? PB : 1][NQ > 0 ? NQ : 1];
   EpiIn4 pin4[PB > 0 ? PB : 1];
   // ---- prologue: the units the steady-state schedule would have issued before phase 0 ------------------------------
@@ -430,6 +440,57 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     o[0] = t_loop0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = nk;
   }
 
+  if constexpr (PAIR) {
+    constexpr int NR = 4 * NF;                                  // float4 accumulators per lane
+    const long slot = ((long)(tm * p.tiles_n + tn) * 8 + wave);
+    unsigned long long* part = (unsigned long long*)p.splitk_ws + slot * (NR * 2 * 64) + lane;      // [register half][lane] 8-byte words
+    unsigned* flag = p.pair_flags + slot;
+    if (kz == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int r = (h * 2 + i) * NF + j;
+            const f32x4 a = acc[h][i][j];
+            __hip_atomic_store(part + (2 * r) * 64, ((unsigned long long)__float_as_uint(a[1]) << 32) | __float_as_uint(a[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(part + (2 * r + 1) * 64, ((unsigned long long)__float_as_uint(a[3]) << 32) | __float_as_uint(a[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every partial sum of this wave is written through
+      __hip_atomic_store(flag, p.pair_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    // slice 1: wait for THIS wave's partner (bounded: ~2 s of polling, then the result is poisoned instead of hanging the GPU)
+    unsigned seen = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seen == p.pair_seq) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    asm volatile("" ::: "memory");
+    const float poison = seen == p.pair_seq ? 0.f : __builtin_nanf("");
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned long long w[NF][2];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = (h * 2 + i) * NF + j;
+          w[j][0] = __hip_atomic_load(part + (2 * r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          w[j][1] = __hip_atomic_load(part + (2 * r + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          // (first half of K) + (second half of K): the partner's sum is the left operand
+          acc[h][i][j][0] = (__uint_as_float((unsigned)w[j][0]) + acc[h][i][j][0]) + poison;
+          acc[h][i][j][1] = (__uint_as_float((unsigned)(w[j][0] >> 32)) + acc[h][i][j][1]) + poison;
+          acc[h][i][j][2] = (__uint_as_float((unsigned)w[j][1]) + acc[h][i][j][2]) + poison;
+          acc[h][i][j][3] = (__uint_as_float((unsigned)(w[j][1] >> 32)) + acc[h][i][j][3]) + poison;
+        }
+      }
+  }
   if (AT && do_cs && lane < 16) {                              // D[n][m]: every row n holds the same sum; lane = m
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -540,7 +601,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 }
 
-template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false>
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false, bool PAIR = false>
 int launch_pp(GemmParams p, int splits, hipStream_t s) {
   using G = PPGeom<NPN, BT>;
   constexpr int LDS_BYTES = G::LDS + ((epi_is_gelu(EPI) && !AT) ? LUT_BYTES : 0);
@@ -548,7 +609,7 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
   if (epi_is_gelu(EPI)) { const int rc = gelu_lut_ready(); if (rc) return rc; }
   static bool attr = false;      // per process; setting it again is harmless if two threads race
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
@@ -574,7 +635,7 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
       p.pp_bc = bc;
     }
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), LDS_BYTES, s, p.A, p.B, p.lda,
+  hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE, PAIR>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), LDS_BYTES, s, p.A, p.B, p.lda,
                      p.ldb, p.M, p.K, p.tiles_m, p.tiles_n, p.pp_xr, p.pp_bc, p);
   return check_launch("gemm_pp_kernel");
 }
@@ -703,6 +764,37 @@ int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipSt
     if (npn == 2) return launch_pp<2, false, true, EPI_SLAB_F32, 0, true>(p, splits, s);
   }
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_slab: npn = %d not built", npn);
+}
+
+// ---- pair split-K ---------------------------------------------------------------------------------------------------------------------
+// OFF by default -- built, correct, measured slower (tools/bench_gemm_cold.py, PAIR=0 / 1 on one box, hot / cold operands): FFN2 forward
+// 47.1 / 55.4 -> 51.9 / 57.3 us, FFN1 data gradient 45.9 / 53.5 -> 51.5 / 63.8, QKV data gradient 38.4 / 43.8 -> 43.0 / 53.3.  The 256 x 192
+// main loop is only ~9 % more efficient per FLOP than the 256 x 96 one (1.40 us per K tile against 2 x 0.77), which saves ~3 us per
+// launch; the exchange (196 KiB written through and read back per tile, B idle until A's write lands) and the wider epilogue cost ~9.
+static int g_pp_pair = 0;          // tuning hook (carel_gemm_set_variant(200 / 201))
+void gemm_pp_pair_enable(int on) { g_pp_pair = on ? 1 : 0; }
+// Worth it where the 256 x 96 tiling is L2 -> LDS-bound and the K loop is long enough to pay for the exchange (196 KiB written and read
+// per tile): N a multiple of 192 but not a 2304 / 3072-wide output (those already run 256 x 192 / 288 tiles), K >= 1536, and twice the
+// 256 x 192 tile count fills the chip in exactly one round.
+int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi) {
+  if (!g_pp_pair || !g_pp_wide || !p.pair_flags || !p.splitk_ws) return 0;
+  if (!(epi == EPI_BIAS_DROP_RESID && !bt) && !(epi == EPI_ADD_F32)) return 0;
+  if (p.N != 768 || p.K % 128 || p.K < 1536 || p.M < 1) return 0;
+  const long tiles = (long)((p.M + 255) / 256) * (p.N / 192);
+  if (tiles * 2 > 256 || tiles * 2 < 224 || (tiles & 7)) return 0;
+  if ((size_t)tiles * 256 * 192 * 4 > p.splitk_ws_bytes || tiles * 8 * 4 > (long)PP_PAIR_FLAG_BYTES) return 0;
+  return 1;
+}
+int gemm_pp_launch_pair(const GemmParams& p0, bool bt, int epi, hipStream_t s) {
+  static std::atomic<unsigned> seq{0};
+  GemmParams p = p0;
+  unsigned v = seq.fetch_add(1, std::memory_order_relaxed) + 1;
+  if (v == 0) v = seq.fetch_add(1, std::memory_order_relaxed) + 1;          // never 0 (the flags start zeroed)
+  p.pair_seq = v;
+  if (!bt && epi == EPI_BIAS_DROP_RESID) return launch_pp<2, false, false, EPI_BIAS_DROP_RESID, 0, true, true>(p, 2, s);
+  if (!bt && epi == EPI_ADD_F32) return launch_pp<2, false, false, EPI_ADD_F32, 0, true, true>(p, 2, s);
+  if (bt && epi == EPI_ADD_F32) return launch_pp<2, false, true, EPI_ADD_F32, 0, true, true>(p, 2, s);
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch_pair: unsupported form/epilogue (%d,%d)", (int)bt, epi);
 }
 
 #ifdef CAREL_GEMM_ABLATE

@@ -99,6 +99,10 @@ typedef struct carel_gemm_args {
                            ones-vector MFMA per step in the first tile column */
   void* colsum_part;    /* optional, CAREL_EPI_DGELU_BF16 / CAREL_EPI_MUL_BF16 only: f32 [M/128][N] per-row-tile column sums of the output
                            (pre-rounding); summing them over M/128 gives the FFN1 bias gradient */
+  int32_t splitk_ws_zeroed; /* (ABI 5) 1 = the caller zero-filled splitk_ws ONCE when it allocated it and lets nobody else write its last
+                           4 KiB: enables pair split-K for N = 768 outputs with K >= 1536 at M ~ 8192 (two workgroups per 256 x 192 tile,
+                           each half of K; the second waits for the first's partial sums through per-wave flags kept in that tail, one-
+                           directionally, so it cannot deadlock).  0 = never (a stale flag in uninitialised memory could end the wait early). */
 } carel_gemm_args;
 
 int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
@@ -267,7 +271,9 @@ int carel_relpos_reduce(const void* ddist_f32_BHx256, int32_t batch, const void*
  * matrix (query rows, then key, then value).
  *   act     : carel_encoder_act_bytes(B, S, L, inference) bytes; holds every activation the backward
  *             needs (inference = 1: one layer's worth, re-used by every layer; no backward possible)
- *   scratch : carel_encoder_scratch_bytes(B, S) bytes of backward workspace
+ *   scratch : carel_encoder_scratch_bytes(B, S) bytes of workspace.  ZERO-FILL IT ONCE when it is allocated, and let nothing but the library
+ *             write to it afterwards (ABI 5): a few words of it are flags of the pair split-K GEMMs (carel_gemm_args.splitk_ws_zeroed), which
+ *             must not start out equal to a launch sequence number
  *   dx      : f32 [B*S, 768]; in: d(loss)/d(last hidden state); carried down through the layers
  * Constraints: hidden 768, 12 heads, intermediate 3072, seq_len in {32,64,96,128}, B*S % 128 == 0.
  * ---------------------------------------------------------------------------------------------- */

@@ -17,7 +17,8 @@ def to_bf16_bits(t: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(A, B, form, epi, M, N, K, splits=1, out_bf16=None, out2_bf16=None, out_f32=None, bias=None,
-         resid=None, aux=None, drop=(0, 0, 0, 0.0), lda=None, ldb=None, ldc=None, colsum_part=None, colsum_a=None, splitk_ws=None):
+         resid=None, aux=None, drop=(0, 0, 0, 0.0), lda=None, ldb=None, ldc=None, colsum_part=None, colsum_a=None, splitk_ws=None,
+         ws_zeroed=False):
     a = L.GemmArgs()
     a.A, a.B = A.data_ptr(), B.data_ptr()
     a.lda = lda if lda is not None else A.stride(0)
@@ -33,6 +34,7 @@ def gemm(A, B, form, epi, M, N, K, splits=1, out_bf16=None, out2_bf16=None, out_
     a.colsum_a = None if colsum_a is None else colsum_a.data_ptr()
     a.splitk_ws = None if splitk_ws is None else splitk_ws.data_ptr()
     a.splitk_ws_bytes = 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size()
+    a.splitk_ws_zeroed = 1 if ws_zeroed else 0
     L.check(L.load().carel_gemm_bf16(C.byref(a), L.current_stream()), "carel_gemm_bf16")
 
 

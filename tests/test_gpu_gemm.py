@@ -545,3 +545,72 @@ def test_rowln_equals_gemm_then_layernorm_bitwise(M, K, packed):
     ref = torch.nn.functional.layer_norm(ref_h, (768,), gamma.double(), beta.double(), 1e-12)
     assert rel_err(got0["xf"][:M], ref) < 2e-5
     assert bool((got0["h"] == 7.0).all())
+
+
+@pytest.mark.parametrize("case", ["ffn2 fwd NT", "ffn1 dgrad NN", "qkv dgrad NN"])
+def test_pp_pair_split_k_exact_and_repeatable(case):
+    """Pair split-K (round 3): the N = 768, K >= 1536 GEMMs at M = 8192 run as 128 tiles of 256 x 192, two workgroups per tile, each half of
+    K; the second waits (one-directionally, per wave) for the first's partial sums in a zero-initialised workspace whose last 4 KiB hold
+    the flags.  Exact small-integer data: any missed / stale / double-counted partial sum shows as an integer difference; random data
+    against fp64 and against the one-workgroup kernel (hook 200, the default: same addends, different tree -> 2e-6); 30 launches on one workspace --
+    each launch must see ITS partner's sums (sequence numbers), never the previous launch's -- bit-identical, with a second stream busy;
+    guard rows untouched; without the caller's zero-fill promise the path is not taken."""
+    lib = L.load()
+    L.check(lib.carel_gemm_set_variant(201))          # the path is off by default (measured slower than the 256 x 96 tiling: gemm_pp.hip)
+    try:
+        _pair_case(case, lib)
+    finally:
+        L.check(lib.carel_gemm_set_variant(200))
+
+
+def _pair_case(case, lib):
+    M, N = 8192, 768
+    form, epi, K = {"ffn2 fwd NT": (L.GEMM_NT, L.EPI_BIAS_DROP_RESID, 3072), "ffn1 dgrad NN": (L.GEMM_NN, L.EPI_ADD_F32, 3072),
+                    "qkv dgrad NN": (L.GEMM_NN, L.EPI_ADD_F32, 2304)}[case]
+    ws = torch.zeros(96 << 20, dtype=torch.uint8, device="cuda")            # zero-filled ONCE
+    def run(A, B, resid, bias, out, zeroed=True, drop=(0, 0, 0, 0.0)):
+        kw = dict(out_f32=out, resid=resid, splitk_ws=ws, ws_zeroed=zeroed)
+        if epi == L.EPI_BIAS_DROP_RESID: kw.update(bias=bias, drop=drop)
+        gemm(A, B, form, epi, M, N, K, **kw)
+    # exact integers
+    A = _ints((M, K), 1)
+    B = _ints((N, K), 2) if form == L.GEMM_NT else _ints((K, N), 2)
+    resid, bias = _ints((M, N), 3).float(), _ints((N,), 4).float()
+    out = torch.full((M + 8, N), 7.0, device="cuda")
+    run(A, B, resid, bias, out)
+    ref = A.double() @ (B.double().t() if form == L.GEMM_NT else B.double()) + resid.double() + (bias.double() if epi == L.EPI_BIAS_DROP_RESID else 0)
+    assert torch.equal(out[:M].double(), ref), float((out[:M].double() - ref).abs().max())
+    assert bool((out[M:] == 7.0).all())
+    flags = ws[-4096:].view(torch.int32)
+    assert int((flags != 0).sum()) == 128 * 8 and int(flags.max()) == int(flags.min())        # the pair path ran: every (tile, wave) flag = this launch's number
+    # random data: fp64, the one-workgroup kernel, repeatability across launches that re-use the workspace
+    A = _rand((M, K), 1, 81).bfloat16()
+    B = (_rand((N, K), 0.05, 82) if form == L.GEMM_NT else _rand((K, N), 0.05, 82)).bfloat16()
+    resid, bias = _rand((M, N), 1, 83), _rand((N,), 0.1, 84)
+    drop = (9, 5, 3 * N, 0.1)
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, device="cuda")
+    first = None
+    for it in range(30):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1.0)
+        o = torch.empty((M, N), device="cuda")
+        run(A, B, resid, bias, o, drop=drop)
+        if first is None:
+            first = o.clone()
+        else:
+            assert torch.equal(o, first), it
+    torch.cuda.synchronize()
+    L.check(lib.carel_gemm_set_variant(200))
+    try:
+        single = torch.empty((M, N), device="cuda")
+        run(A, B, resid, bias, single, drop=drop)
+    finally:
+        L.check(lib.carel_gemm_set_variant(201))          # back on for the rest of this case
+    assert rel_err(first, single) < 2e-6 and not torch.equal(first, single)          # same addends, (K/2) + (K/2) instead of one chain
+    before = ws[-4096:].clone()
+    unz = torch.empty((M, N), device="cuda")
+    run(A, B, resid, bias, unz, zeroed=False, drop=drop)                                # no promise, no pair path: the one-workgroup bits, flags untouched
+    assert torch.equal(unz, single) and torch.equal(ws[-4096:], before)
+    if epi == L.EPI_ADD_F32:
+        assert rel_err(first, A.double() @ B.double() + resid.double()) < TOL

@@ -37,12 +37,14 @@ def timed(fns, n=24):
 tot = {"hot": 0.0, "cold": 0.0}
 for name, form, epi, M, N, K in shapes:
     sets = []
+    ws = torch.zeros(96 << 20, dtype=torch.uint8, device="cuda") if os.environ.get("PAIR", "0") == "1" else None      # PAIR=1 (with VARIANTS=201): zero-filled workspace + pair split-K
     for i in range(NSETS):
         A = rnd(M, K)
         B = rnd(N, K) if form == L.GEMM_NT else rnd(K, N)
         kw = dict(out_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16), out2_bf16=torch.empty((M, N), device="cuda", dtype=torch.bfloat16),
                   out_f32=torch.empty((M, N), device="cuda"), bias=torch.zeros(N, device="cuda"), resid=torch.zeros((M, N), device="cuda"),
                   aux=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), drop=(1, 2, 0, 0.1))
+        if ws is not None and epi in (L.EPI_BIAS_DROP_RESID, L.EPI_ADD_F32): kw.update(splitk_ws=ws, ws_zeroed=True)
         sets.append((A, B, kw))
     def mk(s):
         A, B, kw = s
