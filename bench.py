@@ -523,6 +523,18 @@ def main():
         model.overlap_wgrad = not a.no_overlap
         model._adam_hook = hook
         return ev, ov_e.value, ov_p.value
+    def gemm_roofline(ev, ov_e, ov_p):
+        """achieved / frac from the CONSERVATIVE launch time: event bracket around the launch minus a bare event pair, i.e. the whole
+        interval the stream spends on the launch, dispatch gap included -- the figure that agrees with the rocprofv3 kernel_stats
+        average committed under profiles/ (within ~3 %; VERDICT r02 item 8).  *_kernel_only: bracket minus the bracket around an EMPTY
+        kernel (kernel time over an empty kernel's), the optimistic end of the same measurement."""
+        ms, fl, n = ev
+        us_lo = 1e3 * ms / n                               # bracket - empty-kernel bracket (subtracted inside the library)
+        us_hi = us_lo + ov_e - ov_p                        # bracket - event pair
+        return {"achieved": fl / n / (us_hi * 1e-6) / 1e12, "frac": fl / n / (us_hi * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
+                "avg_launch_us": us_hi, "avg_launch_us_kernel_only": us_lo, "frac_kernel_only": fl / n / (us_lo * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
+                "launches_per_step": n / nprof, "alg_gflop_per_launch": fl / n / 1e9, "gemm_ms_per_step": us_hi * n / nprof * 1e-3,
+                "event_calibration_us": {"empty_kernel_bracket": ov_e, "event_pair": ov_p}}
     ev_timed, ov_empty_v, ov_pair_v = gemm_event_replay(a.warmup + a.steps)
     pairs_per_s = world * a.batch * a.steps / dt
 
@@ -598,18 +610,6 @@ def main():
     roof = None
     ms_t, fl_t, n_t = ev_timed
 
-    def gemm_roofline(ev, ov_e, ov_p):
-        """achieved / frac from the CONSERVATIVE launch time: event bracket around the launch minus a bare event pair, i.e. the whole
-        interval the stream spends on the launch, dispatch gap included -- the figure that agrees with the rocprofv3 kernel_stats
-        average committed under profiles/ (within ~3 %; VERDICT r02 item 8).  *_kernel_only: bracket minus the bracket around an EMPTY
-        kernel (kernel time over an empty kernel's), the optimistic end of the same measurement."""
-        ms, fl, n = ev
-        us_lo = 1e3 * ms / n                               # bracket - empty-kernel bracket (subtracted inside the library)
-        us_hi = us_lo + ov_e - ov_p                        # bracket - event pair
-        return {"achieved": fl / n / (us_hi * 1e-6) / 1e12, "frac": fl / n / (us_hi * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
-                "avg_launch_us": us_hi, "avg_launch_us_kernel_only": us_lo, "frac_kernel_only": fl / n / (us_lo * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
-                "launches_per_step": n / nprof, "alg_gflop_per_launch": fl / n / 1e9, "gemm_ms_per_step": us_hi * n / nprof * 1e-3,
-                "event_calibration_us": {"empty_kernel_bracket": ov_e, "event_pair": ov_p}}
     if n_t:
         traffic = None
         try:        # HBM traffic per GEMM launch from the committed PMC summary (rocprofv3 --pmc passes, see DESIGN.md section 5)
