@@ -458,7 +458,6 @@ template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
-    if (g_gemm_variant == 0 && p.ldc == p.N && gemm_sw_pick(p, BT, EPI)) return gemm_sw_launch(p, BT, EPI, s);
     if (p.pair_flags && p.ldc == p.N && !p.colsum_part && g_gemm_variant == 0 && gemm_pp_pick_pair(p, BT, EPI)) return gemm_pp_launch_pair(p, BT, EPI, s);
     // (a shape only the ping-pong kernel takes -- M not a multiple of 128 -- runs on it whatever the tile-count threshold says:
     // gemm_shape_ok accepted it on that kernel's account)
@@ -733,7 +732,6 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
-  if (v >= 210 && v <= 212) { gemm_sw_mode(v - 210); return CAREL_OK; }               // one-wave-per-SIMD kernel for the 768-wide GEMMs off / on
   if (v == 200 || v == 201) { gemm_pp_pair_enable(v - 200); return CAREL_OK; }        // pair split-K of the N = 768, K >= 1536 GEMMs off (default: measured slower) / on
   if (v == 170 || v == 171) { gemm_pp_epi_prefetch(v - 170); return CAREL_OK; }       // ping-pong kernel: epilogue inputs requested before the main loop off / on
   if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles

@@ -294,11 +294,6 @@ int gemm_rowln_launch(const RowLnParams& p, bool packed, hipStream_t s);
 int gemm_rowln_pack(const void* W, long ldb, int K, void* out, hipStream_t s);
 void gemm_rowln_dbg(int d);
 
-// gemm_sw.hip: one wave per SIMD, 256 x 96 tiles, for the 768-wide outputs at T = 8192 (tuning hook 210 / 211)
-int gemm_sw_pick(const GemmParams& p, bool bt, int epi);
-int gemm_sw_launch(const GemmParams& p, bool bt, int epi, hipStream_t s);
-void gemm_sw_mode(int m);
-
 // gemm_pp.hip: the 256 x (96 * npn) ping-pong kernel for the NT / NN forms.  gemm_pp_pick returns npn (1..3) if the kernel
 // should run this problem, 0 otherwise; force = 1: whenever the shape allows, force = -n: grids of at least n tiles.
 int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force);
