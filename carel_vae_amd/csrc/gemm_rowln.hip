@@ -17,9 +17,13 @@
 //   * the 32 activation rows are shared by all waves: a 768-deep K chunk of them (48 KiB, twelve 32-row ROW images) is staged by
 //     LDS-DMA, double-buffered for K > 768, one barrier per chunk.
 //   * every workgroup streams the WHOLE weight matrix (1.2 MB at K = 768, 4.7 MB at K = 3072) from L2: the main loop is bound by the
-//     L2 -> CU rate (~95 GB/s per CU with all 256 CUs pulling, MI355X_MICROARCH.md "Indexed rows"): ~12.4 us / ~50 us, against
-//     8 us / 37 us of the ping-pong main loop -- and still shorter end to end, because what follows it costs 3 us instead of
-//     15-20 (measured: DESIGN.md section 4.3).
+//     L2 -> CU rate -- measured 108 GB/s per CU with the packed weight order below (0.91 us per K tile: 10.9 / 43.7 us), 30-40 GB/s with
+//     the nn.Linear layout -- against 8 / 37 us of the ping-pong main loop.
+//   * MEASURED (tools/bench_rowln.py, profiles/r03_bench_rowln.txt; hot / cold operands): out-projection 30.1 / 38.7 us against 35.5 / 40.6
+//     for GEMM + LayerNorm; FFN2 62.6 / 77.2 against 59.3 / 69.6.  The fixed part is ~19 us: the sub-layer's 87 MB of residual-stream
+//     traffic (25 read; 25 + 25 + 12.5 written) at ~5 TB/s -- fusing saves the 25-MB re-read and a launch, not the writes, and with one
+//     round of 256 workgroups in lockstep nothing overlaps them.  So the encoder does NOT use this kernel by default (hook 191 / 192);
+//     it stays as an operator of the library (carel_gemm_rowln), bit-identical to the two-kernel path.
 //   * epilogue: acc + bias goes through the LDS once (the staging buffers are free by then) into ROW layout, and each wave then
 //     finishes four rows exactly as ln_fwd_kernel does -- same element-to-lane map, same summation tree (ln_device.h) -- with
 //     1-KiB coalesced accesses: residual read, pre-LayerNorm sum written (saved for the backward pass), x f32, x bf16, row statistics.
