@@ -57,9 +57,7 @@ __device__ __forceinline__ bf16x8 frag32_tr(const char* img, int x0, int kb) {
 
 // registers 8s..8s+7 of a 32x32 accumulator as the bf16 B operand of k-step s (rows of the tile = kk)
 __device__ __forceinline__ bf16x8 acc_as_operand(const f32x16& x, int s) {
-  s16x8 r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(x[8 * s + j]);
+  const uint4 r = {pack2bf(x[8 * s], x[8 * s + 1]), pack2bf(x[8 * s + 2], x[8 * s + 3]), pack2bf(x[8 * s + 4], x[8 * s + 5]), pack2bf(x[8 * s + 6], x[8 * s + 7])};
   return __builtin_bit_cast(bf16x8, r);
 }
 
@@ -116,7 +114,7 @@ constexpr int ATTN_BWD_LDS_REL = ATTN_BWD_LDS + 1024 + 4096;     // + bias by di
 // =========================================================================================== forward
 // REL: scores += rel[h][127 + key - query] (transformers MPNetAttention: `attention_scores += position_bias`, the bias shared by all
 // layers; en_ec_sentence_transformer.py:22 loads all-mpnet-base-v2)
-template <bool REL>
+template <bool REL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 512 + (REL ? 1024 : 0)];
   char* kimg = smem;
@@ -177,7 +175,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float lsum = 0.f;
-  const uint32_t ebase = (uint32_t)((((long)b * NH + h) * S + (q0 + (lane & 31))) * S);
+  // dropout_hash2's argument for key 0 (32-bit wrap-around arithmetic, as the element index is defined); keys kt*32 + acc32_row(r) are added per pair
+  const uint32_t ebase = (uint32_t)((((long)b * NH + h) * S + (q0 + (lane & 31))) * S) + (uint32_t)(4 * hh) + p.drop.idx_offset;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     if (kt < nkt) {
@@ -186,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         const float e0 = __expf(x[kt][r] - m), e1 = __expf(x[kt][r + 1] - m);
         lsum += e0; lsum += e1;
         float d0 = 1.0f, d1 = 1.0f;
-        if (p.drop.thresh) {
-          const uint32_t hsh = dropout_hash2(p.drop, ebase + kt * 32 + acc32_row(r, lane));
+        if constexpr (DROP) {       // (a template parameter: tested at run time, every pair sat in its own basic block)
+          const uint32_t hsh = mix32(((ebase + (uint32_t)(kt * 32 + (r & 3) + 8 * (r >> 2))) >> 1) ^ p.drop.key);
           d0 = dropout_pick(p.drop, hsh, 0u); d1 = dropout_pick(p.drop, hsh, 1u);
         }
         x[kt][r] = e0 * d0; x[kt][r + 1] = e1 * d1;
@@ -233,7 +232,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 __device__ __forceinline__ int swz_ds(int k) { return ((k & 3) << 3) | ((k >> 2) & 7); }
 __device__ __forceinline__ int ds_off(int k, int q) { return k * 256 + ((((q >> 2) ^ swz_ds(k)) & 31) << 3) + (q & 3) * 2; }
 
-template <bool REL>
+// DROP (attention-probability dropout on) is a template parameter, and the per-element arithmetic below is straight-line code: with the
+// rate tested at run time and `live ? exp(..) : 0` written as conditionals, the compiler (ROCm 7.2) built 48 branches per query tile, each
+// around one ds_read_b32 of lse[q] / delta[q] with its own lgkmcnt(0) -- 32 exposed LDS round trips per tile and wave.  Rows past the sample
+// get lse = +inf instead (exp2(-inf) = 0: the exact zeros the `live` test produced) and masked / past-the-sample keys -inf through the mask term.
+constexpr float LOG2E = 1.4426950408889634f;
+template <bool REL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ATTN_BWD_LDS (+ REL: 2048) bytes
   char* qimg = smem;                 // Q  [S][64]
@@ -259,7 +263,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) relg[w * 256 + threadIdx.x] = 0.f;
   }
-  for (int k = threadIdx.x; k < rows; k += 256) lse[k] = k < len ? p.lse[((long)b * NH + h) * S + k] : 0.f;
+  // lse in log2 units; +inf for the rows past the sample (they belong to its neighbours: probability exactly 0).  (The clamp keeps a
+  // fully masked row -- lse = -3.4e38 -- finite: its probabilities come out 0 here; no input of the reference has such a row.)
+  for (int k = threadIdx.x; k < rows; k += 256) lse[k] = k < len ? fmaxf(p.lse[((long)b * NH + h) * S + k], -1e30f) * LOG2E : INFINITY;
   {  // delta[q] = sum_d dO[q][d] * O[q][d]; 2 threads per query, 32 d each
     const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
     float s = 0.f;
@@ -303,6 +309,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     const int key = kw + (lane & 31);
     const bool klive = key < len;
     const float madd = p.cu ? (klive ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + key] == 0) ? MASK_NEG : 0.f);
+    const float madd2 = madd * LOG2E;          // 0 or -inf
+    // dropout_hash2's argument for query 0 of this lane's share (32-bit wrap-around arithmetic, as the element index is defined)
+    const uint32_t hbase = (uint32_t)(((long)b * NH + h) * S * S) + (uint32_t)(key & ~1) + (uint32_t)((16 * (lane & 1) + 4 * hh) * S) + p.drop.idx_offset;
     // (recording the forward's dropout decisions as bits and reading them here instead of re-hashing was built and measured:
     // forward +1 us, backward -0.5 us -- the hash hides behind the MFMA / LDS latencies of the loop; not kept)
     for (int qt = 0; qt < nt; ++qt) {
@@ -318,36 +327,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       // r = 0..7, odd lanes r = 8..15, and the halves are swapped with one DPP move each: 8 hashes per lane instead of 16
       uint32_t hown[8], hoth[8];
       const uint32_t odd = (uint32_t)lane & 1u;
-      if (CAREL_ATTN_ABLATE != 1 && p.drop.thresh) {
+      if constexpr (DROP && CAREL_ATTN_ABLATE != 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int qh = qt * 32 + (j & 3) + 8 * ((j >> 2) + 2 * (int)odd) + 4 * hh;        // = acc32_row(j + 8 * odd, lane)
-          hown[j] = dropout_hash2(p.drop, (uint32_t)((((long)b * NH + h) * S + qh) * S + (key & ~1)));
+          // element ((b*NH + h)*S + qh)*S + key with qh = acc32_row(j + 8 * odd, lane) = qt*32 + (j&3) + 8*(j>>2) + 16*odd + 4*hh: the per-lane part
+          // is hbase (hoisted), the rest is wave-uniform
+          hown[j] = mix32(((hbase + (uint32_t)((qt * 32 + (j & 3) + 8 * (j >> 2)) * S)) >> 1) ^ p.drop.key);
           hoth[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[j], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the neighbour's
         }
       }
-      f32x16 pd, dsv;                                             // dropped probabilities, dS
+      f32x16 pd, dsv;                                             // dropped probabilities, dS (without the 1/sqrt(d): applied to dK / dQ at the end)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qt * 32 + acc32_row(r, lane);
-        const bool live = klive && q < len;      // rows / keys past the sample belong to its neighbours: contribute exact zeros
-        float sc = sa[r] * 0.125f;
-        if (REL) sc += relb[127 + key - q];
-        const float pr = live ? (CAREL_ATTN_ABLATE == 3 ? (sc + madd - lse[q]) : __expf(sc + madd - lse[q])) : 0.f;
-        const float dm = (CAREL_ATTN_ABLATE == 1 || !p.drop.thresh) ? 1.0f
-                         : dropout_pick(p.drop, ((uint32_t)(r >> 3) == odd) ? hown[r & 7] : hoth[r & 7], odd);
-        pd[r] = live ? pr * dm : 0.f;
-        const float ds_raw = live ? pr * (dp[r] * dm - delta[q]) : 0.f;  // d loss / d score
-        dsv[r] = ds_raw * 0.125f;                                        // includes the 1/sqrt(d) of the q.k part of the scores
-        // the bias enters the scores unscaled: its gradient is the plain sum of dS over the diagonal key - query.  Deterministic: each wave
-        // adds into its OWN array, and the two half-waves (same keys, queries 4 apart: lane l of the upper half would hit the address
-        // of lane l - 4 of the lower) take turns, so no two lanes of one instruction share an address -- plain read-add-write in a
-        // fixed order instead of LDS atomics (every other gradient of this library is bit-reproducible)
-        if (REL) {
-          float* mine = relg + wave * 256 + 127 + key - q;
-          if (hh == 0 && live) *mine += ds_raw;
+      for (int i = 0; i < 4; ++i) {
+        // registers 4i..4i+3 of the 32x32 tile are the consecutive queries qt*32 + 8i + 4hh + (0..3): one 16-byte LDS read each
+        const f32x4 l4 = *(const f32x4*)(lse + qt * 32 + 8 * i + 4 * hh);
+        const f32x4 d4 = *(const f32x4*)(delta + qt * 32 + 8 * i + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * i + e;
+          float arg = fmaf(sa[r], 0.125f * LOG2E, madd2 - l4[e]);
+          if (REL) arg = fmaf(relb[127 + key - (qt * 32 + 8 * i + 4 * hh + e)], LOG2E, arg);
+          const float pr = CAREL_ATTN_ABLATE == 3 ? arg : __builtin_amdgcn_exp2f(arg);
+          float dm = 1.0f;
+          if constexpr (DROP && CAREL_ATTN_ABLATE != 1) dm = dropout_pick(p.drop, ((uint32_t)(r >> 3) == odd) ? hown[r & 7] : hoth[r & 7], odd);
+          pd[r] = pr * dm;
+          dsv[r] = pr * fmaf(dp[r], dm, -d4[e]);                  // d loss / d score
+        }
+      }
+      // the bias enters the scores unscaled: its gradient is the plain sum of dS over the diagonal key - query.  Deterministic: each wave
+      // adds into its OWN array, and the two half-waves (same keys, queries 4 apart: lane l of the upper half would hit the address
+      // of lane l - 4 of the lower) take turns, so no two lanes of one instruction share an address -- plain read-add-write in a
+      // fixed order instead of LDS atomics (every other gradient of this library is bit-reproducible).  Dead rows / keys add 0.
+      if (REL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* mine = relg + wave * 256 + 127 + key - (qt * 32 + acc32_row(r, lane));
+          if (hh == 0) *mine += dsv[r];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (hh == 1 && live) *mine += ds_raw;
+          if (hh == 1) *mine += dsv[r];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
       }
@@ -376,11 +393,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     p.drel[((long)b * NH + h) * 256 + threadIdx.x] += g;
   }
   stage_att(qbase + HID, QKV_LD, rows, doimg);  // K image for the dQ phase
-  // (dK, dV stay in registers until the very end: stored here, the vmcnt(0) below -- which the K image needs -- would also wait for
-  // their 25 MB of writes)
+  // dK and dV are stored while the K image is in flight: vmcnt retires in issue order and the image's copies are older than the stores, so
+  // a counted wait for all but the 8 store instructions (dense batches: every row is live, the count is static) retires exactly the image.
+  // (Packed batches mask rows past the sample -- a fully masked store may be skipped -- and drain everything, as before.)
   char* slot = qimg + wave * 4096;           // the Q image is dead now (every wave has left the main loop): 4 KiB per wave for the row stores
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  bf16_t* out = p.dqkv + (row0 + kw) * QKV_LD + h * HD;
+  if (active && CAREL_ATTN_ABLATE != 4) {
+    store_rows_via_lds(dk, 0.125f, slot, out + HID, QKV_LD, kw, len);       // the 1/sqrt(d) of the scores (a power of two: the same bits as scaling dS)
+    store_rows_via_lds(dv, 1.0f, slot, out + 2 * HID, QKV_LD, kw, len);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (active && !p.cu && CAREL_ATTN_ABLATE != 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();              // raw: __syncthreads() would drain the stores too
+  __builtin_amdgcn_sched_barrier(0);
   if (!active) return;
   // dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]   for this wave's 32 queries q = kw + ..
   f32x16 dq[2];
@@ -402,12 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
       for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(frag32_tr<false>(doimg, dt * 32, 16 * ks), bf, dq[dt]);
     }
   }
-  if (CAREL_ATTN_ABLATE != 4) {
-    bf16_t* out = p.dqkv + (row0 + kw) * QKV_LD + h * HD;
-    store_rows_via_lds(dq, 1.0f, slot, out, QKV_LD, kw, len);
-    store_rows_via_lds(dk, 1.0f, slot, out + HID, QKV_LD, kw, len);
-    store_rows_via_lds(dv, 1.0f, slot, out + 2 * HID, QKV_LD, kw, len);
-  }
+  if (CAREL_ATTN_ABLATE != 4) store_rows_via_lds(dq, 0.125f, slot, out, QKV_LD, kw, len);
 }
 
 }  // namespace carel
@@ -435,8 +457,14 @@ extern "C" int carel_attention_fwd(const carel_attn_args* a, void* stream_) {
   AttnParams p;
   int rc = attn_prepare(a, &p, "carel_attention_fwd", false);
   if (rc) return rc;
-  if (p.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(p.B * NH), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(p.B * NH), dim3(256), 0, stream, p);
+  const bool drop = p.drop.thresh != 0;
+  if (p.rel) {
+    if (drop) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3(p.B * NH), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3(p.B * NH), dim3(256), 0, stream, p);
+  } else {
+    if (drop) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), dim3(p.B * NH), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3(p.B * NH), dim3(256), 0, stream, p);
+  }
   return check_launch("attn_fwd_kernel");
 }
 
@@ -447,13 +475,21 @@ extern "C" int carel_attention_bwd(const carel_attn_args* a, void* stream_) {
   if (rc) return rc;
   static bool attr_set = false;     // idempotent; a benign race sets it twice
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS_REL);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS_REL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_BWD_LDS_REL);
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_attention_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  if (p.rel) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(p.B * NH), dim3(256), ATTN_BWD_LDS_REL, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(p.B * NH), dim3(256), ATTN_BWD_LDS, stream, p);
+  const bool drop = p.drop.thresh != 0;
+  if (p.rel) {
+    if (drop) hipLaunchKernelGGL((attn_bwd_kernel<true, true>), dim3(p.B * NH), dim3(256), ATTN_BWD_LDS_REL, stream, p);
+    else hipLaunchKernelGGL((attn_bwd_kernel<true, false>), dim3(p.B * NH), dim3(256), ATTN_BWD_LDS_REL, stream, p);
+  } else {
+    if (drop) hipLaunchKernelGGL((attn_bwd_kernel<false, true>), dim3(p.B * NH), dim3(256), ATTN_BWD_LDS, stream, p);
+    else hipLaunchKernelGGL((attn_bwd_kernel<false, false>), dim3(p.B * NH), dim3(256), ATTN_BWD_LDS, stream, p);
+  }
   return check_launch("attn_bwd_kernel");
 }
 

@@ -25,8 +25,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, Na
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+// two values per v_cvt_pk_bf16_f32 (written as two scalar conversions + shift + or, the compiler emits one conversion per value and
+// two more instructions to merge them: 4 VALU per pair instead of 1 -- every bf16 store of the library goes through here)
+typedef __attribute__((ext_vector_type(2))) float f32x2_cvt;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_cvt v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 // ---------------------------------------------------------------- dropout hash
