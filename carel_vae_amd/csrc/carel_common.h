@@ -58,6 +58,30 @@ __device__ __forceinline__ float dropout_mult(const Dropout& d, uint32_t idx) {
   if (d.thresh == 0u) return 1.0f;
   return dropout_pick(d, dropout_hash2(d, idx), (idx + d.idx_offset) & 1u);
 }
+// The multipliers of the N (even) consecutive elements idx .. idx + N - 1, the same values as N calls of dropout_mult.  When the first element
+// is the even half of its pair (every caller: idx a multiple of 4 or 8, the shard offset even) they are N/2 whole pairs: N/2 hashes and one test
+// of the rate for all of them.  (Element by element the epilogues compiled to one full hash -- two quarter-rate v_mul_lo_u32 -- and one
+// branch on the rate PER ELEMENT: 48 hashes per lane in the 256 x 96 tile's residual epilogue.)
+template <int N>
+__device__ __forceinline__ void dropout_mult_n(const Dropout& d, uint32_t idx, float* m) {
+  static_assert(N % 2 == 0, "whole pairs");
+  if (d.thresh == 0u) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[i] = 1.0f;
+    return;
+  }
+  const uint32_t j0 = idx + d.idx_offset;
+  if ((j0 & 1u) == 0u) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const uint32_t h = mix32(((j0 >> 1) + (uint32_t)i) ^ d.key);
+      m[2 * i] = dropout_pick(d, h, 0u); m[2 * i + 1] = dropout_pick(d, h, 1u);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[i] = dropout_pick(d, dropout_hash2(d, idx + (uint32_t)i), (j0 + (uint32_t)i) & 1u);
+  }
+}
 
 // ---------------------------------------------------------------- reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

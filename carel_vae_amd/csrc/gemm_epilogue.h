@@ -89,10 +89,12 @@ __device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const Epi
     const float4 r = in.r;
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o;
-    o.x = v[0] * dropout_mult(p.drop, e + 0) + r.x;
-    o.y = v[1] * dropout_mult(p.drop, e + 1) + r.y;
-    o.z = v[2] * dropout_mult(p.drop, e + 2) + r.z;
-    o.w = v[3] * dropout_mult(p.drop, e + 3) + r.w;
+    float dm[4];
+    dropout_mult_n<4>(p.drop, e, dm);
+    o.x = v[0] * dm[0] + r.x;
+    o.y = v[1] * dm[1] + r.y;
+    o.z = v[2] * dm[2] + r.z;
+    o.w = v[3] * dm[3] + r.w;
     *(float4*)(p.outf + off) = o;
   } else if (EPI == EPI_DGELU_BF16) {
     const uint2 a = in.a;
@@ -239,10 +241,12 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
     const float4 r0 = in.r0, r1 = in.r1;
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o0, o1;
-    o0.x = v[0] * dropout_mult(p.drop, e + 0) + r0.x; o0.y = v[1] * dropout_mult(p.drop, e + 1) + r0.y;
-    o0.z = v[2] * dropout_mult(p.drop, e + 2) + r0.z; o0.w = v[3] * dropout_mult(p.drop, e + 3) + r0.w;
-    o1.x = v[4] * dropout_mult(p.drop, e + 4) + r1.x; o1.y = v[5] * dropout_mult(p.drop, e + 5) + r1.y;
-    o1.z = v[6] * dropout_mult(p.drop, e + 6) + r1.z; o1.w = v[7] * dropout_mult(p.drop, e + 7) + r1.w;
+    float dm[8];
+    dropout_mult_n<8>(p.drop, e, dm);
+    o0.x = v[0] * dm[0] + r0.x; o0.y = v[1] * dm[1] + r0.y;
+    o0.z = v[2] * dm[2] + r0.z; o0.w = v[3] * dm[3] + r0.w;
+    o1.x = v[4] * dm[4] + r1.x; o1.y = v[5] * dm[5] + r1.y;
+    o1.z = v[6] * dm[6] + r1.z; o1.w = v[7] * dm[7] + r1.w;
     *(float4*)(p.outf + off) = o0; *(float4*)(p.outf + off + 4) = o1;
   } else if (EPI == EPI_DGELU_BF16) {
     float u[8];

@@ -185,10 +185,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(RowLnParams p) {
     for (int i = 0; i < NV; ++i) {
       const uint32_t e = (uint32_t)(drow * H + (i * 64 + lane) * 4);
       // the expression of epi_out8<EPI_BIAS_DROP_RESID>: v * dropout_mult + r
-      X[rr].v[i].x = X[rr].v[i].x * dropout_mult(p.drop, e + 0) + R[rr].v[i].x;
-      X[rr].v[i].y = X[rr].v[i].y * dropout_mult(p.drop, e + 1) + R[rr].v[i].y;
-      X[rr].v[i].z = X[rr].v[i].z * dropout_mult(p.drop, e + 2) + R[rr].v[i].z;
-      X[rr].v[i].w = X[rr].v[i].w * dropout_mult(p.drop, e + 3) + R[rr].v[i].w;
+      float dm[4];
+      dropout_mult_n<4>(p.drop, e, dm);
+      X[rr].v[i].x = X[rr].v[i].x * dm[0] + R[rr].v[i].x;
+      X[rr].v[i].y = X[rr].v[i].y * dm[1] + R[rr].v[i].y;
+      X[rr].v[i].z = X[rr].v[i].z * dm[2] + R[rr].v[i].z;
+      X[rr].v[i].w = X[rr].v[i].w * dm[3] + R[rr].v[i].w;
     }
   }
 #pragma unroll

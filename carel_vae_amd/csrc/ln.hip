@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a, float* __re
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const uint32_t e0 = (uint32_t)(row * H + (i * 64 + lane) * 4);
-      X.v[i].x *= dropout_mult(a.drop, e0); X.v[i].y *= dropout_mult(a.drop, e0 + 1);
-      X.v[i].z *= dropout_mult(a.drop, e0 + 2); X.v[i].w *= dropout_mult(a.drop, e0 + 3);
+      float dm[4];
+      dropout_mult_n<4>(a.drop, e0, dm);
+      X.v[i].x *= dm[0]; X.v[i].y *= dm[1]; X.v[i].z *= dm[2]; X.v[i].w *= dm[3];
     }
   }
   store_row(x_f32 + orow * H, lane, X);
@@ -193,8 +194,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const uint32_t e0 = (uint32_t)(drow * H + (i * 64 + lane) * 4);
-        DY.v[i].x *= dropout_mult(drop, e0); DY.v[i].y *= dropout_mult(drop, e0 + 1);
-        DY.v[i].z *= dropout_mult(drop, e0 + 2); DY.v[i].w *= dropout_mult(drop, e0 + 3);
+        float dm[4];
+        dropout_mult_n<4>(drop, e0, dm);
+        DY.v[i].x *= dm[0]; DY.v[i].y *= dm[1]; DY.v[i].z *= dm[2]; DY.v[i].w *= dm[3];
       }
     }
     if (dyb) store_row_bf16(dyb + row * H, lane, DY);
@@ -250,8 +252,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, const float
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const uint32_t e0 = (uint32_t)(row * H + (i * 64 + lane) * 4);
-        DY.v[i].x *= dropout_mult(a.drop, e0); DY.v[i].y *= dropout_mult(a.drop, e0 + 1);
-        DY.v[i].z *= dropout_mult(a.drop, e0 + 2); DY.v[i].w *= dropout_mult(a.drop, e0 + 3);
+        float dm[4];
+        dropout_mult_n<4>(a.drop, e0, dm);
+        DY.v[i].x *= dm[0]; DY.v[i].y *= dm[1]; DY.v[i].z *= dm[2]; DY.v[i].w *= dm[3];
       }
     }
 #pragma unroll
