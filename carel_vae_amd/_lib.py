@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAREL_HIP_LIB") or os.path.join(_HERE, "libcarel_hip.so")     # CAREL_HIP_LIB: an experiment build (tools/ablate_*.sh, tools/ab_lib.sh)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CarelError(RuntimeError):
@@ -91,7 +91,7 @@ class TailArgs(C.Structure):
                 ("d_pair_w", C.c_void_p), ("d_pair_b", C.c_void_p), ("d_dec_w", C.c_void_p), ("d_dec_b", C.c_void_p),
                 ("d_head_w", C.c_void_p * 4), ("d_head_b", C.c_void_p * 4),
                 ("d_pooler_w", C.c_void_p), ("d_pooler_b", C.c_void_p), ("dx_last_f32", C.c_void_p),
-                ("cls_rows", C.c_void_p), ("n_rows", C.c_int32)]
+                ("cls_rows", C.c_void_p), ("n_rows", C.c_int32), ("serial", C.c_int32)]
 
 
 class AdamArgs(C.Structure):

@@ -732,6 +732,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
+  if (v == 210 || v == 211) { tail_overlap_enable(v - 210); return CAREL_OK; }           // VAE tail: loss kernel on the side stream beside the decoder passes off / on (default)
   if (v == 200 || v == 201) { gemm_pp_pair_enable(v - 200); return CAREL_OK; }        // pair split-K of the N = 768, K >= 1536 GEMMs off (default: measured slower) / on
   if (v == 170 || v == 171) { gemm_pp_epi_prefetch(v - 170); return CAREL_OK; }       // ping-pong kernel: epilogue inputs requested before the main loop off / on
   if (v == 120 || v == 121) { gemm_pp_xcd_rect(v - 120); return CAREL_OK; }             // ping-pong kernel, NT / NN: XCD tile map chunks / rectangles

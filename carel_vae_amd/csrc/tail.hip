@@ -35,7 +35,7 @@ struct TailCore {
   int rank_stride;              // floats between consecutive ranks' blocks of B rows in z_global (B*2D when dense)
   const float* mmd_part; int mmd_nblk; const float* dz_mmd;   // global-batch MMD computed by mmd_global_kernel (else null)
   // outputs
-  float* z;                     // [B, 2D]
+  float* z;                     // [B, 2D]; null = do not write it (the caller's own sample_z_kernel did: overlapped tail)
   float* terms;                 // [16]: 0 partial loss (everything but rec), 1 mmd, 2 emo, 3 cau, 4 pair, 5 kl_e, 6 kl_c
   float* dz;                    // [B, 2D]  d(loss)/dz (without reconstruction)
   float* dlat_direct;           // [B, 4D]  KL part of d(loss)/d lat
@@ -133,6 +133,23 @@ __global__ __launch_bounds__(256) void mmd_global_kernel(MmdGlobalArgs a) {
 }
 
 static long long* g_tail_prof = nullptr;
+// tuning hook (carel_gemm_set_variant(210 / 211)): the single-workgroup loss kernel (~50 us on ONE CU) on the library's low-priority side stream
+// while the reconstruction decoder's passes (~100 us, 186 workgroups) run on the caller's stream, joined before the two results meet
+static int g_tail_overlap = 1;
+void tail_overlap_enable(int on) { g_tail_overlap = on ? 1 : 0; }
+struct TailEvents { hipEvent_t fork, join; bool ok; };
+static TailEvents* tail_events() {               // two events per device, created on first use and kept for the life of the process
+  static TailEvents per_dev[16];
+  static bool made[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!made[dev]) {
+    TailEvents& t = per_dev[dev];
+    t.ok = hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
+    made[dev] = true;
+  }
+  return per_dev[dev].ok ? &per_dev[dev] : nullptr;
+}
 
 __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -159,7 +176,8 @@ __global__ __launch_bounds__(1024) void tail_core_kernel(TailCore a) {
     const int b = e / D2, k = e - b * D2;
     const float* row = a.lat + (long)b * 4 * D;
     const float z = (k < D) ? row[k] + a.eps_e[k] * expf(row[D + k]) : row[2 * D + (k - D)] + a.eps_c[k - D] * expf(row[3 * D + (k - D)]);
-    zl[e] = z; dzl[e] = 0.f; a.z[e] = z;
+    zl[e] = z; dzl[e] = 0.f;
+    if (a.z) a.z[e] = z;
   }
   for (int e = t; e < B * D4; e += blockDim.x) {
     const int b = e / D4, k = e - b * D4;
@@ -745,20 +763,36 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   c.mmd_part = nullptr; c.mmd_nblk = 0; c.dz_mmd = nullptr;
+  // The loss kernel and the decoder passes only share their input z and meet again in decoder_total_kernel (terms[0]) and tail_dlat_kernel:
+  // fork the former onto the side stream (the profiling hook keeps the serial order)
+  hipStream_t core_stream = stream;
+  TailEvents* tev = nullptr;
+  if (g_tail_overlap && !a->serial && !g_tail_prof) {
+    hipStream_t side = (hipStream_t)carel_side_stream(0);     // the weight-gradient stream (idle here: the backward pass has not started); a THIRD stream in play made every later kernel slower
+    tev = side ? tail_events() : nullptr;
+    if (tev) {
+      hipLaunchKernelGGL(sample_z_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, stream, c.lat, c.eps_e, c.eps_c, B, D, c.z);
+      if (hipEventRecord(tev->fork, stream) != hipSuccess || hipStreamWaitEvent(side, tev->fork, 0) != hipSuccess)
+        return set_error(CAREL_ERR_HIP, "carel_tail_losses: event fork failed");
+      core_stream = side;
+      c.z = nullptr;
+    }
+  }
   if (c.z_global && c.dis_mode == 0) {
     MmdGlobalArgs g;
     g.zg = c.z_global; g.n = c.n_global; g.B = B; g.D = D; g.rank_stride = c.rank_stride; g.row_offset = c.row_offset;
     g.alpha = c.alpha; g.eps = c.mmd_eps; g.gscale = -c.w_mmd * c.mmd_grad_scale; g.part = w.mmd_part; g.dz = w.dz_mmd;
     const int nblk = (2 * c.n_global + 31) / 32;
     if (nblk > MMD_MAX_BLOCKS) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: global batch too large for the MMD partial buffer");
-    if (D == 24) hipLaunchKernelGGL(mmd_global_kernel<24>, dim3(nblk), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL(mmd_global_kernel<32>, dim3(nblk), dim3(256), 0, stream, g);
+    if (D == 24) hipLaunchKernelGGL(mmd_global_kernel<24>, dim3(nblk), dim3(256), 0, core_stream, g);
+    else hipLaunchKernelGGL(mmd_global_kernel<32>, dim3(nblk), dim3(256), 0, core_stream, g);
     if ((rc = check_launch("mmd_global_kernel"))) return rc;
     c.mmd_part = w.mmd_part; c.mmd_nblk = nblk; c.dz_mmd = w.dz_mmd;
   }
   c.prof = g_tail_prof;
-  hipLaunchKernelGGL(tail_core_kernel, dim3(1), dim3(1024), lds, stream, c);
+  hipLaunchKernelGGL(tail_core_kernel, dim3(1), dim3(1024), lds, core_stream, c);
   if ((rc = check_launch("tail_core_kernel"))) return rc;
+  if (tev && hipEventRecord(tev->join, core_stream) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: event record failed");
 
   DecArgs d;
   d.B = B; d.D2 = 2 * D; d.V = V; d.z = (const float*)a->z; d.w = (const float*)a->dec_w; d.b = (const float*)a->dec_b;
@@ -789,13 +823,14 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
   hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 1, w.rowstat);
   DEC_LAUNCH(2, lds2);
   hipLaunchKernelGGL(decoder_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const float*)w.part, chunks, B, 2, w.rowstat);
-  hipLaunchKernelGGL(decoder_total_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.rowstat, B, d.gscale, (float*)a->terms);
   DEC_LAUNCH(3, lds3);
 #undef DEC_LAUNCH
   if ((rc = check_launch("decoder kernels"))) return rc;
   // d(loss)/d lat, unscaled (grad_output is applied in carel_tail_backward)
   // sum the decoder's per-chunk dz partials into slot 0 (in place is safe: block c only reads column c of every part)
   hipLaunchKernelGGL(reduce_parts16_kernel, dim3((B * 2 * D + 15) / 16), dim3(256), 0, stream, (const float*)w.dz_part, w.dz_part, B * 2 * D, chunks);
+  if (tev && hipStreamWaitEvent(stream, tev->join, 0) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: event join failed");
+  hipLaunchKernelGGL(decoder_total_kernel, dim3(1), dim3(256), 0, stream, (const float*)w.rowstat, B, d.gscale, (float*)a->terms);   // reads terms[0] of the loss kernel
   hipLaunchKernelGGL(tail_dlat_kernel, dim3((B * 2 * D + 255) / 256), dim3(256), 0, stream, (const float*)w.dz_core, (const float*)w.dz_part,
                      1, (const float*)w.dlat_direct, (const float*)a->lat, (const float*)a->eps_e, (const float*)a->eps_c, B, D, 1.0f, w.dlat);
   return check_launch("tail_dlat_kernel");

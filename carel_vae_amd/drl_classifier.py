@@ -800,6 +800,7 @@ class DrlClassifier(nn.Module):
         ops.tail_latents(ta)
         if self._dp is not None:
             self._dp.fill_global(ta, c)                  # all-gather z, all-reduce label sum
+        ta.serial = 0 if self.overlap_wgrad else 1       # side stream allowed: the loss kernel runs beside the decoder passes
         ops.tail_losses(ta)
         c.ea, c.ta, c.ws = ea, ta, ws
         c.keep = (W, G, xl)

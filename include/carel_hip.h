@@ -30,7 +30,7 @@ extern "C" {
 #define CAREL_ERR_HIP (-3)    /* a HIP runtime call or launch failed    */
 
 /* ABI version of this header; carel_abi_version() must return the same number. */
-#define CAREL_ABI_VERSION 5
+#define CAREL_ABI_VERSION 6
 
 int carel_abi_version(void);
 /* Checks that `device` is a gfx950 part and fills the library's only per-device state, immutable afterwards: the 20-KiB GELU table of
@@ -413,6 +413,10 @@ typedef struct carel_tail_args {
   void* dx_last_f32;                 /* f32 [B*S, 768] (packed: [n_rows, 768]) */
   const void* cls_rows;              /* int32 [B]: row of each sample's [CLS] token in x_last / dx_last; NULL = b*seq_len */
   int32_t n_rows;                    /* rows of dx_last to clear (0 = B*seq_len) */
+  int32_t serial;                    /* ABI 6.  0: carel_tail_losses may run its single-workgroup loss kernel on the library's side stream
+                                        (carel_side_stream(0)) beside the decoder passes on `stream`, forked and joined with events inside
+                                        the call -- `stream` order is all a caller ever sees; 1: every kernel on `stream`, in order
+                                        (serial kernel traces, per-launch timing) */
 } carel_tail_args;
 
 int64_t carel_tail_workspace_floats(int32_t batch, int32_t ec_dim, int32_t bow_dim);

@@ -41,7 +41,7 @@ def oracle_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, it, train, seed, **kw
     return out, pooled, {k: v.grad for k, v in Pg.items()}, xg.grad
 
 
-def hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, drop, **kw):
+def hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, drop, serial=0, **kw):
     dev = "cuda"
     W = {k: v.to(dev) for k, v in P.items()}
     G = {k: torch.full_like(v, float("nan")) for k, v in W.items()}
@@ -51,11 +51,28 @@ def hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, S, V, it, drop, **kw):
     xl = x_last.to(dev)
     a = ops.tail_args(buf, xl, W, labels, eps_e.to(dev), eps_c.to(dev), opt, ops.kl_anneal_weight(it, opt), grads=G, drop=drop, **kw)
     a._keep = (W, G, labels, xl)
+    a.serial = serial
     ops.tail_latents(a)
     ops.tail_losses(a)
     ops.tail_backward(a, None)
     torch.cuda.synchronize()
     return buf, G
+
+
+@pytest.mark.parametrize("B,V,train", [(64, 23771, True), (8, 257, False)])
+def test_loss_kernel_beside_the_decoder_passes_same_bits(B, V, train):
+    """carel_tail_args.serial = 0 (default: the single-workgroup loss kernel on the library's side stream while the decoder passes run on the
+    caller's stream, joined inside the call) against serial = 1 (one stream, in order): every output and gradient bit-identical, also
+    when the call is repeated back to back (the side stream's events are re-used)."""
+    cfg, opt, P, x_last, batch, eps_e, eps_c = setup(B, 32, V, seed=5)
+    drop = (opt.dropout if train else 0.0, 11, 0)
+    ref_buf, ref_G = hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, 32, V, 3, drop, serial=1)
+    for rep in range(3):
+        buf, G = hip_tail(P, x_last, batch, eps_e, eps_c, opt, B, 32, V, 3, drop, serial=0)
+        assert torch.equal(buf.terms, ref_buf.terms), rep
+        assert torch.equal(buf.z, ref_buf.z) and torch.equal(buf.dx_last, ref_buf.dx_last), rep
+        for k in G:
+            assert torch.equal(torch.nan_to_num(G[k]), torch.nan_to_num(ref_G[k])), (rep, k)
 
 
 def close(got, ref, rtol, atol, name):
