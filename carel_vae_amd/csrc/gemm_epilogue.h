@@ -160,39 +160,42 @@ __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col,
 // rounded to bf16, are functions of 16 bits.  The table holds them (low / high half of a word) for every bf16 u with
 // 2^-16 <= |u| < 16 -- 20 exponents x 128 mantissas x 2 signs = 5 120 words, 20 KiB, filled once per process by the same device
 // functions the arithmetic path uses, so both paths give the same bits -- and is copied into the LDS behind the staging buffers at
-// kernel start.  Finite |u| >= 16 needs no table (gelu = u or -0.0, gelu' = 1 or 0: what the arithmetic gives once exp(-u^2 / 2)
-// underflows).  An 8-column group with any lane outside both ranges (|u| < 1.5e-5, Inf, NaN) takes the arithmetic path for the
-// whole wave (< 1 % of the groups on N(0, 1) pre-activations).  The erf + exp arithmetic was what bounded this epilogue:
+// kernel start.  An 8-column group with any lane outside the table's range (|u| < 1.5e-5, |u| >= 16, Inf, NaN) takes the arithmetic
+// path for the whole wave (< 1 % of the groups on N(0, 1) pre-activations).  The erf + exp arithmetic was what bounded this epilogue:
 // FFN1 forward 8192 x 3072 x 768: 41-43 us with the bias -> bf16 epilogue, 55-58 with GELU, one output or two
 // (tools/bench_ffn1_epilogue.py).
 constexpr int LUT_EXP_LO = 111, LUT_NEXP = 20, LUT_HALF = LUT_NEXP * 128, LUT_WORDS = 2 * LUT_HALF, LUT_BYTES = LUT_WORDS * 4;
+// Two elements per instruction: the bf16 pair of a 32-bit word is masked, offset (v_pk_add_u16), range-checked (v_pk_min_u16 + one 32-bit
+// compare) and turned into two table indices (v_pk_mad_u16 with the sign bits) as a pair; the halves of the two looked-up words are
+// merged with one v_perm_b32 per output word.  5.5 VALU instructions per element (the element-by-element form compiled to ~19, and the
+// GELU epilogue of the 256 x 192 tile to ~1 900 per lane: 8 us per round of tiles).  A finite |u| >= 16, a NaN or an |u| < 2^-16 anywhere
+// in the wave's group sends the group to the arithmetic path (same results; none occurs in practice).
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 __device__ __forceinline__ bool gelu_lut8(const uint32_t* lut, const uint4 o, uint4& g, uint4& d) {
   const uint32_t w[4] = {o.x, o.y, o.z, o.w};
-  uint32_t idx[8], hb[8];
-  bool ok = true, big_any = false;
+  u16x2 idx[4];
+  bool ok = true;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const uint32_t h = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
-    const uint32_t a = h & 0x7fffu;
-    const uint32_t i = a - (uint32_t)(LUT_EXP_LO << 7);
-    const bool in = i < (uint32_t)LUT_HALF;
-    // finite |u| >= 16: exp(-u^2 / 2) underflows to 0 and erf is +-1 in fp32, so the arithmetic gives gelu = u / -0.0 and gelu' = 1 / +0.0
-    const bool big = a - (uint32_t)((LUT_EXP_LO + LUT_NEXP) << 7) < (uint32_t)((255 - LUT_EXP_LO - LUT_NEXP) << 7);
-    ok = ok && (in || big);
-    big_any = big_any || big;
-    idx[e] = in ? i + (h >> 15) * (uint32_t)LUT_HALF : 0u;
-    hb[e] = big ? ((h & 0x8000u) ? 0x00008000u : (0x3F800000u | h)) : 0u;       // the word the table would hold (never 0 for a big u)
+  for (int q = 0; q < 4; ++q) {
+    const u16x2 a = __builtin_bit_cast(u16x2, w[q] & 0x7fff7fffu);
+    const u16x2 lo = {(unsigned short)(LUT_EXP_LO << 7), (unsigned short)(LUT_EXP_LO << 7)};
+    const u16x2 i = a - lo;                                                          // wraps past 65535 below the table: out of range either way
+    const u16x2 lim = {(unsigned short)(LUT_HALF - 1), (unsigned short)(LUT_HALF - 1)};
+    const u16x2 c = __builtin_elementwise_min(i, lim);
+    ok = ok && (__builtin_bit_cast(uint32_t, c) == __builtin_bit_cast(uint32_t, i));
+    const u16x2 sg = __builtin_bit_cast(u16x2, (w[q] >> 15) & 0x00010001u);
+    const u16x2 hf = {(unsigned short)LUT_HALF, (unsigned short)LUT_HALF};
+    idx[q] = sg * hf + i;                                                            // < 2 * LUT_HALF when in range
   }
   if (!__all(ok)) return false;                 // wave-uniform: the whole wave computes this group
   uint32_t t[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) t[e] = lut[idx[e]];
-  if (__any(big_any)) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = hb[e] ? hb[e] : t[e];
-  }
-  g = uint4{(t[0] & 0xffffu) | (t[1] << 16), (t[2] & 0xffffu) | (t[3] << 16), (t[4] & 0xffffu) | (t[5] << 16), (t[6] & 0xffffu) | (t[7] << 16)};
-  d = uint4{(t[0] >> 16) | (t[1] & 0xffff0000u), (t[2] >> 16) | (t[3] & 0xffff0000u), (t[4] >> 16) | (t[5] & 0xffff0000u), (t[6] >> 16) | (t[7] & 0xffff0000u)};
+  for (int q = 0; q < 4; ++q) { t[2 * q] = lut[idx[q].x]; t[2 * q + 1] = lut[idx[q].y]; }
+  // word = gelu | gelu' << 16: low halves of a pair -> g, high halves -> d
+  g = uint4{__builtin_amdgcn_perm(t[1], t[0], 0x05040100u), __builtin_amdgcn_perm(t[3], t[2], 0x05040100u),
+            __builtin_amdgcn_perm(t[5], t[4], 0x05040100u), __builtin_amdgcn_perm(t[7], t[6], 0x05040100u)};
+  d = uint4{__builtin_amdgcn_perm(t[1], t[0], 0x07060302u), __builtin_amdgcn_perm(t[3], t[2], 0x07060302u),
+            __builtin_amdgcn_perm(t[5], t[4], 0x07060302u), __builtin_amdgcn_perm(t[7], t[6], 0x07060302u)};
   return true;
 }
 
