@@ -811,6 +811,9 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
         const int npn = gemm_pp_pick_tn(q, splits);
         const long wgs = npn ? (long)(q.M / 256) * (q.N / (96 * npn)) * splits : 0;
         // (the same floor as gemm_pp_wgrad_splits: whatever carel_gemm_wgrad_splits proposes for this kernel must be taken by it)
+#ifdef CAREL_GEMM_ABLATE
+        if (npn == 2 && g_gemm_variant >= 61 && g_gemm_variant <= 68) return gemm_pp_launch_tn_dbg(q, npn, splits, g_gemm_variant - 60, stream);
+#endif
         if (npn && (g_gemm_variant == 3 || wgs >= 64)) return gemm_pp_launch_tn(q, npn, splits, stream);
       }
       if (a->K % (64 * splits) || !((a->M % 128 == 0 && a->N % 128 == 0) || (a->M % 256 == 0 && a->N % 192 == 0)))

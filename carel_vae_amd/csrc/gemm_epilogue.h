@@ -320,6 +320,9 @@ int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
+#ifdef CAREL_GEMM_ABLATE
+int gemm_pp_launch_tn_dbg(const GemmParams& p, int npn, int splits, int dbg, hipStream_t s);
+#endif
 int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipStream_t s);
 // pair split-K (two workgroups per 256 x 192 tile, each half of K; gemm_pp.hip): 1 if this problem should run that way
 int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi);

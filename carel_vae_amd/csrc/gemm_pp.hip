@@ -806,6 +806,12 @@ int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s) {  
 #undef PPD
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_dbg: (npn, dbg) = (%d, %d) not built", npn, dbg);
 }
+int gemm_pp_launch_tn_dbg(const GemmParams& p, int npn, int splits, int dbg, hipStream_t s) {     // weight-gradient form, npn 2, wide schedule
+#define PPT(D) if (npn == 2 && dbg == D) return launch_pp<2, true, true, EPI_SLAB_F32, D, true>(p, splits, s)
+  PPT(1); PPT(2); PPT(3); PPT(4); PPT(6); PPT(7); PPT(8);
+#undef PPT
+  return set_error(CAREL_ERR_ARG, "gemm_pp_launch_tn_dbg: (npn, dbg) = (%d, %d) not built", npn, dbg);
+}
 #endif
 
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {
