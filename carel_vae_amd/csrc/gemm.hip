@@ -461,6 +461,7 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     if (p.pair_flags && p.ldc == p.N && !p.colsum_part && g_gemm_variant == 0 && gemm_pp_pick_pair(p, BT, EPI)) return gemm_pp_launch_pair(p, BT, EPI, s);
     // (a shape only the ping-pong kernel takes -- M not a multiple of 128 -- runs on it whatever the tile-count threshold says:
     // gemm_shape_ok accepted it on that kernel's account)
+    if (!BT && g_gemm_variant == 0 && p.ldc == p.N && gemm_tri_pick(p, EPI)) return gemm_tri_launch(p, EPI, s);
     const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
     const int npn = gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60 || only_pp) ? 1 : -g_pp_min_tiles);
 #ifdef CAREL_GEMM_ABLATE
@@ -732,6 +733,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
+  if (v >= 220 && v <= 225) { gemm_tri_enable(v - 220); return CAREL_OK; }             // three-group kernel for the N = 768 forward GEMMs off (default) / on
   if (v == 210 || v == 211) { tail_overlap_enable(v - 210); return CAREL_OK; }           // VAE tail: loss kernel on the side stream beside the decoder passes off / on (default)
   if (v == 200 || v == 201) { gemm_pp_pair_enable(v - 200); return CAREL_OK; }        // pair split-K of the N = 768, K >= 1536 GEMMs off (default: measured slower) / on
   if (v == 170 || v == 171) { gemm_pp_epi_prefetch(v - 170); return CAREL_OK; }       // ping-pong kernel: epilogue inputs requested before the main loop off / on

@@ -319,6 +319,9 @@ void gemm_pp_epi_prefetch(int on);
 int gemm_pp_pick_tn(const GemmParams& p, int splits);
 int gemm_pp_wgrad_splits(int M, int N, long K);
 void gemm_pp_wgrad_force(int s);
+int gemm_tri_pick(const GemmParams& p, int epi);                 // gemm_tri.hip: the three-group kernel (experiment, hook 220 / 221)
+int gemm_tri_launch(const GemmParams& p, int epi, hipStream_t s);
+void gemm_tri_enable(int on);
 int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
 #ifdef CAREL_GEMM_ABLATE
 int gemm_pp_launch_tn_dbg(const GemmParams& p, int npn, int splits, int dbg, hipStream_t s);

@@ -614,3 +614,36 @@ def _pair_case(case, lib):
     assert torch.equal(unz, single) and torch.equal(ws[-4096:], before)
     if epi == L.EPI_ADD_F32:
         assert rel_err(first, A.double() @ B.double() + resid.double()) < TOL
+
+
+@pytest.mark.parametrize("M,K,epi", [(8192, 3072, "drop_resid"), (8192, 768, "bias"), (7936, 768, "add_f32"), (7999, 2304, "drop_resid")])
+def test_three_group_kernel_has_the_ping_pong_kernels_bits(M, K, epi):
+    """gemm_tri.hip (hook 221, off by default: an experiment that measured no faster -- its header): the 256 x 96 tile by twelve waves in
+    three rotating groups adds each accumulator's K tiles in the ping-pong kernel's order, so every output bit is that kernel's; exact
+    small integers against fp64 as well (a stage overwritten early or read late shows as an integer difference); ragged M; guard rows."""
+    lib = L.load()
+    N = 768
+    code = {"drop_resid": L.EPI_BIAS_DROP_RESID, "bias": L.EPI_BIAS_BF16, "add_f32": L.EPI_ADD_F32}[epi]
+    A, B = _rand((M, K), 1, 91).bfloat16(), _rand((N, K), 0.05, 92).bfloat16()
+    resid, bias = _rand((M, N), 1, 93), _rand((N,), 0.1, 94)
+    outs = {}
+    for hook in (220, 221):
+        L.check(lib.carel_gemm_set_variant(hook))
+        try:
+            of = torch.full((M + 8, N), 7.0, device="cuda"); ob = torch.full((M + 8, N), 7.0, device="cuda").bfloat16()
+            gemm(A, B, L.GEMM_NT, code, M, N, K, out_f32=of, out_bf16=ob, bias=bias, resid=resid, drop=(9, 5, 3 * N, 0.1))
+            torch.cuda.synchronize()
+            outs[hook] = (of, ob)
+        finally:
+            L.check(lib.carel_gemm_set_variant(220))
+    assert torch.equal(outs[220][0], outs[221][0]) and torch.equal(outs[220][1], outs[221][1])
+    assert bool((outs[221][0][M:] == 7.0).all()) and bool((outs[221][1][M:].float() == 7.0).all())
+    if epi == "add_f32":
+        Ai, Bi, ri = _ints((M, K), 1), _ints((N, K), 2), _ints((M, N), 3).float()
+        L.check(lib.carel_gemm_set_variant(221))
+        try:
+            of = torch.empty((M, N), device="cuda")
+            gemm(Ai, Bi, L.GEMM_NT, code, M, N, K, out_f32=of, resid=ri)
+        finally:
+            L.check(lib.carel_gemm_set_variant(220))
+        assert torch.equal(of.double(), Ai.double() @ Bi.double().t() + ri.double())

@@ -1,0 +1,33 @@
+import sys, statistics, torch
+sys.path.insert(0, "/root/repo")
+from carel_vae_amd import _lib as L
+from tests.gpu_util import gemm
+lib = L.load()
+g = torch.Generator().manual_seed(0)
+def rnd(*s): return (torch.randn(s, generator=g) * 0.5).cuda().bfloat16()
+def timed(fn, n=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+for (M, N, K, epi, name) in [(8192, 768, 3072, L.EPI_BIAS_BF16, "bias"), (8192, 768, 768, L.EPI_BIAS_BF16, "bias"), (8192, 768, 3072, L.EPI_BIAS_DROP_RESID, "drop_resid"),
+                             (8192, 768, 768, L.EPI_BIAS_DROP_RESID, "drop_resid"), (7936, 768, 3072, L.EPI_ADD_F32, "add_f32 ragged M")]:
+    A, B = rnd(M, K), rnd(N, K)
+    outs = {}
+    bias, resid = torch.randn(N, device="cuda"), torch.randn((M, N), device="cuda")
+    for hook in (220, 221):
+        L.check(lib.carel_gemm_set_variant(hook))
+        kw = dict(out_bf16=torch.zeros((M, N), device="cuda", dtype=torch.bfloat16), out_f32=torch.zeros((M, N), device="cuda"), bias=bias,
+                  resid=resid, drop=(1, 2, 0, 0.1))
+        f = lambda: gemm(A, B, L.GEMM_NT, epi, M, N, K, **kw)
+        f(); torch.cuda.synchronize()
+        outs[hook] = (kw["out_bf16"].clone(), kw["out_f32"].clone())
+        ts = [timed(f) for _ in range(5)]
+        print("%-18s M=%d K=%d hook %d: %.1f us" % (name, M, K, hook, statistics.median(ts)), flush=True)
+    same = torch.equal(outs[220][0], outs[221][0]) and torch.equal(outs[220][1], outs[221][1])
+    print("   bit-identical to the ping-pong kernel:", same, flush=True)
+    if not same:
+        d = (outs[220][1] - outs[221][1]).abs().max().item(), (outs[220][0].float() - outs[221][0].float()).abs().max().item()
+        print("   max abs diff f32 / bf16 outputs:", d)
+L.check(lib.carel_gemm_set_variant(220))
