@@ -160,37 +160,54 @@ __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col,
 // rounded to bf16, are functions of 16 bits.  The table holds them (low / high half of a word) for every bf16 u with
 // 2^-16 <= |u| < 16 -- 20 exponents x 128 mantissas x 2 signs = 5 120 words, 20 KiB, filled once per process by the same device
 // functions the arithmetic path uses, so both paths give the same bits -- and is copied into the LDS behind the staging buffers at
-// kernel start.  An 8-column group with any lane outside the table's range (|u| < 1.5e-5, |u| >= 16, Inf, NaN) takes the arithmetic
-// path for the whole wave (< 1 % of the groups on N(0, 1) pre-activations).  The erf + exp arithmetic was what bounded this epilogue:
+// kernel start.  Finite |u| >= 16 needs no table (gelu = u or -0.0, gelu' = 1 or 0: what the arithmetic gives once exp(-u^2 / 2)
+// underflows).  An 8-column group with any lane outside both ranges (|u| < 1.5e-5, Inf, NaN) takes the arithmetic path for the
+// whole wave (< 1 % of the groups on N(0, 1) pre-activations).  The erf + exp arithmetic was what bounded this epilogue:
 // FFN1 forward 8192 x 3072 x 768: 41-43 us with the bias -> bf16 epilogue, 55-58 with GELU, one output or two
 // (tools/bench_ffn1_epilogue.py).
 constexpr int LUT_EXP_LO = 111, LUT_NEXP = 20, LUT_HALF = LUT_NEXP * 128, LUT_WORDS = 2 * LUT_HALF, LUT_BYTES = LUT_WORDS * 4;
 // Two elements per instruction: the bf16 pair of a 32-bit word is masked, offset (v_pk_add_u16), range-checked (v_pk_min_u16 + one 32-bit
 // compare) and turned into two table indices (v_pk_mad_u16 with the sign bits) as a pair; the halves of the two looked-up words are
 // merged with one v_perm_b32 per output word.  5.5 VALU instructions per element (the element-by-element form compiled to ~19, and the
-// GELU epilogue of the 256 x 192 tile to ~1 900 per lane: 8 us per round of tiles).  A finite |u| >= 16, a NaN or an |u| < 2^-16 anywhere
-// in the wave's group sends the group to the arithmetic path (same results; none occurs in practice).
+// GELU epilogue of the 256 x 192 tile to ~1 900 per lane: 8 us per round of tiles).  A NaN, an Inf or an |u| < 2^-16 anywhere in the wave's
+// group sends the group to the arithmetic path (same results); finite |u| >= 16 get their (table-free) words in a pass that only runs
+// when the wave holds one.
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 __device__ __forceinline__ bool gelu_lut8(const uint32_t* lut, const uint4 o, uint4& g, uint4& d) {
   const uint32_t w[4] = {o.x, o.y, o.z, o.w};
-  u16x2 idx[4];
-  bool ok = true;
+  u16x2 idx[4], off[4];
+  bool ok = true, big_any = false;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u16x2 a = __builtin_bit_cast(u16x2, w[q] & 0x7fff7fffu);
     const u16x2 lo = {(unsigned short)(LUT_EXP_LO << 7), (unsigned short)(LUT_EXP_LO << 7)};
-    const u16x2 i = a - lo;                                                          // wraps past 65535 below the table: out of range either way
+    const u16x2 i = a - lo;                                                          // wraps past 51 000 below the table
+    // finite and not below the table: i < (255 - LUT_EXP_LO) << 7; inside the table: i < LUT_HALF; in between: finite |u| >= 16
+    const u16x2 fin = {(unsigned short)(((255 - LUT_EXP_LO) << 7) - 1), (unsigned short)(((255 - LUT_EXP_LO) << 7) - 1)};
     const u16x2 lim = {(unsigned short)(LUT_HALF - 1), (unsigned short)(LUT_HALF - 1)};
     const u16x2 c = __builtin_elementwise_min(i, lim);
-    ok = ok && (__builtin_bit_cast(uint32_t, c) == __builtin_bit_cast(uint32_t, i));
+    ok = ok && (__builtin_bit_cast(uint32_t, __builtin_elementwise_min(i, fin)) == __builtin_bit_cast(uint32_t, i));
+    big_any = big_any || (__builtin_bit_cast(uint32_t, c) != __builtin_bit_cast(uint32_t, i));
     const u16x2 sg = __builtin_bit_cast(u16x2, (w[q] >> 15) & 0x00010001u);
     const u16x2 hf = {(unsigned short)LUT_HALF, (unsigned short)LUT_HALF};
-    idx[q] = sg * hf + i;                                                            // < 2 * LUT_HALF when in range
+    idx[q] = sg * hf + c;                                                            // < 2 * LUT_HALF always (big values look up the table's last entry)
+    off[q] = i;
   }
-  if (!__all(ok)) return false;                 // wave-uniform: the whole wave computes this group
+  if (!__all(ok)) return false;                 // wave-uniform: the whole wave computes this group (|u| < 2^-16, Inf, NaN somewhere)
   uint32_t t[8];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { t[2 * q] = lut[idx[q].x]; t[2 * q + 1] = lut[idx[q].y]; }
+  if (__any(big_any)) {
+    // finite |u| >= 16 needs no table: exp(-u^2 / 2) underflows to 0 and erf is +-1 in fp32, so the arithmetic gives gelu = u / -0.0 and
+    // gelu' = 1 / +0.0 -- the word the table would hold
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t h = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+      const uint32_t ie = (e & 1) ? (uint32_t)off[e >> 1].y : (uint32_t)off[e >> 1].x;
+      const uint32_t hb = (h & 0x8000u) ? 0x00008000u : (0x3F800000u | h);
+      t[e] = ie >= (uint32_t)LUT_HALF ? hb : t[e];
+    }
+  }
   // word = gelu | gelu' << 16: low halves of a pair -> g, high halves -> d
   g = uint4{__builtin_amdgcn_perm(t[1], t[0], 0x05040100u), __builtin_amdgcn_perm(t[3], t[2], 0x05040100u),
             __builtin_amdgcn_perm(t[5], t[4], 0x05040100u), __builtin_amdgcn_perm(t[7], t[6], 0x05040100u)};
