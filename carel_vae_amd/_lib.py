@@ -66,7 +66,8 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("batch", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
-                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p), ("rel_bias_dist", C.c_void_p), ("d_rel_bias_dist", C.c_void_p)]
+                ("drop_p", C.c_float), ("cu_seqlens", C.c_void_p), ("rel_bias_dist", C.c_void_p), ("d_rel_bias_dist", C.c_void_p),
+                ("q_rows", C.c_int32)]
 
 
 class TailArgs(C.Structure):

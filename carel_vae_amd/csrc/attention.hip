@@ -100,6 +100,7 @@ struct AttnParams {
   Dropout drop;             // element index ((b*NH + h)*S + q)*S + k
   const int* cu;            // packed: rows [cu[b], cu[b+1]) belong to sample b (null = dense, rows b*S ..)
   const float* rel;         // MPNet relative-position bias by distance: [NH][256], entry 127 + (key - query); null = none
+  int qlim;                 // 0 = all; else only the first qlim (multiple of 32) positions of every sample are live queries
   float* drel;              // bwd: its gradient by distance, [B * NH][256]: row (sample, head) is read-modify-written by that workgroup alone (every
                             // layer adds to it in stream order) -- no atomics anywhere, so the table gradient is bit-reproducible
 };
@@ -139,13 +140,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int hh = lane >> 5;
   // Q fragments (B operand of S^T = K Q^T): Q[q0 + (l&31)][16s + 8hh + j] -- requested before the wait for the staged K / V images
   bf16x8 qf[4];
-  if (wave < nkt) {
+  const bool qact = wave < nkt && (p.qlim == 0 || q0 < p.qlim);       // wave-uniform: this wave's 32 queries exist and are wanted
+  if (qact) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = load_frag_global(qbase + (long)(q0 + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (wave >= nkt) return;                       // no barrier below this point
+  if (!qact) return;                             // no barrier below this point
 
   f32x16 x[4];
 #pragma unroll
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
   const long row0 = p.cu ? (long)p.cu[b] : (long)b * S;
   const int len = p.cu ? (p.cu[b + 1] - p.cu[b]) : S;
   const int nt = (len + 31) >> 5, rows = nt << 5;
+  const int ntq = p.qlim ? min(nt, p.qlim >> 5) : nt;         // query tiles that carry a gradient (q_rows: the rest have dctx = 0)
   const bf16_t* qbase = p.qkv + row0 * QKV_LD + h * HD;
   const bf16_t* dobase = p.dctx + row0 * HID + h * HD;
   const bf16_t* obase = p.ctx + row0 * HID + h * HD;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     const uint32_t hbase = (uint32_t)(((long)b * NH + h) * S * S) + (uint32_t)(key & ~1) + (uint32_t)((16 * (lane & 1) + 4 * hh) * S) + p.drop.idx_offset;
     // (recording the forward's dropout decisions as bits and reading them here instead of re-hashing was built and measured:
     // forward +1 us, backward -0.5 us -- the hash hides behind the MFMA / LDS latencies of the loop; not kept)
-    for (int qt = 0; qt < nt; ++qt) {
+    for (int qt = 0; qt < ntq; ++qt) {
       f32x16 sa, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
   {
     const int g = lane >> 4, g1 = g & 1, h2 = g >> 1, qq = (lane & 15) >> 2, pp = lane & 3;
-    for (int ks = 0; ks < (rows >> 4); ++ks) {
+    for (int ks = 0; ks < (wave < ntq ? (rows >> 4) : 0); ++ks) {        // (queries past q_rows: dQ = 0, stored below)
       // B operand: dS^T[k = 16ks + 8*h2 + j][q = kw + (l&31)] via transposed reads of the dS^T image
       const int kr0 = 16 * ks + 8 * h2 + qq, kr1 = kr0 + 4;
       const int qcol = kw + 16 * g1 + 4 * pp;
@@ -447,6 +450,8 @@ static int attn_prepare(const carel_attn_args* a, AttnParams* p, const char* who
   p->lse = (float*)a->lse; p->dctx = (const bf16_t*)a->dctx; p->dqkv = (bf16_t*)a->dqkv;
   p->B = a->batch; p->S = a->seq_len; p->cu = (const int*)a->cu_seqlens;
   p->rel = (const float*)a->rel_bias_dist; p->drel = (float*)a->d_rel_bias_dist;
+  if (a->q_rows < 0 || a->q_rows > 128 || (a->q_rows & 31)) return set_error(CAREL_ERR_ARG, "%s: q_rows must be 0, 32, 64 or 96", who);
+  p->qlim = a->q_rows >= a->seq_len ? 0 : a->q_rows;
   if (bwd && p->rel && !p->drel) return set_error(CAREL_ERR_ARG, "%s: rel_bias_dist needs d_rel_bias_dist in the backward", who);
   p->drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   return CAREL_OK;

@@ -245,8 +245,10 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * i; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
     at.cu_seqlens = whole ? a->cu_seqlens : nullptr;
     at.rel_bias_dist = a->rel_bias_dist; at.d_rel_bias_dist = nullptr;
-    if ((rc = carel_attention_fwd(&at, stream))) return rc;
     const bool cls_only = a->n_cls > 0 && i + 1 == a->n_layers;
+    // the [CLS]-only last layer reads one context row per sample (position 0): the other query tiles are never computed
+    at.q_rows = cls_only ? 32 : 0;
+    if ((rc = carel_attention_fwd(&at, stream))) return rc;
     if (cls_only && !whole) return set_error(CAREL_ERR_ARG, "carel_encoder_forward: internal: [CLS]-only layer on a partial batch");
     long R = T;                                  // rows of the row-wise half of this layer
     const int fixed = cls_only ? GEMM_EX_FIXED_ROWS : 0;
@@ -425,6 +427,7 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   at.drop_seed = a->drop_seed; at.drop_site = 1 + 3 * layer; at.drop_idx_offset = aoff; at.drop_p = a->attn_dropout;
   at.cu_seqlens = a->cu_seqlens;
   at.rel_bias_dist = a->rel_bias_dist; at.d_rel_bias_dist = a->d_rel_bias_dist;
+  at.q_rows = cls_only ? 32 : 0;                 // dctx is zero off the [CLS] rows: only the first query tile carries a gradient
   if (a->tok_row && layer + 1 == a->n_layers) {
     // packed: the attention backward writes only rows that belong to a sample; the filler rows up to the next multiple
     // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows.  Once per backward pass

@@ -255,6 +255,10 @@ typedef struct carel_attn_args {
   void* d_rel_bias_dist;       /* bwd, required with rel_bias_dist: f32 [batch * heads][256], row (sample, head) ADDED to by that workgroup alone
                                   (no atomics: bit-reproducible); the caller zeroes it once per step -- every layer adds to it -- and folds
                                   it into the table gradient with carel_relpos_reduce */
+  int32_t q_rows;              /* ABI 6.  0 = every query row; 32 / 64 / 96: only the first q_rows positions of every sample are queries --
+                                  forward: ctx / lse rows past them are NOT written; backward: dctx rows past them are taken as zero and
+                                  their dQ rows are written as zeros.  Exact where nothing downstream reads the other rows: the encoder's
+                                  last layer when only [CLS] (position 0) is read after it (carel_encoder_args.n_cls) */
 } carel_attn_args;
 
 int carel_attention_fwd(const carel_attn_args* args, void* stream);

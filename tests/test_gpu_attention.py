@@ -15,11 +15,12 @@ pytestmark = pytest.mark.gpu
 NH, HD, H = 12, 64, 768
 
 
-def run_attn(qkv, mask, B, S, drop=(0, 0, 0, 0.0), dctx=None):
+def run_attn(qkv, mask, B, S, drop=(0, 0, 0, 0.0), dctx=None, q_rows=0):
     lib = L.load()
     a = L.AttnArgs()
-    ctx = torch.empty((B * S, H), device="cuda", dtype=torch.bfloat16)
-    lse = torch.empty((B, NH, S), device="cuda")
+    a.q_rows = q_rows
+    ctx = torch.full((B * S, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    lse = torch.full((B, NH, S), float("nan"), device="cuda")
     a.qkv, a.attention_mask, a.ctx, a.lse = qkv.data_ptr(), (None if mask is None else mask.data_ptr()), ctx.data_ptr(), lse.data_ptr()
     a.batch, a.seq_len, a.heads, a.head_dim = B, S, NH, HD
     a.drop_seed, a.drop_site, a.drop_idx_offset, a.drop_p = drop
@@ -222,3 +223,30 @@ def test_relative_position_bias_forward_backward_and_table_gradient(packed):
         else:
             assert all(torch.equal(x, y) for x, y in zip(cur, ref)), it
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_query_row_limit_is_exact_where_the_other_rows_are_dead(p):
+    """carel_attn_args.q_rows = 32 (the encoder's [CLS]-only last layer): the first 32 positions of every sample are the only queries.
+    Forward: their ctx / lse rows carry the bits of the unrestricted launch, the other rows are not written.  Backward, with dctx zero off
+    those rows (what the encoder hands over): every dK / dV / dQ bit of the unrestricted launch -- the skipped query tiles only ever
+    contributed exact zeros -- and zeros for the dQ rows past the limit."""
+    B, S = 5, 128
+    g = torch.Generator().manual_seed(77)
+    qkv = (torch.randn((B * S, 3 * H), generator=g) * 1.5).cuda().bfloat16()
+    mask = torch.ones((B, S), dtype=torch.int64); mask[1, 100:] = 0; mask[3, 40:] = 0
+    mask = mask.cuda()
+    dctx = torch.zeros((B * S, H), device="cuda", dtype=torch.bfloat16)
+    live = torch.zeros(B * S, dtype=torch.bool, device="cuda").view(B, S)
+    live[:, 0] = True; live[:, 17] = True                       # [CLS] and one more row inside the first tile
+    dctx.view(B, S, H)[live] = (torch.randn((int(live.sum()), H), generator=g)).cuda().bfloat16()
+    drop = (5, 7, 64, p)
+    ctx0, lse0, dq0 = run_attn(qkv, mask, B, S, drop, dctx)
+    ctx1, lse1, dq1 = run_attn(qkv, mask, B, S, drop, dctx, q_rows=32)
+    first = torch.zeros((B, S), dtype=torch.bool, device="cuda"); first[:, :32] = True
+    assert torch.equal(ctx1.view(B, S, H)[first], ctx0.view(B, S, H)[first])
+    assert bool(torch.isnan(ctx1.view(B, S, H)[~first].float()).all())          # never written
+    assert torch.equal(lse1[:, :, :32], lse0[:, :, :32]) and bool(torch.isnan(lse1[:, :, 32:]).all())
+    # (+0 against -0 is the only licence: adding the skipped tiles' exact zeros can flip the sign of a zero sum)
+    assert torch.equal(dq1.float(), dq0.float())
+    assert bool((dq1.view(B, S, 3 * H)[:, 32:, :H] == 0).all())
