@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("resid_f32", C.c_void_p), ("aux_bf16", C.c_void_p),
                 ("drop_seed", C.c_uint32), ("drop_site", C.c_uint32), ("drop_idx_offset", C.c_uint32),
                 ("drop_p", C.c_float), ("drop_row_map", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
-                ("colsum_a", C.c_void_p), ("colsum_part", C.c_void_p), ("splitk_ws_zeroed", C.c_int32)]
+                ("colsum_a", C.c_void_p), ("colsum_part", C.c_void_p), ("splitk_ws_zeroed", C.c_int32),
+                ("resid_ln_stats", C.c_void_p), ("resid_ln_gamma", C.c_void_p), ("resid_ln_beta", C.c_void_p)]
 
 
 class GemmRowLnArgs(C.Structure):

@@ -83,6 +83,11 @@ __device__ __forceinline__ void dropout_mult_n(const Dropout& d, uint32_t idx, f
   }
 }
 
+// One element of a LayerNorm output from its input, the row's statistics and the column's gamma / beta: THE expression of the LayerNorm
+// kernels (ln_device.h: ln_normalise) -- also used by the GEMM epilogues that recompute a residual LN(h) from the saved pre-LayerNorm
+// rows instead of reading a stored copy (gemm_epilogue.h: resid_stats), so that both give the same bits.
+__device__ __forceinline__ float ln_apply(float a, float mean, float rstd, float g, float b) { return (a - mean) * rstd * g + b; }
+
 // ---------------------------------------------------------------- reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -14,6 +14,7 @@ int slab_reduce_multi(const void* slabs, void* out, int64_t n, const void* slabs
                       int nparts, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);   // gemm.hip: weight slabs + bias partials + LayerNorm partials in one launch
 int gemm_rowln_wanted(long rows);         // gemm.hip: should a 768-wide linear + LayerNorm of this many rows run as the fused row-band kernel?
 int gemm_rowln_wanted_k(int K);           // ... also for this contraction length (tuning hook: the K = 3072 form can be switched off alone)
+void encoder_ln_resid_enable(int on);      // encoder.hip: LayerNorm residuals recomputed by the next epilogue (tuning hook 230 / 231)
 void tail_overlap_enable(int on);          // tail.hip: loss kernel beside the decoder passes (tuning hook 210 / 211)
 int gemm_pp_init_device(int device);      // gemm_pp.hip: fills the GELU table (carel_init)
 // 768-wide row gather / scatter by int32 index (ln.hip); either of the f32 / bf16 pairs may be null

@@ -140,11 +140,17 @@ SideStream* side_stream() {
   return per_dev[dev].ok ? &per_dev[dev] : nullptr;
 }
 
+// lnres != null (residual epilogue): `resid` holds the pre-LayerNorm rows of the LayerNorm whose output is the residual; the epilogue
+// recomputes it (carel_gemm_args.resid_ln_*), so that LayerNorm never writes its f32 output
+struct LnResid { const void* stats; const void* gamma; const void* beta; };
+static int g_ln_resid = 1;          // tuning hook (carel_gemm_set_variant(230 / 231)): LayerNorm f32 outputs written and read back / recomputed by the next epilogue
+int ln_resid_enabled() { return g_ln_resid; }
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
               uint32_t off, float p, void* stream, void* colsum_part = nullptr, const void* row_map = nullptr, void* ws = nullptr,
-              size_t ws_bytes = 0, int split_tile_factor = 1) {
+              size_t ws_bytes = 0, int split_tile_factor = 1, const LnResid* lnres = nullptr) {
   carel_gemm_args g;
+  g.resid_ln_stats = lnres ? lnres->stats : nullptr; g.resid_ln_gamma = lnres ? lnres->gamma : nullptr; g.resid_ln_beta = lnres ? lnres->beta : nullptr;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
   g.out_bf16 = out_bf16; g.out2_bf16 = out2; g.out_f32 = out_f32; g.bias = bias; g.resid_f32 = resid; g.aux_bf16 = aux;
   g.drop_seed = seed; g.drop_site = site; g.drop_idx_offset = off; g.drop_p = p; g.colsum_part = colsum_part; g.drop_row_map = row_map; g.colsum_a = nullptr;
@@ -169,6 +175,7 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
   g.splits = splits; g.out_bf16 = nullptr; g.out2_bf16 = nullptr; g.out_f32 = slabs; g.bias = nullptr; g.resid_f32 = nullptr; g.aux_bf16 = nullptr;
   g.drop_seed = 0; g.drop_site = 0; g.drop_idx_offset = 0; g.drop_p = 0.f; g.drop_row_map = nullptr; g.colsum_part = nullptr;
   g.splitk_ws = nullptr; g.splitk_ws_bytes = 0; g.splitk_ws_zeroed = 0;
+  g.resid_ln_stats = nullptr; g.resid_ln_gamma = nullptr; g.resid_ln_beta = nullptr;
   float* cs = db ? (float*)slabs + (size_t)splits * M * N : nullptr;
   g.colsum_a = cs;
   if (splits == 1) {                 // one slab IS the result: write it (and the bias sums) in place, nothing to reduce
@@ -186,6 +193,8 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
 }
 
 }  // namespace
+
+namespace carel { void encoder_ln_resid_enable(int on) { g_ln_resid = on ? 1 : 0; } }
 
 extern "C" void* carel_side_stream(int32_t which) {
   SideStream* sd = side_stream();
@@ -253,12 +262,28 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     long R = T;                                  // rows of the row-wise half of this layer
     const int fixed = cls_only ? GEMM_EX_FIXED_ROWS : 0;
     const void* Actx = la.ctx; const void* res1 = xa; const void* rmap = whole ? a->tok_row : nullptr;
+    // The f32 output of a LayerNorm is only ever read as the residual of the next linear's epilogue: that epilogue recomputes it from the
+    // pre-LayerNorm rows and the statistics the backward pass keeps anyway (bit-identical, tests/test_gpu_gemm.py), and the LayerNorm does not
+    // write it (25 MB per sub-layer at T = 8192).  Exceptions, which still get their f32 rows: the embedding output (layer 0's residual),
+    // the input of a [CLS]-only last layer (gathered by row) and the encoder's final output.  g_ln_resid: tuning hook 230 / 231.
+    LnResid lr1, lr2;
+    const LnResid* plr1 = nullptr;               // residual of the out-projection = LayerNorm 2 of the previous layer
+    const bool lnres_on = ln_resid_enabled() && !gemm_rowln_wanted(T);      // (the fused row-band kernel writes its own f32 rows)
+    if (lnres_on && i > 0 && !cls_only) {
+      LayerAct lp = layer_act(l, base, i - 1, a->inference);
+      lr1.stats = (const char*)lp.st2 + (size_t)r0 * 2 * 4; lr1.gamma = a->layers[i - 1].ln2_g; lr1.beta = a->layers[i - 1].ln2_b;
+      res1 = (const char*)lp.h2 + (size_t)r0 * EH * 4; plr1 = &lr1;
+    }
     if (cls_only) {                              // only the [CLS] rows of the last layer are ever read
       R = a->n_cls;
       char* cctx = base + l.o_cctx; char* cxres = base + l.o_cxres;
       if ((rc = gather_rows(xa, la.ctx, a->cls_rows, (int)R, cxres, cctx, (hipStream_t)stream))) return rc;
       Actx = cctx; res1 = cxres; rmap = a->cls_orig_rows;
     }
+    const bool lnres2 = lnres_on;                // residual of FFN2 = LayerNorm 1 of this layer
+    lr2.stats = la.st1; lr2.gamma = w.ln1_g; lr2.beta = w.ln1_b;
+    // does anything read this layer's f32 output rows?  (the next layer's epilogue recomputes them unless it is a [CLS]-only last layer)
+    const bool need_xa = !lnres_on || i + 1 == a->n_layers || (a->n_cls > 0 && i + 2 == a->n_layers);
     // dense batches: linear + dropout + residual + LayerNorm as ONE kernel (gemm_rowln.hip: 32 complete rows per workgroup; the same bits
     // as the GEMM followed by the stand-alone LayerNorm).  Packed ECPE batches and the [CLS]-only rows are too few rows to fill the chip
     // with 32-row workgroups that each stream the whole weight matrix: they keep the two-kernel path.
@@ -276,8 +301,8 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
       if ((rc = linear_ln(Actx, w.out_w, EH, w.out_b, res1, 2 + 3 * i, w.ln1_g, w.ln1_b, a->inference ? nullptr : la.h1, xb, la.x1_bf16, la.st1))) return rc;
     } else {
     if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
-                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
-    if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, xb, la.x1_bf16, la.st1, stream))) return rc;
+                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed, plr1))) return rc;
+    if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, lnres2 ? nullptr : xb, la.x1_bf16, la.st1, stream))) return rc;
     }
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, a->inference ? nullptr : la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains | fixed))) return rc;
@@ -287,8 +312,9 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
       if ((rc = linear_ln(la.g, w.ffn2_w, EI, w.ffn2_b, xb, 3 + 3 * i, w.ln2_g, w.ln2_b, a->inference ? nullptr : la.h2, xa, next_bf16, la.st2))) return rc;
     } else {
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed))) return rc;
-    if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, xa, next_bf16, la.st2, stream))) return rc;
+                        w.ffn2_b, lnres2 ? (const void*)la.h1 : (const void*)xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws,
+                        ws_bytes, chains | fixed, lnres2 ? &lr2 : nullptr))) return rc;
+    if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, need_xa ? xa : nullptr, next_bf16, la.st2, stream))) return rc;
     }
   }
   return CAREL_OK;

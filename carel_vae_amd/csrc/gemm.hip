@@ -733,6 +733,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
+  if (v == 230 || v == 231) { encoder_ln_resid_enable(v - 230); return CAREL_OK; }     // encoder forward: LayerNorm f32 outputs stored and re-read / recomputed by the next residual epilogue (default)
   if (v >= 220 && v <= 225) { gemm_tri_enable(v - 220); return CAREL_OK; }             // three-group kernel for the N = 768 forward GEMMs off (default) / on
   if (v == 210 || v == 211) { tail_overlap_enable(v - 210); return CAREL_OK; }           // VAE tail: loss kernel on the side stream beside the decoder passes off / on (default)
   if (v == 200 || v == 201) { gemm_pp_pair_enable(v - 200); return CAREL_OK; }        // pair split-K of the N = 768, K >= 1536 GEMMs off (default: measured slower) / on
@@ -760,6 +761,13 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
   p.M = a->M; p.N = a->N; p.K = a->K / splits;
   p.out0 = (bf16_t*)a->out_bf16; p.out1 = (bf16_t*)a->out2_bf16; p.outf = (float*)a->out_f32; p.ldc = a->ldc;
   p.bias = (const float*)a->bias; p.resid = (const float*)a->resid_f32; p.aux = (const bf16_t*)a->aux_bf16;
+  p.resid_stats = (const float*)a->resid_ln_stats; p.resid_gamma = (const float*)a->resid_ln_gamma; p.resid_beta = (const float*)a->resid_ln_beta;
+  if (p.resid_stats || p.resid_gamma || p.resid_beta) {
+    if (a->epilogue != EPI_BIAS_DROP_RESID || !p.resid_stats || !p.resid_gamma || !p.resid_beta)
+      return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: resid_ln_stats / _gamma / _beta go together and with CAREL_EPI_BIAS_DROP_RESID only");
+    if ((((uintptr_t)p.resid_stats) & 7) || (((uintptr_t)p.resid_gamma | (uintptr_t)p.resid_beta) & 15))
+      return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: resid_ln_* pointers must be 8 / 16-byte aligned");
+  }
   p.drop = make_dropout(a->drop_seed, a->drop_site, a->drop_p, a->drop_idx_offset);
   p.tiles_m = a->M / 128; p.tiles_n = a->N / 128;
   p.split_tile_factor = split_tile_factor;

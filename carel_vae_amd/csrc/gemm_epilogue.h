@@ -31,6 +31,10 @@ struct GemmParams {
   long ldc;
   const float* bias;        // [N] or null
   const float* resid;       // [M,ldc] f32 or null
+  // EPI_BIAS_DROP_RESID only, all three or none: `resid` then holds the PRE-LayerNorm rows h of the LayerNorm whose output is the residual,
+  // and the epilogue recomputes LN(h) = (h - mean) * rstd * gamma + beta itself (resid_stats [M][2] = mean, rstd as ln_fwd_kernel stores
+  // them; resid_gamma / resid_beta [ldc]) -- the LayerNorm kernel then need not write its f32 output at all (25 MB per sub-layer)
+  const float* resid_stats; const float* resid_gamma; const float* resid_beta;
   const bf16_t* aux;        // [M,ldc] bf16 (pre-GELU) for EPI_DGELU
   Dropout drop;
   int tiles_m, tiles_n;
@@ -53,15 +57,26 @@ struct GemmParams {
 // ---------------------------------------------------------------------------------------------
 // The inputs of the 4-column epilogue (f32 residual or bf16 aux values of the same 4 elements), so that a kernel can request them
 // long before the accumulators are final (gemm_pp.hip asks for a whole tile's inputs before its main loop).
-struct EpiIn4 { float4 r; uint2 a; };
+struct EpiIn4 { float4 r; uint2 a; float2 st; };
 template <int EPI>
 __device__ __forceinline__ void epi_in4(const GemmParams& p, long row, long col, EpiIn4& in) {
   const long off = row * p.ldc + col;
   if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) in.r = *(const float4*)(p.resid + off);
+  if (EPI == EPI_BIAS_DROP_RESID) { if (p.resid_stats) in.st = *(const float2*)(p.resid_stats + row * 2); }
   if (epi_is_dgelu(EPI)) in.a = *(const uint2*)(p.aux + off);
 }
+// gamma (ln[0..3]) and beta (ln[4..7]) of the 4 columns, for the recomputed residual (resid_stats); loaded once per column group
 template <int EPI>
-__device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const EpiIn4& in, long row, long col) {
+__device__ __forceinline__ void epi_ln4(const GemmParams& p, long col, float* ln) {
+  if (EPI == EPI_BIAS_DROP_RESID) {
+    if (p.resid_stats) {
+      const float4 g = *(const float4*)(p.resid_gamma + col), b = *(const float4*)(p.resid_beta + col);
+      ln[0] = g.x; ln[1] = g.y; ln[2] = g.z; ln[3] = g.w; ln[4] = b.x; ln[5] = b.y; ln[6] = b.z; ln[7] = b.w;
+    }
+  }
+}
+template <int EPI>
+__device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const EpiIn4& in, long row, long col, const float* ln = nullptr) {
   const long off = row * p.ldc + col;
   if (epi_has_bias(EPI)) {
     if (p.bias) {
@@ -86,7 +101,12 @@ __device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const Epi
     *(uint2*)(p.out0 + off) = uint2{pack2bf(da.x, da.y), pack2bf(db.x, db.y)};
     *(uint2*)(p.out1 + off) = uint2{pack2bf(ga.x, ga.y), pack2bf(gb.x, gb.y)};
   } else if (EPI == EPI_BIAS_DROP_RESID) {
-    const float4 r = in.r;
+    float4 r = in.r;
+    if (p.resid_stats) {
+      const float mean = in.st.x, rstd = in.st.y;
+      r.x = ln_apply(r.x, mean, rstd, ln[0], ln[4]); r.y = ln_apply(r.y, mean, rstd, ln[1], ln[5]);
+      r.z = ln_apply(r.z, mean, rstd, ln[2], ln[6]); r.w = ln_apply(r.w, mean, rstd, ln[3], ln[7]);
+    }
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o;
     float dm[4];
@@ -124,8 +144,10 @@ __device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const Epi
 template <int EPI>
 __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
   EpiIn4 in;
+  float ln[8];
+  epi_ln4<EPI>(p, col, ln);
   epi_in4<EPI>(p, row, col, in);
-  epi_out4<EPI>(p, v, in, row, col);
+  epi_out4<EPI>(p, v, in, row, col, ln);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -142,7 +164,7 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 // The 8-column epilogue in three steps, so that a kernel can issue the loads of the NEXT row block before the stores of
 // the current one (a load's s_waitcnt also waits for every older store: loads queued behind stores serialise the store
 // round trips).  epi_store8 = the three steps back to back; every kernel's results are those of this one code path.
-struct EpiIn8 { float4 r0, r1; uint4 a; };
+struct EpiIn8 { float4 r0, r1; uint4 a; float2 st; };
 template <int EPI>
 __device__ __forceinline__ void epi_bias8(const GemmParams& p, long col, float* b) {
   if (epi_has_bias(EPI) && p.bias) {
@@ -154,7 +176,20 @@ template <int EPI>
 __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col, EpiIn8& in) {
   const long off = row * p.ldc + col;
   if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) { in.r0 = *(const float4*)(p.resid + off); in.r1 = *(const float4*)(p.resid + off + 4); }
+  if (EPI == EPI_BIAS_DROP_RESID) { if (p.resid_stats) in.st = *(const float2*)(p.resid_stats + row * 2); }
   if (epi_is_dgelu(EPI)) in.a = *(const uint4*)(p.aux + off);
+}
+// gamma (ln[0..7]) and beta (ln[8..15]) of the 8 columns, for the recomputed residual (resid_stats); loaded once per column group
+template <int EPI>
+__device__ __forceinline__ void epi_ln8(const GemmParams& p, long col, float* ln) {
+  if (EPI == EPI_BIAS_DROP_RESID) {
+    if (p.resid_stats) {
+      const float4 g0 = *(const float4*)(p.resid_gamma + col), g1 = *(const float4*)(p.resid_gamma + col + 4);
+      const float4 b0 = *(const float4*)(p.resid_beta + col), b1 = *(const float4*)(p.resid_beta + col + 4);
+      ln[0] = g0.x; ln[1] = g0.y; ln[2] = g0.z; ln[3] = g0.w; ln[4] = g1.x; ln[5] = g1.y; ln[6] = g1.z; ln[7] = g1.w;
+      ln[8] = b0.x; ln[9] = b0.y; ln[10] = b0.z; ln[11] = b0.w; ln[12] = b1.x; ln[13] = b1.y; ln[14] = b1.z; ln[15] = b1.w;
+    }
+  }
 }
 // GELU by table (ping-pong kernel): the activation is evaluated on the bf16-ROUNDED pre-activation, so gelu(u) and gelu'(u), both
 // rounded to bf16, are functions of 16 bits.  The table holds them (low / high half of a word) for every bf16 u with
@@ -219,7 +254,8 @@ __device__ __forceinline__ bool gelu_lut8(const uint32_t* lut, const uint4 o, ui
 // after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
 // lut: the GELU table in LDS (ping-pong kernel) or null (arithmetic)
 template <int EPI>
-__device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col, const uint32_t* lut = nullptr) {
+__device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col, const uint32_t* lut = nullptr,
+                                         const float* ln = nullptr) {
   const long off = row * p.ldc + col;
   if (epi_has_bias(EPI)) {
     if (p.bias) {
@@ -258,7 +294,14 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
     *(uint4*)(p.out0 + off) = dq;       // (a streaming / non-temporal store of this backward-only output: measured, no effect -- tools/bench_gemm_chain.py)
     *(uint4*)(p.out1 + off) = gq;
   } else if (EPI == EPI_BIAS_DROP_RESID) {
-    const float4 r0 = in.r0, r1 = in.r1;
+    float4 r0 = in.r0, r1 = in.r1;
+    if (p.resid_stats) {                       // the residual is LN(h): recomputed from the pre-LayerNorm rows (same expression as ln_fwd_kernel)
+      const float mean = in.st.x, rstd = in.st.y;
+      r0.x = ln_apply(r0.x, mean, rstd, ln[0], ln[8]); r0.y = ln_apply(r0.y, mean, rstd, ln[1], ln[9]);
+      r0.z = ln_apply(r0.z, mean, rstd, ln[2], ln[10]); r0.w = ln_apply(r0.w, mean, rstd, ln[3], ln[11]);
+      r1.x = ln_apply(r1.x, mean, rstd, ln[4], ln[12]); r1.y = ln_apply(r1.y, mean, rstd, ln[5], ln[13]);
+      r1.z = ln_apply(r1.z, mean, rstd, ln[6], ln[14]); r1.w = ln_apply(r1.w, mean, rstd, ln[7], ln[15]);
+    }
     const uint32_t e = p.drop_row_map ? (uint32_t)((long)p.drop_row_map[row] * p.ldc + col) : (uint32_t)off;
     float4 o0, o1;
     float dm[8];
@@ -294,11 +337,12 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
 }
 template <int EPI>
 __device__ __forceinline__ void epi_store8(const GemmParams& p, float* v, long row, long col) {
-  float b[8];
+  float b[8], ln[16];
   EpiIn8 in;
   epi_bias8<EPI>(p, col, b);
+  epi_ln8<EPI>(p, col, ln);
   epi_in8<EPI>(p, row, col, in);
-  epi_out8<EPI>(p, v, b, in, row, col);
+  epi_out8<EPI>(p, v, b, in, row, col, nullptr, ln);
 }
 
 // gemm_rowln.hip: 32-row x 768-column workgroups, GEMM + bias + dropout + residual + LayerNorm in one kernel

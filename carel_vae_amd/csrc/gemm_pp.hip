@@ -518,6 +518,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   float bias8[NQ > 0 ? NQ : 1][8];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) epi_bias8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, bias8[q]);
+  // (EPI_BIAS_DROP_RESID with a recomputed LayerNorm residual: gamma / beta of this lane's columns, once)
+  float ln8[NQ > 0 ? NQ : 1][16], ln4[8];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) epi_ln8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, ln8[q]);
+  if constexpr (NF & 1) epi_ln4<EPI>(p, n0 + wc * WN + (NF - 1) * 16 + rho * 4, ln4);
   // (npn 3 with a residual / aux input has no registers for two blocks of inputs: load and use block by block there;
   // the encoder never runs that combination -- N = 2304 is the bias-only QKV projection)
   constexpr bool PIPE = NPN < 3 || EPI == EPI_BIAS_BF16 || epi_is_gelu(EPI) || EPI == EPI_SLAB_F32;
@@ -550,8 +555,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
       if (ok) {
         bool done = false;         // (no struct copy / select here: a copied EpiIn8 ends up in scratch memory)
-        if constexpr (b < PB) { if (pre) { epi_out8<EPI>(p, v, bias8[q], pin[b][q], row, col, lut_lds); done = true; } }
-        if (!done) epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds);
+        if constexpr (b < PB) { if (pre) { epi_out8<EPI>(p, v, bias8[q], pin[b][q], row, col, lut_lds, ln8[q]); done = true; } }
+        if (!done) epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds, ln8[q]);
         if (epi_is_dgelu(EPI)) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (row < (long)p.M) {
         const long col = n0 + wc * WN + (NF - 1) * 16 + rho * 4;
         bool done = false;
-        if constexpr (b < PB) { if (pre) { epi_out4<EPI>(p, acc[b >> 1][b & 1][NF - 1], pin4[b], row, col); done = true; } }
+        if constexpr (b < PB) { if (pre) { epi_out4<EPI>(p, acc[b >> 1][b & 1][NF - 1], pin4[b], row, col, ln4); done = true; } }
         if (!done) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, col);
       }
     });

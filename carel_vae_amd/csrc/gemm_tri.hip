@@ -147,8 +147,9 @@ __global__ __launch_bounds__(768) void gemm_tri_kernel(GemmParams p) {
   // so that every lane owns 8 consecutive columns of one row
   const int rho = lane >> 4;
   const long col = n0 + wc * 32 + (rho & 1) * 16 + (rho >> 1) * 8;
-  float bias8[8];
+  float bias8[8], ln8[16];
   epi_bias8<EPI>(p, col, bias8);
+  epi_ln8<EPI>(p, col, ln8);
   EpiIn8 in[2];
   auto row_of = [&](int b) { return m0 + wr * 64 + b * 16 + (lane & 15); };
   if (row_of(0) < (long)p.M) epi_in8<EPI>(p, row_of(0), col, in[0]);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(768) void gemm_tri_kernel(GemmParams p) {
       v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
     }
     const long row = row_of(b);
-    if (row < (long)p.M) epi_out8<EPI>(p, v, bias8, in[b & 1], row, col);
+    if (row < (long)p.M) epi_out8<EPI>(p, v, bias8, in[b & 1], row, col, nullptr, ln8);
   }
 }
 

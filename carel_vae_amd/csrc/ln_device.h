@@ -55,7 +55,7 @@ __device__ __forceinline__ void ln_normalise(Row& X, const Row& G, const Row& Bt
   const float var = wave_sum(s) * (1.0f / H);
   rstd = rsqrtf(var + eps);
   Row& A = X; const Row& B = G; const Row& Cc = Bt;
-  ROW_FOREACH(a = (a - mean) * rstd * b + c; (void)e)
+  ROW_FOREACH(a = ln_apply(a, mean, rstd, b, c); (void)e)
 }
 
 }  // namespace carel

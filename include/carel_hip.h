@@ -103,6 +103,11 @@ typedef struct carel_gemm_args {
                            4 KiB: enables pair split-K for N = 768 outputs with K >= 1536 at M ~ 8192 (two workgroups per 256 x 192 tile,
                            each half of K; the second waits for the first's partial sums through per-wave flags kept in that tail, one-
                            directionally, so it cannot deadlock).  0 = never (a stale flag in uninitialised memory could end the wait early). */
+  /* ABI 6.  CAREL_EPI_BIAS_DROP_RESID only, all three or none: resid_f32 then holds the PRE-LayerNorm rows h of the LayerNorm whose output
+   * is the residual, and the epilogue recomputes LN(h) = (h - mean) * rstd * gamma + beta with the expression of carel_layernorm_fwd
+   * (bit-identical to reading its f32 output) -- that LayerNorm call may then pass x_f32 = NULL and not write its 4 B/element at all.
+   * resid_ln_stats: f32 [M][2] = mean, rstd as carel_layernorm_fwd stores them; resid_ln_gamma / resid_ln_beta: f32 [ldc]. */
+  const void* resid_ln_stats; const void* resid_ln_gamma; const void* resid_ln_beta;
 } carel_gemm_args;
 
 int carel_gemm_bf16(const carel_gemm_args* args, void* stream);

@@ -18,7 +18,7 @@ def to_bf16_bits(t: torch.Tensor) -> torch.Tensor:
 
 def gemm(A, B, form, epi, M, N, K, splits=1, out_bf16=None, out2_bf16=None, out_f32=None, bias=None,
          resid=None, aux=None, drop=(0, 0, 0, 0.0), lda=None, ldb=None, ldc=None, colsum_part=None, colsum_a=None, splitk_ws=None,
-         ws_zeroed=False):
+         ws_zeroed=False, resid_ln=None):
     a = L.GemmArgs()
     a.A, a.B = A.data_ptr(), B.data_ptr()
     a.lda = lda if lda is not None else A.stride(0)
@@ -35,6 +35,8 @@ def gemm(A, B, form, epi, M, N, K, splits=1, out_bf16=None, out2_bf16=None, out_
     a.splitk_ws = None if splitk_ws is None else splitk_ws.data_ptr()
     a.splitk_ws_bytes = 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size()
     a.splitk_ws_zeroed = 1 if ws_zeroed else 0
+    if resid_ln is not None:           # (stats [M, 2], gamma [N], beta [N]): resid holds the pre-LayerNorm rows
+        a.resid_ln_stats, a.resid_ln_gamma, a.resid_ln_beta = (t.data_ptr() for t in resid_ln)
     L.check(L.load().carel_gemm_bf16(C.byref(a), L.current_stream()), "carel_gemm_bf16")
 
 

@@ -647,3 +647,43 @@ def test_three_group_kernel_has_the_ping_pong_kernels_bits(M, K, epi):
         finally:
             L.check(lib.carel_gemm_set_variant(220))
         assert torch.equal(of.double(), Ai.double() @ Bi.double().t() + ri.double())
+
+
+@pytest.mark.parametrize("M,K,hook", [(8192, 768, 0), (8192, 3072, 0), (7999, 768, 0), (1664, 3072, 0), (1664, 768, 0), (384, 768, 0), (8192, 3072, 221)])
+def test_residual_recomputed_from_pre_layernorm_rows_same_bits(M, K, hook):
+    """carel_gemm_args.resid_ln_* (ABI 6): the residual epilogue given the PRE-LayerNorm rows h, the row statistics and gamma / beta must
+    produce the bits it produces when given carel_layernorm_fwd's stored f32 output of the same h -- on the ping-pong kernel (M = 8192 /
+    ragged), the split-K slab path with its separate epilogue kernel and the 128x128 kernel (packed-ECPE row counts; they get a workspace),
+    and the three-group kernel (hook 221).  Dropout on, guard rows untouched."""
+    lib = L.load()
+    N = 768
+    A, B = _rand((M, K), 1, 61).bfloat16(), _rand((N, K), 0.05, 62).bfloat16()
+    h = _rand((M, N), 2.0, 63) + 0.5
+    gamma, beta, bias = _rand((N,), 1.0, 64) + 1.0, _rand((N,), 0.3, 65), _rand((N,), 0.1, 66)
+    xf = torch.empty((M, N), device="cuda"); st = torch.empty((M, 2), device="cuda")
+    L.check(lib.carel_layernorm_fwd(h.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-12, M, 768, xf.data_ptr(), None, st.data_ptr(), L.current_stream()))
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    if hook: L.check(lib.carel_gemm_set_variant(hook))
+    try:
+        for resid, rl in ((xf, None), (h, (st, gamma, beta))):
+            out = torch.full((M + 8, N), 7.0, device="cuda")
+            a = dict(out_f32=out, bias=bias, resid=resid, drop=(9, 5, 64, 0.1), splitk_ws=ws, resid_ln=rl)
+            gemm(A, B, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, **a)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        if hook: L.check(lib.carel_gemm_set_variant(220))
+    assert torch.equal(outs[0], outs[1])
+    assert bool((outs[1][M:] == 7.0).all())
+    # sanity against fp64, dropout off
+    out = torch.empty((M, N), device="cuda")
+    if hook: L.check(lib.carel_gemm_set_variant(hook))
+    try:
+        gemm(A, B, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=out, bias=bias, resid=h, splitk_ws=ws, resid_ln=(st, gamma, beta))
+    finally:
+        if hook: L.check(lib.carel_gemm_set_variant(220))
+    h64 = h.double()
+    x64 = (h64 - h64.mean(1, keepdim=True)) / torch.sqrt(h64.var(1, unbiased=False, keepdim=True) + 1e-12) * gamma.double() + beta.double()
+    ref = A.double() @ B.double().t() + bias.double() + x64
+    assert float((out.double() - ref).abs().max()) < 2e-2

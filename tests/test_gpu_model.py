@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from carel_vae_amd import _lib as L
 from carel_vae_amd import drl_classifier as M
 from oracle import carel_oracle as O
 
@@ -609,3 +610,42 @@ def test_bench_shape_backward_and_adam_vs_oracle(shape):
         if not k.endswith("key.bias") and worst.get(k, 1.0) < 4e-2:
             # rows of the embedding tables that no token of the batch touches have an exactly zero gradient on both sides
             assert float((d <= 0.2 * opt.vae_lr).float().mean()) >= 0.90, (k, float((d <= 0.2 * opt.vae_lr).float().mean()))
+
+
+@pytest.mark.parametrize("name,varlen,cls_only", [("zh_small", False, False), ("zh_ragged", True, True), ("zh_full12", True, True), ("zh_full12", False, False)])
+def test_layernorm_residual_recomputed_in_the_next_epilogue_is_bitwise_identical(golden_dir, name, varlen, cls_only):
+    """The encoder's LayerNorms no longer write their f32 output (hook 231, default): the out-projection / FFN2 epilogue that adds it as the
+    residual recomputes it from the pre-LayerNorm rows and the saved statistics with the LayerNorm kernel's own expression.  Against hook
+    230 (f32 rows written and read back): the loss and every gradient bit-identical, dense and packed, with and without the [CLS]-only
+    last layer (whose gathered residual rows and the encoder's final output still come from stored rows), dropout on."""
+    lib = L.load()
+    cfg, opt = CASES[name]
+    opt = O.Opt(**{**vars(opt), "dropout": 0.3})
+    z, batch = load(golden_dir, name)
+    B, S, Lr, vocab, V, wseed, bseed, steps, it0 = (int(v) for v in z["meta"])
+    res = {}
+    for hook in (230, 231):
+        L.check(lib.carel_gemm_set_variant(hook))
+        try:
+            model, P = build(cfg, opt, wseed, train_dropout=True)
+            model.train()
+            model.overlap_wgrad, model.varlen, model.cls_only_last = False, varlen, cls_only
+            out = []
+            for s in range(2):
+                model.set_noise(torch.from_numpy(z["eps_e_0"]), torch.from_numpy(z["eps_c_0"]))
+                loss = model(*call(model, batch, it0 + s))
+                for p in model.parameters():
+                    p.grad = None
+                loss.backward()
+                out.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+            torch.cuda.synchronize()
+            res[hook] = out
+        finally:
+            L.check(lib.carel_gemm_set_variant(231))
+    for (l0, g0), (l1, g1) in zip(res[230], res[231]):
+        assert l0 == l1
+        for k in g0:
+            if "embeddings.word" in k or "embeddings.position" in k or "embeddings.token_type" in k:
+                assert relnorm(g1[k], g0[k]) < 1e-5, k
+            else:
+                assert torch.equal(g0[k], g1[k]), k
