@@ -50,13 +50,15 @@ def test_forward_gelu_epilogue():
     assert torch.equal(g2, g)
 
 
-@pytest.mark.parametrize("p", [0.0, 0.1])
-def test_forward_dropout_residual_epilogue(p):
-    M, N, K = 256, 768, 768
+@pytest.mark.parametrize("p,off,M", [(0.0, 5 * 768, 256), (0.1, 5 * 768, 256), (0.1, 5 * 768 + 1, 256), (0.1, 7, 8192)])
+def test_forward_dropout_residual_epilogue(p, off, M):
+    """(odd element offsets: the epilogues take the multipliers by PAIRS when the group starts on the even half of a pair -- every caller --
+    and element by element otherwise; both must be the oracle's mask.  M = 8192: the ping-pong kernel's epilogue, M = 256: the 128x128 one)"""
+    N, K = 768, 768
     A, W, b = _rand((M, K), 1, 7).bfloat16(), _rand((N, K), 0.05, 8).bfloat16(), _rand((N,), 0.1, 9)
     r = _rand((M, N), 1, 10)
     out = torch.empty((M, N), device="cuda", dtype=torch.float32)
-    seed, site, off = 1234, O.site_attn_out(2), 5 * N
+    seed, site = 1234, O.site_attn_out(2)
     gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=out, bias=b, resid=r, drop=(seed, site, off, p))
     y = (A.double() @ W.double().t() + b.double())
     if p > 0:
