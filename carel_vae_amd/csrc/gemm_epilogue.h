@@ -58,11 +58,13 @@ struct GemmParams {
 // The inputs of the 4-column epilogue (f32 residual or bf16 aux values of the same 4 elements), so that a kernel can request them
 // long before the accumulators are final (gemm_pp.hip asks for a whole tile's inputs before its main loop).
 struct EpiIn4 { float4 r; uint2 a; float2 st; };
-template <int EPI>
+// LNR = false: this instantiation never recomputes a LayerNorm residual (the wide ping-pong tiles have no registers for its statistics and
+// gamma / beta; gemm_pp_pick keeps such GEMMs off them)
+template <int EPI, bool LNR = true>
 __device__ __forceinline__ void epi_in4(const GemmParams& p, long row, long col, EpiIn4& in) {
   const long off = row * p.ldc + col;
   if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) in.r = *(const float4*)(p.resid + off);
-  if (EPI == EPI_BIAS_DROP_RESID) { if (p.resid_stats) in.st = *(const float2*)(p.resid_stats + row * 2); }
+  if (EPI == EPI_BIAS_DROP_RESID && LNR) { if (p.resid_stats) in.st = *(const float2*)(p.resid_stats + row * 2); }
   if (epi_is_dgelu(EPI)) in.a = *(const uint2*)(p.aux + off);
 }
 // gamma (ln[0..3]) and beta (ln[4..7]) of the 4 columns, for the recomputed residual (resid_stats); loaded once per column group
@@ -75,7 +77,7 @@ __device__ __forceinline__ void epi_ln4(const GemmParams& p, long col, float* ln
     }
   }
 }
-template <int EPI>
+template <int EPI, bool LNR = true>
 __device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const EpiIn4& in, long row, long col, const float* ln = nullptr) {
   const long off = row * p.ldc + col;
   if (epi_has_bias(EPI)) {
@@ -102,7 +104,7 @@ __device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const Epi
     *(uint2*)(p.out1 + off) = uint2{pack2bf(ga.x, ga.y), pack2bf(gb.x, gb.y)};
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     float4 r = in.r;
-    if (p.resid_stats) {
+    if (LNR && p.resid_stats) {
       const float mean = in.st.x, rstd = in.st.y;
       r.x = ln_apply(r.x, mean, rstd, ln[0], ln[4]); r.y = ln_apply(r.y, mean, rstd, ln[1], ln[5]);
       r.z = ln_apply(r.z, mean, rstd, ln[2], ln[6]); r.w = ln_apply(r.w, mean, rstd, ln[3], ln[7]);
@@ -141,13 +143,13 @@ __device__ __forceinline__ void epi_out4(const GemmParams& p, f32x4 v, const Epi
   }
 }
 // epi_store = the two steps back to back; every kernel's results are those of this one code path
-template <int EPI>
+template <int EPI, bool LNR = true>
 __device__ __forceinline__ void epi_store(const GemmParams& p, f32x4 v, long row, long col) {
   EpiIn4 in;
   float ln[8];
-  epi_ln4<EPI>(p, col, ln);
-  epi_in4<EPI>(p, row, col, in);
-  epi_out4<EPI>(p, v, in, row, col, ln);
+  if (LNR) epi_ln4<EPI>(p, col, ln);
+  epi_in4<EPI, LNR>(p, row, col, in);
+  epi_out4<EPI, LNR>(p, v, in, row, col, ln);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -172,11 +174,11 @@ __device__ __forceinline__ void epi_bias8(const GemmParams& p, long col, float* 
     b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
   }
 }
-template <int EPI>
+template <int EPI, bool LNR = true>
 __device__ __forceinline__ void epi_in8(const GemmParams& p, long row, long col, EpiIn8& in) {
   const long off = row * p.ldc + col;
   if (EPI == EPI_BIAS_DROP_RESID || (EPI == EPI_ADD_F32 && p.resid)) { in.r0 = *(const float4*)(p.resid + off); in.r1 = *(const float4*)(p.resid + off + 4); }
-  if (EPI == EPI_BIAS_DROP_RESID) { if (p.resid_stats) in.st = *(const float2*)(p.resid_stats + row * 2); }
+  if (EPI == EPI_BIAS_DROP_RESID && LNR) { if (p.resid_stats) in.st = *(const float2*)(p.resid_stats + row * 2); }
   if (epi_is_dgelu(EPI)) in.a = *(const uint4*)(p.aux + off);
 }
 // gamma (ln[0..7]) and beta (ln[8..15]) of the 8 columns, for the recomputed residual (resid_stats); loaded once per column group
@@ -253,7 +255,7 @@ __device__ __forceinline__ bool gelu_lut8(const uint32_t* lut, const uint4 o, ui
 
 // after the call v[] holds the values that were stored (pre-rounding), for the fused column sums
 // lut: the GELU table in LDS (ping-pong kernel) or null (arithmetic)
-template <int EPI>
+template <int EPI, bool LNR = true>
 __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const float* b, const EpiIn8& in, long row, long col, const uint32_t* lut = nullptr,
                                          const float* ln = nullptr) {
   const long off = row * p.ldc + col;
@@ -295,7 +297,7 @@ __device__ __forceinline__ void epi_out8(const GemmParams& p, float* v, const fl
     *(uint4*)(p.out1 + off) = gq;
   } else if (EPI == EPI_BIAS_DROP_RESID) {
     float4 r0 = in.r0, r1 = in.r1;
-    if (p.resid_stats) {                       // the residual is LN(h): recomputed from the pre-LayerNorm rows (same expression as ln_fwd_kernel)
+    if (LNR && p.resid_stats) {                // the residual is LN(h): recomputed from the pre-LayerNorm rows (same expression as ln_fwd_kernel)
       const float mean = in.st.x, rstd = in.st.y;
       r0.x = ln_apply(r0.x, mean, rstd, ln[0], ln[8]); r0.y = ln_apply(r0.y, mean, rstd, ln[1], ln[9]);
       r0.z = ln_apply(r0.z, mean, rstd, ln[2], ln[10]); r0.w = ln_apply(r0.w, mean, rstd, ln[3], ln[11]);

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         long row = row_of(b);
         if (row > (long)p.M - 1) row = (long)p.M - 1;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) epi_in8<EPI>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, pin[b][q]);
-        if constexpr (NF & 1) epi_in4<EPI>(p, row, n0 + wc * WN + (NF - 1) * 16 + rho * 4, pin4[b]);
+        for (int q = 0; q < NQ; ++q) epi_in8<EPI, NPN == 1>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, pin[b][q]);
+        if constexpr (NF & 1) epi_in4<EPI, NPN == 1>(p, row, n0 + wc * WN + (NF - 1) * 16 + rho * 4, pin4[b]);
       });
       asm volatile("" ::: "memory");
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::PRO_WAIT + NE) : "memory");
@@ -518,11 +518,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   float bias8[NQ > 0 ? NQ : 1][8];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) epi_bias8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, bias8[q]);
-  // (EPI_BIAS_DROP_RESID with a recomputed LayerNorm residual: gamma / beta of this lane's columns, once)
-  float ln8[NQ > 0 ? NQ : 1][16], ln4[8];
+  // (EPI_BIAS_DROP_RESID with a recomputed LayerNorm residual: gamma / beta of this lane's columns, once, up front -- on the 96-wide tile only
+  // (the encoder's shape: 24 registers); the wider tiles have no registers for them and never get such a GEMM: gemm_pp_pick)
+  constexpr bool LN_HOIST = NPN == 1;
+  float ln8[LN_HOIST && NQ > 0 ? NQ : 1][16], ln4[8];
+  if constexpr (LN_HOIST) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) epi_ln8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, ln8[q]);
-  if constexpr (NF & 1) epi_ln4<EPI>(p, n0 + wc * WN + (NF - 1) * 16 + rho * 4, ln4);
+    for (int q = 0; q < NQ; ++q) epi_ln8<EPI>(p, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, ln8[q]);
+  }
+  if constexpr ((NF & 1) && LN_HOIST) epi_ln4<EPI>(p, n0 + wc * WN + (NF - 1) * 16 + rho * 4, ln4);
   // (npn 3 with a residual / aux input has no registers for two blocks of inputs: load and use block by block there;
   // the encoder never runs that combination -- N = 2304 is the bias-only QKV projection)
   constexpr bool PIPE = NPN < 3 || EPI == EPI_BIAS_BF16 || epi_is_gelu(EPI) || EPI == EPI_SLAB_F32;
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const long row = row_of(b);
     if (row < (long)p.M) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) epi_in8<EPI>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, dst[q]);
+      for (int q = 0; q < NQ; ++q) epi_in8<EPI, NPN == 1>(p, row, n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8, dst[q]);
     }
   };
   // blocks below PB already hold their inputs (requested before the main loop) when `pre`
@@ -553,10 +557,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
       }
       const long col = n0 + wc * WN + (2 * q + (rho & 1)) * 16 + (rho >> 1) * 8;
+      const float* lnp = ln8[LN_HOIST ? q : 0];
       if (ok) {
         bool done = false;         // (no struct copy / select here: a copied EpiIn8 ends up in scratch memory)
-        if constexpr (b < PB) { if (pre) { epi_out8<EPI>(p, v, bias8[q], pin[b][q], row, col, lut_lds, ln8[q]); done = true; } }
-        if (!done) epi_out8<EPI>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds, ln8[q]);
+        if constexpr (b < PB) { if (pre) { epi_out8<EPI, NPN == 1>(p, v, bias8[q], pin[b][q], row, col, lut_lds, lnp); done = true; } }
+        if (!done) epi_out8<EPI, NPN == 1>(p, v, bias8[q], in[PIPE ? (b & 1) : 0][q], row, col, lut_lds, lnp);
         if (epi_is_dgelu(EPI)) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[q][e] += v[e];
@@ -571,8 +576,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (row < (long)p.M) {
         const long col = n0 + wc * WN + (NF - 1) * 16 + rho * 4;
         bool done = false;
-        if constexpr (b < PB) { if (pre) { epi_out4<EPI>(p, acc[b >> 1][b & 1][NF - 1], pin4[b], row, col, ln4); done = true; } }
-        if (!done) epi_store<EPI>(p, acc[b >> 1][b & 1][NF - 1], row, col);
+        if constexpr (b < PB) { if (pre) { epi_out4<EPI, NPN == 1>(p, acc[b >> 1][b & 1][NF - 1], pin4[b], row, col, ln4); done = true; } }
+        if (!done) epi_store<EPI, NPN == 1>(p, acc[b >> 1][b & 1][NF - 1], row, col);
       }
     });
   }
@@ -686,6 +691,7 @@ int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
   int best = 0; double best_score = 0.0;
   for (int npn = bt ? 2 : 3; npn >= 1; --npn) {
     if (p.N % (96 * npn)) continue;
+    if (p.resid_stats && npn > 1) continue;                                 // the recomputed LayerNorm residual exists on the 96-wide tile only
     if (g_pp_force_npn && npn != g_pp_force_npn && p.N % (96 * g_pp_force_npn) == 0 && !(bt && g_pp_force_npn == 3)) continue;
     if (epi_is_dgelu(epi) && p.colsum_part && (npn & 1)) continue;      // the fused column sums need fragment pairs
     const long tiles = (long)tiles_m * (p.N / (96 * npn));
@@ -782,7 +788,7 @@ void gemm_pp_pair_enable(int on) { g_pp_pair = on ? 1 : 0; }
 // per tile): N a multiple of 192 but not a 2304 / 3072-wide output (those already run 256 x 192 / 288 tiles), K >= 1536, and twice the
 // 256 x 192 tile count fills the chip in exactly one round.
 int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi) {
-  if (!g_pp_pair || !g_pp_wide || !p.pair_flags || !p.splitk_ws) return 0;
+  if (!g_pp_pair || !g_pp_wide || !p.pair_flags || !p.splitk_ws || p.resid_stats) return 0;
   if (!(epi == EPI_BIAS_DROP_RESID && !bt) && !(epi == EPI_ADD_F32)) return 0;
   if (p.N != 768 || p.K % 128 || p.K < 1536 || p.M < 1) return 0;
   const long tiles = (long)((p.M + 255) / 256) * (p.N / 192);
