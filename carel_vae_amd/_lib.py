@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAREL_HIP_LIB") or os.path.join(_HERE, "libcarel_hip.so")     # CAREL_HIP_LIB: an experiment build (tools/ablate_*.sh, tools/ab_lib.sh)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CarelError(RuntimeError):
@@ -187,19 +187,31 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_DGELU_BF16, EPI_ADD_F32, EPI_SLAB_F32, EPI_BIAS_GELU_DG, EPI_MUL_BF16 = range(8)
 
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header exports
+class WgradProblem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32)]
+
+
+class LnPartialSet(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("rows", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias", C.c_void_p)]
+
+
+class WgradGroupArgs(C.Structure):
+    _fields_ = [("prob", WgradProblem * 4), ("n_prob", C.c_int32), ("T", C.c_int64), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("ln", LnPartialSet * 2), ("n_ln", C.c_int32)]
+
+
 SIGNATURES = {
     "carel_abi_version": (C.c_int, []),
     "carel_init": (C.c_int, [C.c_int]),
     "carel_last_error": (C.c_char_p, []),
     "carel_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
-    "carel_gemm_rowln": (C.c_int, [C.POINTER(GemmRowLnArgs), C.c_void_p]),
-    "carel_gemm_rowln_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_gemm_wgrad_splits": (C.c_int32, [C.c_int32, C.c_int32, C.c_int64]),
-    "carel_gemm_set_variant": (C.c_int, [C.c_int32]),
     "carel_profile_gemm": (C.c_int, [C.c_int32, C.c_int32]),
     "carel_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "carel_profile_gemm_overheads": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "carel_slab_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "carel_gemm_wgrad_group_ws_bytes": (C.c_int64, [C.POINTER(WgradGroupArgs)]),
+    "carel_gemm_wgrad_group": (C.c_int, [C.POINTER(WgradGroupArgs), C.c_void_p]),
     "carel_mean_pool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_mean_pool_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "carel_triplet_semihard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -266,31 +278,76 @@ SIGNATURES = {
     "carel_relpos_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
-_lib = None
+# entry points of the EXPERIMENTS build only (include/carel_hip_experiments.h): tuning hooks + the kernels that were not adopted
+EXP_SIGNATURES = {
+    "carel_gemm_set_variant": (C.c_int, [C.c_int32]),
+    "carel_gemm_rowln": (C.c_int, [C.POINTER(GemmRowLnArgs), C.c_void_p]),
+    "carel_gemm_rowln_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+}
+EXP_LIB_PATH = os.path.join(_HERE, "libcarel_hip_exp.so")
+
+_lib = None          # the ACTIVE library: the product library unless an experiments() block is open
+_product = None
+_exp = None
 
 
-def load():
-    """Load the library once; raise loudly if it is absent or of the wrong ABI."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def _open(path, sigs, what):
     # torch ships its own HIP runtime (libamdhip64); it must be the one already loaded when our library's
     # dependency is resolved, otherwise two runtimes coexist and torch sees no GPU.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise CarelError(
-            "libcarel_hip.so not found at %s -- build it with `python -m carel_vae_amd.build` "
-            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+            "%s not found at %s -- build it with `python -m carel_vae_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % (what, path))
+    lib = C.CDLL(path)
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     v = lib.carel_abi_version()
     if v != ABI_VERSION:
-        raise CarelError("libcarel_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
-    _lib = lib
+        raise CarelError("%s ABI %d != binding ABI %d: rebuild" % (what, v, ABI_VERSION))
     return lib
+
+
+def load():
+    """The active library (loaded once); raises loudly if it is absent or of the wrong ABI."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    if os.environ.get("CAREL_USE_EXPERIMENTS") == "1":       # A/B tools (tools/*.py that flip hooks): the whole process on the experiments build
+        _lib = load_experiments()
+        return _lib
+    _product = _open(LIB_PATH, SIGNATURES, "libcarel_hip.so")
+    _lib = _product
+    return _lib
+
+
+def load_experiments():
+    """libcarel_hip_exp.so (every product entry point + EXP_SIGNATURES), without making it the active library."""
+    global _exp
+    if _exp is None:
+        sigs = dict(SIGNATURES)
+        sigs.update(EXP_SIGNATURES)
+        _exp = _open(os.environ.get("CAREL_HIP_EXP_LIB") or EXP_LIB_PATH, sigs, "libcarel_hip_exp.so")
+    return _exp
+
+
+class experiments:
+    """`with _lib.experiments():` -- inside the block load() returns the EXPERIMENTS library, so that everything (the model, ops, the
+    tests' direct calls) runs on the build that has carel_gemm_set_variant and the non-adopted kernels.  Tests and A/B tools only; the
+    two libraries keep separate side streams / events / GELU tables, so do not mix objects created under one with calls under the other."""
+
+    def __enter__(self):
+        global _lib
+        load()
+        self._prev = _lib
+        _lib = load_experiments()
+        return _lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._prev
 
 
 def check(rc, what=""):
@@ -303,12 +360,13 @@ _INITED = set()
 
 
 def ensure_init(device=None):
-    """carel_init(device) once per device per process (the library's per-device immutable state: the GELU table)."""
+    """carel_init(device) once per device per process and library (the library's per-device immutable state: the GELU table)."""
     import torch
     d = torch.cuda.current_device() if device is None else int(device)
-    if d not in _INITED:
-        check(load().carel_init(d), "carel_init")
-        _INITED.add(d)
+    lib = load()
+    if (id(lib), d) not in _INITED:
+        check(lib.carel_init(d), "carel_init")
+        _INITED.add((id(lib), d))
 
 
 def current_stream():

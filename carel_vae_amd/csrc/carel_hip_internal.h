@@ -6,15 +6,30 @@
 #include "../../include/carel_hip.h"
 #include "carel_common.h"
 
+// Tuning hooks exist in the EXPERIMENTS build only (-DCAREL_EXPERIMENTS -> libcarel_hip_exp.so: carel_gemm_set_variant, the
+// kernels that were built, measured and not adopted -- gemm_tri.hip, gemm_rowln.hip, pair split-K -- and every switch the A/B tools
+// flip).  In the product library each of these is a compile-time constant: no mutable process-wide state, dead branches folded away.
+#ifdef CAREL_EXPERIMENTS
+#define CAREL_TUNABLE(type, name, value) static type name = value
+#else
+#define CAREL_TUNABLE(type, name, value) static constexpr type name = value
+#endif
+
 namespace carel {
 
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
 int slab_reduce_multi(const void* slabs, void* out, int64_t n, const void* slabs2, void* out2, int64_t n2, int splits, const void* partials,
                       int nparts, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);   // gemm.hip: weight slabs + bias partials + LayerNorm partials in one launch
+#ifdef CAREL_EXPERIMENTS
 int gemm_rowln_wanted(long rows);         // gemm.hip: should a 768-wide linear + LayerNorm of this many rows run as the fused row-band kernel?
 int gemm_rowln_wanted_k(int K);           // ... also for this contraction length (tuning hook: the K = 3072 form can be switched off alone)
+#else
+inline int gemm_rowln_wanted(long) { return 0; }      // (the row-band kernel exists in the experiments build only)
+inline int gemm_rowln_wanted_k(int) { return 0; }
+#endif
 void encoder_ln_resid_enable(int on);      // encoder.hip: LayerNorm residuals recomputed by the next epilogue (tuning hook 230 / 231)
+void encoder_wgrad_group_enable(int on);    // encoder.hip: one grouped weight-gradient launch per layer (tuning hook 240 / 241)
 void tail_overlap_enable(int on);          // tail.hip: loss kernel beside the decoder passes (tuning hook 210 / 211)
 int gemm_pp_init_device(int device);      // gemm_pp.hip: fills the GELU table (carel_init)
 // 768-wide row gather / scatter by int32 index (ln.hip); either of the f32 / bf16 pairs may be null
@@ -36,6 +51,13 @@ int gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream);
 int gemm_wgrad_splits_max(int M, int N, long T);
 int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,
                     void* partials, void* row_scratch, hipStream_t stream);
+
+// grouped weight gradients (gemm_pp.hip, round 4): up to four dW[M, N] = dY^T X over the same T tokens in ONE launch + one small reduction
+struct WgradGroupProb { const void* dY; const void* X; void* dW; void* db; int M, N; };      // dY bf16 [T, M], X bf16 [T, N], dW f32 [M, N], db f32 [M] or null
+struct WgradGroupLn { const void* partials; int nparts; void* dgamma; void* dbeta; void* dbias; };   // LayerNorm-backward partials [nparts][3 * 768] summed by the same reduction
+size_t gemm_pp_wgrad_group_ws_bytes(const WgradGroupProb* pb, int n, long T);
+int gemm_pp_wgrad_group_ok(const WgradGroupProb* pb, int n, long T);
+int gemm_pp_wgrad_group(const WgradGroupProb* pb, int n, long T, void* ws, size_t ws_bytes, const WgradGroupLn* ln, int n_ln, hipStream_t stream);   // NT / NN, `splits` K slices -> fp32 slabs at p.outf
 
 inline Dropout make_dropout(uint32_t seed, uint32_t site, float p, uint32_t idx_offset) {
   Dropout d;

@@ -59,7 +59,10 @@ LayerAct layer_act(const ActLayout& a, char* base, int l, int inference) {
 }
 
 struct Scratch { char* dy; char* dyb; char* dyb2; char* du; char* dctx; char* dqkv; char* slabs; char* ws; char* part; char* part2; char* part3; };
-struct ScratchLayout { size_t o_dy, o_dyb, o_dyb2, o_du, o_dctx, o_dqkv, o_slabs, o_ws, o_part, o_part2, o_part3, ws_bytes, total; };
+// The operands of a layer's weight gradients -- dyb, dyb2, du, dqkv and the two LayerNorm-backward partial buffers -- exist TWICE, used by
+// layers of even / odd index: the layer's weight gradients run as one grouped launch on the side stream after its attention backward
+// and may still be reading them while the main stream is already writing the next layer's (round 4; 113 MB at T = 8192).
+struct ScratchLayout { size_t o_dy, o_dyb[2], o_dyb2[2], o_du[2], o_dctx, o_dqkv[2], o_slabs, o_ws, o_part[2], o_part2, o_part3[2], ws_bytes, slab_bytes, total; };
 
 // split-K factor of the weight-gradient GEMMs (K = tokens): chosen by the GEMM library for the kernel it will run
 int wgrad_splits(long T, int M, int N) { return carel_gemm_wgrad_splits(M, N, T); }
@@ -68,32 +71,42 @@ ScratchLayout scratch_layout(long B, long S) {
   const size_t T = (size_t)B * S;
   ScratchLayout s; size_t o = 0;
   s.o_dy = o; o += al(T * EH * 4);
-  s.o_dyb = o; o += al(T * EH * 2);
-  s.o_dyb2 = o; o += al(T * EH * 2);        // LN1-backward output, so that the FFN2 weight gradient may still read dyb (side stream)
-  s.o_du = o; o += al(T * EI * 2);
+  for (int par = 0; par < 2; ++par) {
+    s.o_dyb[par] = o; o += al(T * EH * 2);
+    s.o_dyb2[par] = o; o += al(T * EH * 2);      // LN1-backward output, so that the FFN2 weight gradient may still read dyb (side stream)
+    s.o_du[par] = o; o += al(T * EI * 2);
+    s.o_dqkv[par] = o; o += al(T * 3 * EH * 2);
+  }
   s.o_dctx = o; o += al(T * EH * 2);
-  s.o_dqkv = o; o += al(T * 3 * EH * 2);
   size_t slab = 0;
   const int shapes[4][2] = {{EH, EI}, {EI, EH}, {EH, EH}, {3 * EH, EH}};
   for (auto& sh : shapes) {     // sized for the largest split count either GEMM kernel may choose (the tuning hooks can switch kernels later)
     const size_t n = (size_t)gemm_wgrad_splits_max(sh[0], sh[1], (long)T) * ((size_t)sh[0] * sh[1] + sh[0]) * 4;
     slab = n > slab ? n : slab;
   }
-  s.o_slabs = o; o += al(slab);             // weight-gradient slabs (side stream when overlapping)
+  {   // ... and for the split tiles of the grouped launch
+    const WgradGroupProb pb[4] = {{nullptr, nullptr, nullptr, nullptr, EH, EI}, {nullptr, nullptr, nullptr, nullptr, EI, EH}, {nullptr, nullptr, nullptr, nullptr, 3 * EH, EH},
+                                  {nullptr, nullptr, nullptr, nullptr, EH, EH}};
+    const size_t n = gemm_pp_wgrad_group_ws_bytes(pb, 4, (long)T);
+    slab = n > slab ? n : slab;
+  }
+  s.o_slabs = o; o += al(slab); s.slab_bytes = al(slab);      // weight-gradient slabs (side stream when overlapping)
   s.o_ws = o; o += al(slab); s.ws_bytes = al(slab);      // split-K workspace of the forward / data-gradient GEMMs (main stream)
   size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;
   const size_t cs = ((T + 255) / 256) * EI * 4;
   part = part > cs ? part : cs;
-  s.o_part = o; o += al(part);              // LN2-backward partials (and the embedding backward's)
-  s.o_part2 = o; o += al(part);             // DGELU column-sum partials      } three buffers: their reductions run on the side
-  s.o_part3 = o; o += al(part);             // LN1-backward partials          } stream while the main stream moves on
+  for (int par = 0; par < 2; ++par) {
+    s.o_part[par] = o; o += al(part);       // LN2-backward partials (and the embedding backward's)
+    s.o_part3[par] = o; o += al(part);      // LN1-backward partials          } their reductions run on the side stream while the main stream moves on
+  }
+  s.o_part2 = o; o += al(part);             // DGELU column-sum partials
   s.total = o;
   return s;
 }
 
-Scratch scratch_of(const ScratchLayout& l, char* b) {
-  Scratch s; s.dy = b + l.o_dy; s.dyb = b + l.o_dyb; s.dyb2 = b + l.o_dyb2; s.du = b + l.o_du; s.dctx = b + l.o_dctx; s.dqkv = b + l.o_dqkv;
-  s.slabs = b + l.o_slabs; s.ws = b + l.o_ws; s.part = b + l.o_part; s.part2 = b + l.o_part2; s.part3 = b + l.o_part3;
+Scratch scratch_of(const ScratchLayout& l, char* b, int par = 0) {
+  Scratch s; s.dy = b + l.o_dy; s.dyb = b + l.o_dyb[par]; s.dyb2 = b + l.o_dyb2[par]; s.du = b + l.o_du[par]; s.dctx = b + l.o_dctx; s.dqkv = b + l.o_dqkv[par];
+  s.slabs = b + l.o_slabs; s.ws = b + l.o_ws; s.part = b + l.o_part[par]; s.part2 = b + l.o_part2; s.part3 = b + l.o_part3[par];
   return s;
 }
 
@@ -121,7 +134,7 @@ int enc_check(const carel_encoder_args* a, const char* who) {
 }
 
 // One low-priority stream + a few events per device, created on first use and kept for the life of the process.
-struct SideStream { static constexpr int NEV = 10; hipStream_t stream; hipStream_t aux; hipStream_t peer; hipEvent_t ev[NEV]; bool ok; };
+struct SideStream { static constexpr int NEV = 13; hipStream_t stream; hipStream_t aux; hipStream_t peer; hipEvent_t ev[NEV]; bool ok; };
 SideStream* side_stream() {
   static SideStream per_dev[16];
   static bool made[16];
@@ -143,7 +156,9 @@ SideStream* side_stream() {
 // lnres != null (residual epilogue): `resid` holds the pre-LayerNorm rows of the LayerNorm whose output is the residual; the epilogue
 // recomputes it (carel_gemm_args.resid_ln_*), so that LayerNorm never writes its f32 output
 struct LnResid { const void* stats; const void* gamma; const void* beta; };
-static int g_ln_resid = 1;          // tuning hook (carel_gemm_set_variant(230 / 231)): LayerNorm f32 outputs written and read back / recomputed by the next epilogue
+CAREL_TUNABLE(int, g_wgrad_group, 1);       // (experiments build: hook 240 / 241) one GEMM + reduction per weight gradient / the grouped launch
+int wgrad_group_enabled() { return g_wgrad_group; }
+CAREL_TUNABLE(int, g_ln_resid, 1);          // tuning hook (carel_gemm_set_variant(230 / 231)): LayerNorm f32 outputs written and read back / recomputed by the next epilogue
 int ln_resid_enabled() { return g_ln_resid; }
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
@@ -194,7 +209,9 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
 
 }  // namespace
 
-namespace carel { void encoder_ln_resid_enable(int on) { g_ln_resid = on ? 1 : 0; } }
+#ifdef CAREL_EXPERIMENTS
+namespace carel { void encoder_ln_resid_enable(int on) { g_ln_resid = on ? 1 : 0; } void encoder_wgrad_group_enable(int on) { g_wgrad_group = on ? 1 : 0; } }
+#endif
 
 extern "C" void* carel_side_stream(int32_t which) {
   SideStream* sd = side_stream();
@@ -290,12 +307,16 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     const bool fuse_ln = gemm_rowln_wanted(R);
     auto linear_ln = [&](const void* A, const void* W, int K, const void* bias, const void* resid, int site, const void* g, const void* bt,
                          void* h, void* xf, void* xbf, void* st) -> int {
+#ifndef CAREL_EXPERIMENTS
+      return set_error(CAREL_ERR_ARG, "carel_encoder_forward: internal: the fused row-band kernel exists in the experiments build only");
+#else
       carel_gemm_rowln_args ra;
       ra.A = A; ra.W = W; ra.lda = K; ra.ldb = K; ra.M = (int)R; ra.K = K; ra.bias = bias; ra.resid_f32 = resid; ra.gamma = g; ra.beta = bt; ra.eps = a->ln_eps;
       ra.h_f32 = h; ra.x_f32 = xf; ra.x_bf16 = xbf; ra.stats = st;
       ra.w_packed = 0;
       ra.drop_seed = a->drop_seed; ra.drop_site = (uint32_t)site; ra.drop_idx_offset = hoff; ra.drop_p = a->hidden_dropout; ra.drop_row_map = rmap;
       return carel_gemm_rowln(&ra, stream);
+#endif
     };
     if (fuse_ln) {
       if ((rc = linear_ln(Actx, w.out_w, EH, w.out_b, res1, 2 + 3 * i, w.ln1_g, w.ln1_b, a->inference ? nullptr : la.h1, xb, la.x1_bf16, la.st1))) return rc;
@@ -364,11 +385,12 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const long B = a->batch, S = a->seq_len, T = n_rows_of(a);
   const ActLayout l = act_layout(B, S, a->n_layers, 0);
   const LayerAct la = layer_act(l, (char*)a->act, layer, 0);
-  const Scratch s = scratch_of(scratch_layout(B, S), (char*)a->scratch);
+  const ScratchLayout sl = scratch_layout(B, S);
+  const int par = layer & 1;                   // the weight-gradient operands live in the buffer set of the layer's parity (scratch_layout)
+  const Scratch s = scratch_of(sl, (char*)a->scratch, par);
   const carel_layer_params& w = a->layers[layer];
   const carel_layer_grads& g = a->layer_grads[layer];
   const uint32_t hoff = a->drop_row_offset * (uint32_t)(S * EH), aoff = a->drop_row_offset * (uint32_t)(ENH * S * S);
-  const ScratchLayout sl = scratch_layout(B, S);
   const size_t ws_bytes = sl.ws_bytes;
   // Weight gradients on a second stream (a->overlap_wgrad): each dW GEMM + slab reduction is forked (events ev[0..3])
   // behind the kernel that produced its dY operand and runs beside the data-gradient chain, LayerNorm and attention
@@ -404,23 +426,47 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   const long R = cls_only ? (long)a->n_cls : T;
   const void* rmap = cls_only ? a->cls_orig_rows : a->tok_row;
   const void* ctx_rows = cls_only ? (const void*)((char*)a->act + l.o_cctx) : (const void*)la.ctx;
+  // The layer's four weight gradients (+ the two bias gradients that ride on them, + the sums of both LayerNorm backward passes' partials)
+  // as ONE grouped launch behind the attention backward: carel_gemm_wgrad_group (whole output tiles written in place, only the
+  // remainder of the tile count goes through split-K partials: 25 MB per layer instead of 165 MB of slabs, 2 launches instead of 8).
+  // Not for a [CLS]-only last layer (its row-wise half has 128 rows: two K tiles) or token counts below the kernel's minimum: those keep
+  // one split-K GEMM + reduction per weight gradient, forked behind the kernel that produced its dY.
+  carel_wgrad_group_args ga;
+  ga.prob[0] = carel_wgrad_problem{s.dyb, la.g, g.ffn2_w, nullptr, EH, EI};
+  ga.prob[1] = carel_wgrad_problem{s.du, la.x1_bf16, g.ffn1_w, g.ffn1_b, EI, EH};
+  ga.prob[2] = carel_wgrad_problem{s.dqkv, la.xin_bf16, g.qkv_w, g.qkv_b, 3 * EH, EH};
+  ga.prob[3] = carel_wgrad_problem{s.dyb2, la.ctx, g.out_w, nullptr, EH, EH};
+  ga.n_prob = 4; ga.T = T; ga.workspace = s.slabs; ga.workspace_bytes = (int64_t)sl.slab_bytes;
+  ga.ln[0] = carel_ln_partial_set{s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b};
+  ga.ln[1] = carel_ln_partial_set{s.part3, R, g.ln1_g, g.ln1_b, g.out_b};
+  ga.n_ln = 2;
+  bool grouped = false;
+  if (wgrad_group_enabled() && !cls_only) {
+    const int64_t need = carel_gemm_wgrad_group_ws_bytes(&ga);
+    grouped = need >= 0 && need <= (int64_t)sl.slab_bytes;
+  }
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
   if ((rc = wait_group(0))) return rc;
   if ((rc = layernorm_bwd_rows(a->dx, la.h2, la.st2, w.ln2_g, R, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb,
                                s.part, (hipStream_t)stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
-  if ((rc = fork())) return rc;
-  const LnPartials lp2{s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b};
-  if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream, nullptr, &lp2))) return rc;
-  if ((rc = group_done(0)) || (rc = wait_group(1))) return rc;
+  if (!grouped) {
+    if ((rc = fork())) return rc;
+    const LnPartials lp2{s.part, R, g.ln2_g, g.ln2_b, g.ffn2_b};
+    if ((rc = wgrad_call(s.dyb, la.g, R, EH, EI, s.slabs, g.ffn2_w, wstream, nullptr, &lp2))) return rc;
+    if ((rc = group_done(0))) return rc;
+  }
+  if ((rc = wait_group(1))) return rc;
   if ((rc = gemm_call(s.dyb, w.ffn2_w, EH, EI, (int)R, EI, EH, CAREL_GEMM_NN, CAREL_EPI_MUL_BF16, 1, s.du, nullptr, nullptr, nullptr,
                       nullptr, la.u, 0, 0, 0, 0.f, stream, nullptr))) return rc;
   // FFN1: dx1 = du W1 + dh2 -> a->dx ; dW1 = du^T x1, and the FFN1 bias gradient (column sums of du) from the same GEMM: its ones-vector
   // MFMAs are free there (43.2 vs 43.1 us, tools/bench_wgrad_colsum.py), the fused column sums of the data-gradient epilogue cost 3.9 us
-  if ((rc = fork())) return rc;
-  if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream, g.ffn1_b))) return rc;
-  if ((rc = group_done(1))) return rc;
+  if (!grouped) {
+    if ((rc = fork())) return rc;
+    if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream, g.ffn1_b))) return rc;
+    if ((rc = group_done(1))) return rc;
+  }
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
                       nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0)))) return rc;
   // LN1 backward (its bf16 output goes to a second buffer: the FFN2 weight gradient may still be reading dyb)
@@ -429,10 +475,12 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
                                s.part3, (hipStream_t)stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
   void* dctx_rows = cls_only ? (void*)s.dqkv : (void*)s.dctx;     // compact result parks in the (still free) dqkv buffer
-  if ((rc = fork())) return rc;
-  const LnPartials lp1{s.part3, R, g.ln1_g, g.ln1_b, g.out_b};
-  if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream, nullptr, &lp1))) return rc;
-  if ((rc = group_done(2))) return rc;
+  if (!grouped) {
+    if ((rc = fork())) return rc;
+    const LnPartials lp1{s.part3, R, g.ln1_g, g.ln1_b, g.out_b};
+    if ((rc = wgrad_call(s.dyb2, ctx_rows, R, EH, EH, s.slabs, g.out_w, wstream, nullptr, &lp1))) return rc;
+    if ((rc = group_done(2))) return rc;
+  }
   if (cls_only && (rc = wait_group(3))) return rc;             // the compact result parks in dqkv
   if ((rc = gemm_call(s.dyb2, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NN, CAREL_EPI_BIAS_BF16, 1, dctx_rows, nullptr, nullptr, nullptr,
                       nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0)))) return rc;
@@ -454,10 +502,10 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   at.cu_seqlens = a->cu_seqlens;
   at.rel_bias_dist = a->rel_bias_dist; at.d_rel_bias_dist = a->d_rel_bias_dist;
   at.q_rows = cls_only ? 32 : 0;                 // dctx is zero off the [CLS] rows: only the first query tile carries a gradient
-  if (a->tok_row && layer + 1 == a->n_layers) {
+  if (a->tok_row && layer + 2 >= a->n_layers) {
     // packed: the attention backward writes only rows that belong to a sample; the filler rows up to the next multiple
-    // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows.  Once per backward pass
-    // (its first call is the last layer): nothing else writes those rows between the layers of one pass
+    // of 128 must be exact zeros for the column sums / dgrad / wgrad GEMMs that read dqkv over all T rows.  Once per backward pass and
+    // buffer set (the pass's first two calls are the last two layers): nothing else writes those rows between the layers of one pass
     hipError_t he = hipMemsetAsync(s.dqkv + (size_t)(T - 128) * 3 * EH * 2, 0, (size_t)128 * 3 * EH * 2, (hipStream_t)stream);
     if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: memset: %s", hipGetErrorString(he));
   }
@@ -465,10 +513,18 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = carel_attention_bwd(&at, stream))) return rc;
   // QKV: dx_in = dqkv Wqkv + dh1 -> a->dx ; dWqkv = dqkv^T x_in
   if ((rc = fork())) return rc;
-  if ((rc = wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, wstream, g.qkv_b))) return rc;
+  if (grouped) { if ((rc = carel_gemm_wgrad_group(&ga, wstream))) return rc; }
+  else if ((rc = wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, wstream, g.qkv_b))) return rc;
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
                       dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
-  return group_done(3);
+  if (!grouped && (rc = group_done(3))) return rc;
+  if (sd) {
+    // side stream: this layer's weight gradients are enqueued; main stream: those of the PREVIOUS call (layer + 1) are complete from here
+    // on in stream order -- they were enqueued a whole layer ago -- which also frees that call's buffer set for the next call
+    if (hipEventRecord(sd->ev[10 + par], sd->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, sd->ev[10 + (par ^ 1)], 0) != hipSuccess)
+      return set_error(CAREL_ERR_HIP, "carel_encoder_backward_layer: event record / wait failed");
+  }
+  return CAREL_OK;
 }
 
 // `stream` waits for every weight-gradient kernel enqueued so far (no-op without overlap_wgrad).  Call it after the last

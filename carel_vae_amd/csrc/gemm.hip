@@ -419,15 +419,15 @@ static int launch_big(GemmParams p, int splits, hipStream_t s) {
   return check_launch("gemm_kernel_big");
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x192 kernel, 3 force the ping-pong kernel (NT / NN)
-static int g_xcd_n = 1;          // XCD tile layout (see gemm_kernel): 1 = row-major chunks (default), 0 = row bands walked M-fastest, 2/4/8 = patches
+CAREL_TUNABLE(int, g_gemm_variant, 0);   // 0 auto, 1 force the 128x128 kernel, 2 force the 256x192 kernel, 3 force the ping-pong kernel (NT / NN)
+CAREL_TUNABLE(int, g_xcd_n, 1);          // XCD tile layout (see gemm_kernel): 1 = row-major chunks (default), 0 = row bands walked M-fastest, 2/4/8 = patches
 
 // Small-M GEMMs (packed ECPE batches: ~1.8 k tokens) launch only 84-170 workgroups of 12-48 K steps each on 256 CUs.
 // With a workspace they are run split-K into fp32 slabs + one fused-epilogue pass instead.
 // GemmParams::split_tile_factor (carel::gemm_bf16_ex, internal): the caller runs this many equal GEMMs side by side (the
 // forward's half-batch chains), so the split factor is chosen as for ONE GEMM over all of their rows -- the same K
 // partition, hence the same bits, as the single-chain forward.
-static int g_auto_split_min_k = 768;   // carel_gemm_set_variant(130 / 131): internal split-K for K >= 1536 only (round-1 behaviour) / K >= 768
+CAREL_TUNABLE(int, g_auto_split_min_k, 768);   // carel_gemm_set_variant(130 / 131): internal split-K for K >= 1536 only (round-1 behaviour) / K >= 768
 static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   if (g_gemm_variant != 0 || p.K < g_auto_split_min_k) return 1;
   const int factor = p.split_tile_factor & 0xff;
@@ -445,9 +445,9 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
   return s;
 }
 
-static int g_pp_split = 1;       // carel_gemm_set_variant(140 / 141): internally split NT / NN GEMMs on the 128x128 kernel / on the ping-pong kernel where it fits
-static int g_pp_min_tiles = 192; // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles
-static int g_big_auto = 0;       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
+CAREL_TUNABLE(int, g_pp_split, 1);       // carel_gemm_set_variant(140 / 141): internally split NT / NN GEMMs on the 128x128 kernel / on the ping-pong kernel where it fits
+CAREL_TUNABLE(int, g_pp_min_tiles, 192); // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles
+CAREL_TUNABLE(int, g_big_auto, 0);       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
 static bool big_auto(const GemmParams& p, int splits) {
   if (!g_big_auto) return false;
   const long tiles = (long)(p.M / 256) * (p.N / 192) * splits;
@@ -458,10 +458,14 @@ template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
+#ifdef CAREL_EXPERIMENTS
     if (p.pair_flags && p.ldc == p.N && !p.colsum_part && g_gemm_variant == 0 && gemm_pp_pick_pair(p, BT, EPI)) return gemm_pp_launch_pair(p, BT, EPI, s);
+#endif
     // (a shape only the ping-pong kernel takes -- M not a multiple of 128 -- runs on it whatever the tile-count threshold says:
     // gemm_shape_ok accepted it on that kernel's account)
+#ifdef CAREL_EXPERIMENTS
     if (!BT && g_gemm_variant == 0 && p.ldc == p.N && gemm_tri_pick(p, EPI)) return gemm_tri_launch(p, EPI, s);
+#endif
     const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
     const int npn = gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60 || only_pp) ? 1 : -g_pp_min_tiles);
 #ifdef CAREL_GEMM_ABLATE
@@ -693,8 +697,9 @@ static int gemm_shape_ok(int M, int N, int K, int splits, int form) {
 
 // tuning hook (carel_gemm_set_variant(190 + m)): 0 = never fuse LayerNorm into the 768-wide linears (default: measured), 1 = out-projection and FFN2,
 // 2 = out-projection only
-static int g_rowln_mode = 0;
-static long g_rowln_min_rows = 6144;        // 192 workgroups of 32 rows: below that the chip is not filled
+#ifdef CAREL_EXPERIMENTS
+CAREL_TUNABLE(int, g_rowln_mode, 0);
+CAREL_TUNABLE(long, g_rowln_min_rows, 6144);        // 192 workgroups of 32 rows: below that the chip is not filled
 namespace carel {
 int gemm_rowln_wanted(long rows) { return g_rowln_mode != 0 && rows >= g_rowln_min_rows; }
 int gemm_rowln_wanted_k(int K) { return g_rowln_mode == 1 || K <= 768; }
@@ -721,6 +726,7 @@ extern "C" int carel_gemm_rowln_pack(const void* W, int64_t ldb, int32_t K, void
   return gemm_rowln_pack(W, (long)ldb, K, out, (hipStream_t)stream);
 }
 
+// EXPERIMENTS build only: the product library has no tuning hooks (every switch below is a compile-time constant there)
 extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v >= 20 && v <= 23) { g_xcd_n = 1 << (v - 20); return CAREL_OK; }    // 20: 8x1, 21: 4x2, 22: 2x4, 23: 1x8
   if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
@@ -733,6 +739,8 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
+  if (v >= 250 && v <= 252) { gemm_pp_group_mode(v - 250); return CAREL_OK; }             // grouped weight gradients: 256 x 96 tiles + split remainder (default) / 256 x 192 whole / 256 x 96 whole
+  if (v == 240 || v == 241) { encoder_wgrad_group_enable(v - 240); return CAREL_OK; }   // one GEMM + reduction per weight gradient / one grouped launch per layer (default)
   if (v == 230 || v == 231) { encoder_ln_resid_enable(v - 230); return CAREL_OK; }     // encoder forward: LayerNorm f32 outputs stored and re-read / recomputed by the next residual epilogue (default)
   if (v >= 220 && v <= 225) { gemm_tri_enable(v - 220); return CAREL_OK; }             // three-group kernel for the N = 768 forward GEMMs off (default) / on
   if (v == 210 || v == 211) { tail_overlap_enable(v - 210); return CAREL_OK; }           // VAE tail: loss kernel on the side stream beside the decoder passes off / on (default)
@@ -743,6 +751,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   g_gemm_variant = v;
   return CAREL_OK;
 }
+#endif   // CAREL_EXPERIMENTS
 
 extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) { return carel::gemm_bf16_ex(a, 1, stream_); }
 
@@ -863,6 +872,35 @@ int gemm_wgrad_splits_max(int M, int N, long T) {
   return ab > c ? ab : c;
 }
 }  // namespace carel
+
+// ---- grouped weight gradients (gemm_pp.hip) --------------------------------------------------------------------------------------------
+static int wgrad_group_probs(const carel_wgrad_group_args* a, WgradGroupProb* pb) {
+  if (!a || a->n_prob < 1 || a->n_prob > 4) return 0;
+  for (int i = 0; i < a->n_prob; ++i) pb[i] = WgradGroupProb{a->prob[i].dY, a->prob[i].X, a->prob[i].dW, a->prob[i].db, a->prob[i].M, a->prob[i].N};
+  return a->n_prob;
+}
+extern "C" int64_t carel_gemm_wgrad_group_ws_bytes(const carel_wgrad_group_args* a) {
+  WgradGroupProb pb[4];
+  const int n = wgrad_group_probs(a, pb);
+  if (!n || !gemm_pp_wgrad_group_ok(pb, n, (long)a->T)) return -1;
+  return (int64_t)gemm_pp_wgrad_group_ws_bytes(pb, n, (long)a->T);
+}
+extern "C" int carel_gemm_wgrad_group(const carel_wgrad_group_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradGroupProb pb[4];
+  const int n = wgrad_group_probs(a, pb);
+  if (!n) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: null args or n_prob outside 1..4");
+  if (a->n_ln < 0 || a->n_ln > 2) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: n_ln outside 0..2");
+  WgradGroupLn ln[2];
+  for (int i = 0; i < a->n_ln; ++i) {
+    if (!a->ln[i].partials || a->ln[i].rows < 1) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: null LayerNorm partials");
+    ln[i] = WgradGroupLn{a->ln[i].partials, carel_layernorm_bwd_blocks(a->ln[i].rows), a->ln[i].dgamma, a->ln[i].dbeta, a->ln[i].dbias};
+  }
+  double fl = 0.0;
+  for (int i = 0; i < n; ++i) fl += 2.0 * (double)pb[i].M * (double)pb[i].N * (double)a->T;
+  ProfScope prof_scope(stream, fl);         // (the bracket covers the reduction launch too)
+  return gemm_pp_wgrad_group(pb, n, (long)a->T, a->workspace, a->workspace_bytes > 0 ? (size_t)a->workspace_bytes : 0, ln, a->n_ln, stream);
+}
 
 extern "C" int carel_slab_reduce_f32(const void* slabs, void* out, long n, int splits, int accumulate,
                                      void* stream_) {

@@ -394,6 +394,7 @@ int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipSt
 int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi);
 int gemm_pp_launch_pair(const GemmParams& p, bool bt, int epi, hipStream_t s);
 void gemm_pp_pair_enable(int on);
-constexpr size_t PP_PAIR_FLAG_BYTES = 4096;   // NT / NN, `splits` K slices -> fp32 slabs at p.outf
+void gemm_pp_group_mode(int m);
+constexpr size_t PP_PAIR_FLAG_BYTES = 4096;
 
 }  // namespace carel

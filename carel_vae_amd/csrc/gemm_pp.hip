@@ -25,8 +25,10 @@
 //         NN: 64 k-rows x 96 columns in a 256-B-pitch COL image = 16 KiB (12 of 16 chunks per row populated)
 //   image row r of B_j <-> tile column (r / 48) * 48*NPN + j*48 + r % 48, i.e. each wave's columns are contiguous.
 #include <atomic>
+#include <type_traits>
 #include <utility>
 #include "gemm_epilogue.h"
+#include "reduce_device.h"
 
 namespace carel {
 
@@ -67,9 +69,9 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-static int g_pp_gelu_lut = 1;    // tuning hook (carel_gemm_set_variant(160 / 161)): GELU epilogues by erf / exp arithmetic / by table lookup
-static int g_pp_epi_prefetch = 1;   // tuning hook (carel_gemm_set_variant(170 / 171)): epilogue inputs requested at the end / before the main loop
-static int g_pp_xcd_rect = 1;    // tuning hook (carel_gemm_set_variant(120 / 121)): XCD tile map of the NT / NN forms: row-major chunks / rectangles
+CAREL_TUNABLE(int, g_pp_gelu_lut, 1);    // tuning hook (carel_gemm_set_variant(160 / 161)): GELU epilogues by erf / exp arithmetic / by table lookup
+CAREL_TUNABLE(int, g_pp_epi_prefetch, 1);   // tuning hook (carel_gemm_set_variant(170 / 171)): epilogue inputs requested at the end / before the main loop
+CAREL_TUNABLE(int, g_pp_xcd_rect, 1);    // tuning hook (carel_gemm_set_variant(120 / 121)): XCD tile map of the NT / NN forms: row-major chunks / rectangles
 constexpr int PP_A_BYTES = 32768;
 #ifndef CAREL_PP_MPRIO
 #define CAREL_PP_MPRIO 1           // s_setprio level of the matrix segment (experiment: CAREL_EXTRA_FLAGS=-DCAREL_PP_MPRIO=0)
@@ -98,11 +100,32 @@ template <int NPN, bool BT> struct PPGeom {
 // kernels or other processes sharing the GPU.  All pair traffic is system-scope (write-through stores, cache-bypassing loads): it
 // does not rely on A and B sharing an XCD's L2.  The sum is (first half of K) + (second half): deterministic, but not the bits of the
 // one-workgroup order.
-template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false, bool PAIR = false>
+// GROUP (weight-gradient form only; round 4): ONE launch computes up to four weight gradients dW_g[M_g, N_g] = dY_g^T X_g over the same T
+// tokens -- the four linears of an encoder layer -- from a work list in the kernel arguments.  An item is a 256 x 96 output tile with either
+// the WHOLE contraction (its result goes straight into dW: no slab, no reduction pass) or one of `s` K slices of a tile (a compact partial
+// tile in the workspace, summed in slice order by wgrad_group_reduce_kernel).  The list holds a multiple of the CU count of whole tiles
+// first and splits only the remainder (an encoder layer at T = 8192: 288 tiles = 256 whole + 32 x 8 slices; every CU runs 128 + 16 K
+// tiles), so the slab traffic of the per-GEMM split-K launches (5 / 5 / 3 / 9 slabs written and read back: 1.98 GB per step) shrinks to
+// the 32 split tiles (25 MB per layer) and four launches + four reductions become one + one.  Item order = dispatch order: workgroup i runs
+// on XCD i % 8, and the list gives each XCD a run of consecutive tiles of ONE problem (same dY columns or same X columns: shared through
+// its L2).  No workgroup waits for another: nothing here can deadlock, whatever else shares the GPU.
+struct PPGroupProb { const bf16_t* A; const bf16_t* B; float* out; float* colsum; int M, N; };      // A = dY [T, M], B = X [T, N], out = dW [M, N], colsum = db [M] or null
+constexpr int PP_GROUP_MAX_ITEMS = 768;
+struct PPGroup {
+  PPGroupProb prob[4];
+  float* part;                       // [n_items - n_full][256 * 96] partial tiles of the split items, in item order
+  float* cs_part;                    // [n_items - n_full][256] their bias-gradient partials
+  int nk, s, n_full, n_items;        // K tiles (T / 64); slices per split tile; whole-tile items; all items
+  unsigned short item[PP_GROUP_MAX_ITEMS];    // problem | tile row << 2 | tile column << 6 | (slice + 1, 0 = whole) << 11
+};
+struct PPNoGroup {};
+
+template <int NPN, bool AT, bool BT, int EPI, int DBG = 0, bool WIDE = false, bool PAIR = false, bool GROUP = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_pp_kernel(const bf16_t* A_, const bf16_t* B_, long lda_, long ldb_, int M_, int K_, int tiles_m_,
-                                                         int tiles_n_, int pp_xr_, int pp_bc_, GemmParams p) {
+                                                         int tiles_n_, int pp_xr_, int pp_bc_, GemmParams p, std::conditional_t<GROUP, PPGroup, PPNoGroup> grp) {
   p.A = A_; p.B = B_; p.lda = lda_; p.ldb = ldb_; p.M = M_; p.K = K_; p.tiles_m = tiles_m_; p.tiles_n = tiles_n_; p.pp_xr = pp_xr_; p.pp_bc = pp_bc_;
   static_assert(!AT || BT, "the A^T form (weight gradient) has both operands K-strided");
+  static_assert(!GROUP || (AT && EPI == EPI_SLAB_F32 && !PAIR), "grouped launches exist for the weight-gradient form only");
   using S = std::conditional_t<WIDE, PPSchedW<NPN>, PPSched<NPN>>;
   using G = PPGeom<NPN, BT>;
   static_assert(S::STAGES == PPSched<NPN>::STAGES, "PPGeom sizes the LDS from the fine schedule's stage count");
@@ -122,7 +145,24 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // wait then absorbs the previous tile's store acknowledgements, and those arrive at the HBM write rate -- an XCD's 32 CUs
   // write more per round than its L2 holds -- so nothing overlapped, and the loop-carried state cost 40-60 VGPRs.)
   int tm, tn, kz = 0;                                            // kz = K slice (weight-gradient form), not blockIdx.z: see below
-  {
+  int g_kt0 = 0, g_kt1 = 0;                                      // (GROUP: this item's K tiles)
+  if constexpr (GROUP) {
+    const unsigned code = grp.item[blockIdx.x];
+    const int gi = (int)(code & 3u), sl = (int)((code >> 11) & 15u);
+    tm = (int)((code >> 2) & 15u); tn = (int)((code >> 6) & 31u);
+    // (a select chain, not grp.prob[gi]: a dynamically indexed by-value argument may be copied to scratch memory)
+    const PPGroupProb pr = gi == 0 ? grp.prob[0] : gi == 1 ? grp.prob[1] : gi == 2 ? grp.prob[2] : grp.prob[3];
+    p.A = pr.A; p.B = pr.B; p.lda = pr.M; p.ldb = pr.N; p.M = pr.M; p.N = pr.N; p.ldc = pr.N; p.outf = pr.out; p.colsum_a = pr.colsum;
+    p.K = grp.nk << 6;
+    g_kt1 = grp.nk;
+    if (sl) {                                                    // one K slice of a split tile: compact partial tile [256][96 NPN] in the workspace
+      const long j = (long)blockIdx.x - grp.n_full;
+      p.ldc = 96 * NPN;
+      p.outf = grp.part + j * (256 * 96 * NPN) - ((long)tm * 256 * (96 * NPN) + (long)tn * (96 * NPN));
+      if (p.colsum_a) p.colsum_a = grp.cs_part + j * 256 - (long)tm * 256;
+      g_kt0 = ((sl - 1) * grp.nk) / grp.s; g_kt1 = (sl * grp.nk) / grp.s;      // (K tiles dealt to the slices as evenly as possible)
+    }
+  } else {
     const int tiles = p.tiles_m * p.tiles_n;
     // position in dispatch order (x fastest, then z); workgroups are dealt to the XCDs round-robin in that order
     // (row-major-A forms with an internal K split, gridDim.z > 1: every K slice walks the same tile map; kz = blockIdx.z)
@@ -197,7 +237,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   // K range of this z slice: the K tiles are dealt to gridDim.z slices as evenly as possible (slices may differ by one)
   const int nk_all = p.K >> 6;
-  const int kt0 = (int)(((long)kz * nk_all) / gridDim.z), kt1 = (int)(((long)(kz + 1) * nk_all) / gridDim.z);
+  const int kt0 = GROUP ? g_kt0 : (int)(((long)kz * nk_all) / gridDim.z), kt1 = GROUP ? g_kt1 : (int)(((long)(kz + 1) * nk_all) / gridDim.z);
   const int nk = kt1 - kt0;
   const long a_step = AT ? 64 * p.lda * 2 : 128, b_step = BT ? 64 * p.ldb * 2 : 128;
   const char* a_ptr = (const char*)(AT ? p.A + m0 : p.A + m0 * p.lda) + kt0 * a_step;      // first K tile of the slice
@@ -646,11 +686,112 @@ int launch_pp(GemmParams p, int splits, hipStream_t s) {
     }
   }
   hipLaunchKernelGGL((gemm_pp_kernel<NPN, AT, BT, EPI, DBG, WIDE, PAIR>), dim3(p.tiles_m * p.tiles_n, 1, splits), dim3(512), LDS_BYTES, s, p.A, p.B, p.lda,
-                     p.ldb, p.M, p.K, p.tiles_m, p.tiles_n, p.pp_xr, p.pp_bc, p);
+                     p.ldb, p.M, p.K, p.tiles_m, p.tiles_n, p.pp_xr, p.pp_bc, p, PPNoGroup{});
   return check_launch("gemm_pp_kernel");
 }
 
-static int g_pp_wide = 1;        // tuning hook (carel_gemm_set_variant(90 / 91)): the fine (12-MFMA phases) / wide-phase schedule
+// ---- grouped weight gradients (GROUP): reduction of the split tiles + the small sums that ride along ---------------------------------
+// Blocks [0, P * TB): split tile t = b / TB, 256 float4 of it per block: out = sum over the s slices IN SLICE ORDER (fixed order of additions:
+// bit-reproducible) of the compact partial tiles, written to the tile's place in dW.  Blocks [P * TB, P * TB + P): the bias-gradient
+// partials of split tile t (first tile column of a problem with a bias gradient only).  The blocks after that sum the per-block partials of up
+// to two LayerNorm backward passes into dgamma / dbeta / bias gradient (partial_colsum16: the device function, and the bits, of
+// partial_reduce_seg_kernel) -- they used to ride on the per-GEMM slab reductions.
+struct PPGroupLn { const float* partials; SegOuts outs; int nparts; };
+template <int NPN>
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(PPGroup grp, PPGroupLn ln0, PPGroupLn ln1) {
+  constexpr int BN = 96 * NPN, TILE = 256 * BN, TB = TILE / 4 / 256;
+  __shared__ float lds[256];
+  const int P = grp.s > 0 ? (grp.n_items - grp.n_full) / grp.s : 0;
+  int b = (int)blockIdx.x;
+  if (b < P * TB + P) {
+    const bool cs = b >= P * TB;
+    const int t = cs ? b - P * TB : b / TB;
+    const unsigned code = grp.item[grp.n_full + t * grp.s];
+    const int gi = (int)(code & 3u), tm = (int)((code >> 2) & 15u), tn = (int)((code >> 6) & 31u);
+    const PPGroupProb pr = gi == 0 ? grp.prob[0] : gi == 1 ? grp.prob[1] : gi == 2 ? grp.prob[2] : grp.prob[3];
+    if (cs) {
+      if (!pr.colsum || tn != 0) return;
+      const float* src = grp.cs_part + (long)t * grp.s * 256 + threadIdx.x;
+      float a = src[0];
+      for (int z = 1; z < grp.s; ++z) a += src[(long)z * 256];
+      pr.colsum[tm * 256 + threadIdx.x] = a;
+      return;
+    }
+    const int i4 = (b - t * TB) * 256 + (int)threadIdx.x;          // float4 index inside the tile
+    const int r = i4 / (BN / 4), c4 = i4 - r * (BN / 4);
+    const float* src = grp.part + (long)t * grp.s * TILE + (long)i4 * 4;
+    float4 a = *(const float4*)src;
+    int z = 1;
+    for (; z + 3 < grp.s; z += 4) {                                  // four slices requested before the first add (same order of additions)
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(src + (long)(z + u) * TILE);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; z < grp.s; ++z) {
+      const float4 v = *(const float4*)(src + (long)z * TILE);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *(float4*)(pr.out + ((long)tm * 256 + r) * pr.N + (long)tn * BN + c4 * 4) = a;
+    return;
+  }
+  b -= P * TB + P;
+  constexpr int LNB = (3 * 768 + PR_COLS - 1) / PR_COLS;
+  const PPGroupLn& ln = b < LNB ? ln0 : ln1;
+  if (b >= LNB) b -= LNB;
+  if (!ln.partials) return;
+  int c;
+  const float tsum = partial_colsum16(ln.partials, 3 * 768, ln.nparts, lds, c, b);
+  if (threadIdx.x < PR_COLS && c < 3 * 768) {
+    float* o = ln.outs.p[c / 768];
+    if (o) o[c % 768] = tsum;
+  }
+}
+
+// the work list of a grouped launch (see PPGroup): `cus` whole tiles per round first, each XCD's share a run of consecutive tiles in
+// (problem, tile row, tile column) order; the remaining tiles split into s K slices each
+static int wgrad_group_plan(const WgradGroupProb* pb, int n, long T, PPGroup& g, int npn, bool allow_split = true) {
+  const int BN = 96 * npn, cus = 256;
+  if (n < 1 || n > 4 || T < 256 || (T & 63)) return 0;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (pb[i].M < 256 || pb[i].M % 256 || pb[i].N < BN || pb[i].N % BN || pb[i].M / 256 > 16 || pb[i].N / BN > 32) return 0;
+    tiles += (pb[i].M / 256) * (pb[i].N / BN);
+  }
+  const int nk = (int)(T >> 6);
+  int n_full = (tiles / cus) * cus, P = tiles - n_full, s = 0;
+  if (P > 0 && !allow_split) { n_full = tiles; P = 0; }
+  if (P > 0) {
+    s = cus / P;                                   // the split items fill one more round of the chip ...
+    if (s > 8) s = 8;
+    if (s > nk / 4) s = nk / 4;                    // ... with at least four K tiles each (the static schedule's prologue + tail)
+    if (s < 2) { s = 0; n_full = tiles; P = 0; }   // not worth splitting: the remainder runs as whole tiles in a last partial round
+  }
+  if (nk < 4 || n_full + P * s > PP_GROUP_MAX_ITEMS) return 0;
+  unsigned short lin[PP_GROUP_MAX_ITEMS];
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    for (int tm = 0; tm < pb[i].M / 256; ++tm)
+      for (int tn = 0; tn < pb[i].N / BN; ++tn) lin[k++] = (unsigned short)(i | (tm << 2) | (tn << 6));
+  // whole tiles: round r (cus tiles) of the linear order, XCD x takes the run [x * cus / 8, (x + 1) * cus / 8) of it; dispatch slot 8 q + x
+  const int per = cus / 8, full_rounds = (n_full / cus) * cus;
+  for (int f = 0; f < full_rounds; ++f) {
+    const int r = f / cus, w = f - r * cus, x = w & 7, q = w >> 3;
+    g.item[f] = lin[r * cus + x * per + q];
+  }
+  for (int f = full_rounds; f < n_full; ++f) g.item[f] = lin[f];      // a last partial round of whole tiles (s = 0 above): plain order
+  for (int t = 0; t < P; ++t)
+    for (int z = 0; z < s; ++z) g.item[n_full + t * s + z] = (unsigned short)(lin[n_full + t] | ((z + 1) << 11));
+  for (int i = 0; i < 4; ++i) {
+    const WgradGroupProb& q = pb[i < n ? i : 0];
+    g.prob[i] = PPGroupProb{(const bf16_t*)q.dY, (const bf16_t*)q.X, (float*)q.dW, (float*)q.db, q.M, q.N};
+  }
+  g.nk = nk; g.s = s; g.n_full = n_full; g.n_items = n_full + P * s;
+  return 1;
+}
+
+CAREL_TUNABLE(int, g_pp_wide, 1);        // tuning hook (carel_gemm_set_variant(90 / 91)): the fine (12-MFMA phases) / wide-phase schedule
 
 template <bool BT, int EPI>
 int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
@@ -661,6 +802,70 @@ int launch_pp_n(const GemmParams& p, int npn, hipStream_t s) {
 }
 
 }  // namespace
+
+size_t gemm_pp_wgrad_group_ws_bytes(const WgradGroupProb* pb, int n, long T) {
+  PPGroup g;
+  if (!wgrad_group_plan(pb, n, T, g, 1)) return 0;
+  return (size_t)(g.n_items - g.n_full) * (256 * 96 + 256) * 4 + 256;
+}
+
+// 0 = this problem list cannot run grouped (the caller falls back to one GEMM per weight gradient)
+int gemm_pp_wgrad_group_ok(const WgradGroupProb* pb, int n, long T) {
+  PPGroup g;
+  return wgrad_group_plan(pb, n, T, g, 1);
+}
+
+CAREL_TUNABLE(int, g_group_mode, 0);       // (experiments, hook 250 + m) 0 = 256 x 96 tiles, remainder split along K (product); 1 = 256 x 192 whole tiles; 2 = 256 x 96 whole tiles
+#ifdef CAREL_EXPERIMENTS
+void gemm_pp_group_mode(int m) { g_group_mode = (m >= 0 && m <= 2) ? m : 0; }
+#endif
+template <int NPN>
+static int wgrad_group_launch(const WgradGroupProb* pb, int n, long T, void* ws, size_t ws_bytes, const WgradGroupLn* ln, int n_ln, bool allow_split, hipStream_t stream) {
+  PPGroup g;
+  if (!pb || !wgrad_group_plan(pb, n, T, g, NPN, allow_split)) return set_error(CAREL_ERR_SHAPE, "carel_gemm_wgrad_group: 1-4 problems with M a multiple of 256 (<= 4096), N of 96 (<= 3072), T of 64 (>= 256)");
+  for (int i = 0; i < n; ++i) {
+    if (!pb[i].dY || !pb[i].X || !pb[i].dW) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: null operand");
+    if (((uintptr_t)pb[i].dY | (uintptr_t)pb[i].X | (uintptr_t)pb[i].dW) & 15) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: operands must be 16-byte aligned");
+  }
+  const int n_split = g.n_items - g.n_full;
+  const size_t need = (size_t)n_split * (256 * 96 * NPN + 256) * 4 + 256;
+  if (n_split && (!ws || ws_bytes < need || ((uintptr_t)ws & 15))) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: workspace of %zu bytes needed (carel_gemm_wgrad_group_ws_bytes)", need);
+  if (n_ln < 0 || n_ln > 2 || (n_ln && !ln)) return set_error(CAREL_ERR_ARG, "carel_gemm_wgrad_group: at most two LayerNorm partial sets");
+  g.part = (float*)ws;
+  g.cs_part = g.part + (size_t)n_split * 256 * 96 * NPN;
+  using G = PPGeom<NPN, true>;
+  constexpr int LDS_BYTES = G::LDS;
+  auto kern = gemm_pp_kernel<NPN, true, true, EPI_SLAB_F32, 0, true, false, true>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "gemm_pp_kernel (grouped): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = true;
+  }
+  GemmParams p = {};
+  p.gelu_lut = 0; p.epi_prefetch = 0; p.pp_bc = 1;
+  hipLaunchKernelGGL(kern, dim3(g.n_items), dim3(512), LDS_BYTES, stream, (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0L, 0L, 0, 0, 0, 0, 0, 1, p, g);
+  int rc = check_launch("gemm_pp_kernel (grouped weight gradients)");
+  if (rc) return rc;
+  PPGroupLn l[2] = {};
+  for (int i = 0; i < n_ln; ++i) {
+    l[i].partials = (const float*)ln[i].partials; l[i].nparts = ln[i].nparts;
+    l[i].outs.p[0] = (float*)ln[i].dgamma; l[i].outs.p[1] = (float*)ln[i].dbeta; l[i].outs.p[2] = (float*)ln[i].dbias; l[i].outs.p[3] = nullptr;
+  }
+  constexpr int TB = 256 * 96 * NPN / 4 / 256, LNB = (3 * 768 + PR_COLS - 1) / PR_COLS;
+  const int P = g.s ? n_split / g.s : 0;
+  const int blocks = P * TB + P + n_ln * LNB;
+  if (blocks == 0) return CAREL_OK;
+  hipLaunchKernelGGL((wgrad_group_reduce_kernel<NPN>), dim3(blocks), dim3(256), 0, stream, g, l[0], l[1]);
+  return check_launch("wgrad_group_reduce_kernel");
+}
+int gemm_pp_wgrad_group(const WgradGroupProb* pb, int n, long T, void* ws, size_t ws_bytes, const WgradGroupLn* ln, int n_ln, hipStream_t stream) {
+#ifdef CAREL_EXPERIMENTS
+  if (g_group_mode == 1) return wgrad_group_launch<2>(pb, n, T, ws, ws_bytes, ln, n_ln, false, stream);
+  if (g_group_mode == 2) return wgrad_group_launch<1>(pb, n, T, ws, ws_bytes, ln, n_ln, false, stream);
+#endif
+  return wgrad_group_launch<1>(pb, n, T, ws, ws_bytes, ln, n_ln, true, stream);
+}
 
 int gemm_pp_init_device(int device) {
   if (device < 0 || device >= 16) return set_error(CAREL_ERR_ARG, "carel_init: device index %d out of range", device);
@@ -675,12 +880,14 @@ int gemm_pp_init_device(int device) {
   g_lut_state[device].store(1, std::memory_order_release);     // two racing initialisers both fill the same values: harmless
   return CAREL_OK;
 }
+CAREL_TUNABLE(int, g_pp_force_npn, 0);     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
+#ifdef CAREL_EXPERIMENTS
 void gemm_pp_wide_variant(int on) { g_pp_wide = on ? 1 : 0; }
 void gemm_pp_xcd_rect(int on) { g_pp_xcd_rect = on ? 1 : 0; }
 void gemm_pp_gelu_lut(int on) { g_pp_gelu_lut = on ? 1 : 0; }
 void gemm_pp_epi_prefetch(int on) { g_pp_epi_prefetch = on ? 1 : 0; }
-static int g_pp_force_npn = 0;     // tuning hook (carel_gemm_set_variant(70 + n)): tile width 96 n wherever N allows; 0 = heuristic
 void gemm_pp_force_npn(int n) { g_pp_force_npn = (n >= 1 && n <= 3) ? n : 0; }
+#endif
 
 // npn (1..3) when the ping-pong kernel should run this GEMM, 0 when it cannot or should not.
 int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
@@ -730,8 +937,10 @@ int gemm_pp_pick_tn(const GemmParams& p, int splits) {
 
 // The split-K factor the ping-pong kernel wants for dW[M,N] = A^T B over K tokens: as many slices as keep <= 256
 // workgroups of the wider tile, each with at least 8 K tiles, at most 16 slabs.  0 = shape not supported.
-static int g_pp_wgrad_force = 0;   // tuning hook (carel_gemm_set_variant(100 + s)): this split-K factor for every supported weight gradient
+CAREL_TUNABLE(int, g_pp_wgrad_force, 0);   // tuning hook (carel_gemm_set_variant(100 + s)): this split-K factor for every supported weight gradient
+#ifdef CAREL_EXPERIMENTS
 void gemm_pp_wgrad_force(int s) { g_pp_wgrad_force = (s >= 0 && s <= 16) ? s : 0; }
+#endif
 
 int gemm_pp_wgrad_splits(int M, int N, long K) {
   if (M % 256 || N % 96 || K % 64 || K < 512) return 0;
@@ -777,7 +986,8 @@ int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipSt
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_slab: npn = %d not built", npn);
 }
 
-// ---- pair split-K ---------------------------------------------------------------------------------------------------------------------
+// ---- pair split-K (EXPERIMENTS build only) ---------------------------------------------------------------------------------------------
+#ifdef CAREL_EXPERIMENTS
 // OFF by default -- built, correct, measured slower (tools/bench_gemm_cold.py, PAIR=0 / 1 on one box, hot / cold operands): FFN2 forward
 // 47.1 / 55.4 -> 51.9 / 57.3 us, FFN1 data gradient 45.9 / 53.5 -> 51.5 / 63.8, QKV data gradient 38.4 / 43.8 -> 43.0 / 53.3.  The 256 x 192
 // main loop is only ~9 % more efficient per FLOP than the 256 x 96 one (1.40 us per K tile against 2 x 0.77), which saves ~3 us per
@@ -807,6 +1017,7 @@ int gemm_pp_launch_pair(const GemmParams& p0, bool bt, int epi, hipStream_t s) {
   if (bt && epi == EPI_ADD_F32) return launch_pp<2, false, true, EPI_ADD_F32, 0, true, true>(p, 2, s);
   return set_error(CAREL_ERR_ARG, "gemm_pp_launch_pair: unsupported form/epilogue (%d,%d)", (int)bt, epi);
 }
+#endif   // CAREL_EXPERIMENTS
 
 #ifdef CAREL_GEMM_ABLATE
 int gemm_pp_launch_dbg(const GemmParams& p, int npn, int dbg, hipStream_t s) {     // NT, bias -> bf16 epilogue only

@@ -31,6 +31,7 @@
 // dropout / residual expression is the one of epi_out8, the normalisation is ln_normalise: the results equal the two-kernel path bit
 // for bit (tests/test_gpu_gemm.py::test_rowln_equals_gemm_then_layernorm_bitwise).
 // Only worth it when the row count fills the chip (256 workgroups at T = 8192): packed ECPE batches (~1.8 k rows) keep the old path.
+#ifdef CAREL_EXPERIMENTS      // an experiment (built, measured, not adopted): not part of the product library
 #include "gemm_epilogue.h"
 #include "ln_device.h"
 
@@ -257,3 +258,5 @@ int gemm_rowln_launch(const RowLnParams& p, bool packed, hipStream_t s) {
 }
 
 }  // namespace carel
+
+#endif   // CAREL_EXPERIMENTS

@@ -23,6 +23,7 @@
 //     group 2 issues tile i + 2 in L1(i) (slot 3i + 2)                  and waits for tile i + 1 at the end of L1(i);
 // all three waits fall in slot 3i + 2, whose barrier publishes tile i + 1 before its first read (slot 3i + 3), and each leaves exactly
 // the 4 newer pieces (tile i + 2) in flight: s_waitcnt vmcnt(4), vmcnt(0) once nothing newer was issued.
+#ifdef CAREL_EXPERIMENTS      // an experiment (built, measured, not adopted): not part of the product library
 #include "gemm_epilogue.h"
 
 namespace carel {
@@ -207,3 +208,5 @@ int gemm_tri_launch(const GemmParams& p, int epi, hipStream_t s) {
 }
 
 }  // namespace carel
+
+#endif   // CAREL_EXPERIMENTS

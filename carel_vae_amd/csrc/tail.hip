@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256) void mmd_global_kernel(MmdGlobalArgs a) {
 static long long* g_tail_prof = nullptr;
 // tuning hook (carel_gemm_set_variant(210 / 211)): the single-workgroup loss kernel (~50 us on ONE CU) on the library's low-priority side stream
 // while the reconstruction decoder's passes (~100 us, 186 workgroups) run on the caller's stream, joined before the two results meet
-static int g_tail_overlap = 1;
+CAREL_TUNABLE(int, g_tail_overlap, 1);
+#ifdef CAREL_EXPERIMENTS
 void tail_overlap_enable(int on) { g_tail_overlap = on ? 1 : 0; }
+#endif
 struct TailEvents { hipEvent_t fork, join; bool ok; };
 static TailEvents* tail_events() {               // two events per device, created on first use and kept for the life of the process
   static TailEvents per_dev[16];

@@ -12,8 +12,10 @@
  *   - every call only ENQUEUES work on `stream` (void* = hipStream_t): no device allocation, no host sync.  Process-wide
  *     state the library does keep: the thread-local error string; per device, three library-owned streams and ten events
  *     created on first use (overlap_wgrad / forward chains, see carel_encoder_args); a 20-KiB table of gelu / gelu' by bf16 input in
- *     device memory, filled by the first GELU GEMM of the process (that one call synchronises the device); the tuning hooks set through
- *     carel_gemm_set_variant; the carel_profile_gemm event log.  None of it changes results;
+ *     device memory, filled by carel_init (the one call that synchronises the device), immutable afterwards; the carel_profile_gemm
+ *     event log (measurement aid).  None of it changes results.  The product library has NO tuning hooks and no other mutable
+ *     process-wide state (ABI 7): carel_gemm_set_variant and the kernels that were built, measured and not adopted live in the
+ *     EXPERIMENTS build only (libcarel_hip_exp.so, -DCAREL_EXPERIMENTS; include/carel_hip_experiments.h);
  *   - return 0 on success, a negative CAREL_ERR_* otherwise; carel_last_error() gives the message;
  *   - "bf16" = raw bfloat16 bits (uint16_t); "f32" = IEEE float.
  */
@@ -30,7 +32,7 @@ extern "C" {
 #define CAREL_ERR_HIP (-3)    /* a HIP runtime call or launch failed    */
 
 /* ABI version of this header; carel_abi_version() must return the same number. */
-#define CAREL_ABI_VERSION 6
+#define CAREL_ABI_VERSION 7
 
 int carel_abi_version(void);
 /* Checks that `device` is a gfx950 part and fills the library's only per-device state, immutable afterwards: the 20-KiB GELU table of
@@ -115,18 +117,6 @@ int carel_gemm_bf16(const carel_gemm_args* args, void* stream);
  * `splits` with an out_f32 of [splits][M][ldc] floats, then carel_slab_reduce_f32.  With the 256 x 96n kernel the T/64
  * K tiles are dealt to the slices as evenly as possible, so T need not be a multiple of 64 * splits. */
 int32_t carel_gemm_wgrad_splits(int32_t M, int32_t N, int64_t T);
-/* test / tuning hook (process-wide, not thread-safe: set it before any other thread calls the library): 0 = choose the
- * kernel automatically, 1 = 128x128 kernel only, 2 = force the old 256x192 kernel, 3 = the 256 x 96n ping-pong kernel
- * wherever the shape allows; 50+k = the ping-pong kernel takes grids of at least 32*k workgroups (default 192);
- * 30/31 = automatic use of the old 256x192 tile off/on; 20..24 XCD tile layouts of the 128x128 kernel; 70+n = ping-pong tile width
- * 96n forced (0 = heuristic); 90/91 = ping-pong schedule with fine (12-MFMA) / wide (24-MFMA, default) phases; 100+s = weight-gradient
- * split-K factor of the ping-pong kernel forced to s (0 = heuristic); 120/121 = its XCD tile map: row-major chunks / rectangles
- * (default); 130/131 = internal split-K for K >= 1536 only / also for the K = 768 one-row-tile GEMMs (default); 140/141 = the K slices
- * of an internally split NT / NN GEMM on the 128x128 kernel / on the ping-pong kernel where they fit one round (default); 160/161 = the
- * ping-pong kernel's GELU epilogues by erf / exp arithmetic / by table lookup (default; the same bits); 11..19, 61..68 timing
- * ablations (wrong results; only in a -DCAREL_GEMM_ABLATE build).  None of the non-ablation settings changes results beyond the fp32
- * summation order of split-K. */
-int carel_gemm_set_variant(int32_t variant);
 /* Measurement aid (bench.py roofline leg): while enabled, every carel_gemm_bf16 launch is bracketed by
  * HIP events on its stream.  carel_profile_gemm_read() synchronises and returns the summed kernel time
  * (ms), the summed algorithmic flops (2*M*N*K) and the launch count, then resets the log. */
@@ -135,43 +125,47 @@ int carel_profile_gemm_read(double* total_ms, double* total_flops, int64_t* laun
 /* the two calibration medians of the last read-out, us: an event pair around an empty kernel (what _read subtracts from every
  * bracket), and an event pair with nothing in between */
 int carel_profile_gemm_overheads(double* empty_kernel_bracket_us, double* event_pair_us);
-/* ------------------------------------------------------------------------------------------------
- * Row-band GEMM with the sub-layer tail fused (ABI 5):
- *     h = dropout(A W^T + bias) + resid ;  x = LayerNorm(h) * gamma + beta        for 768-wide outputs
- * Replaces nn.Linear + nn.Dropout + residual add + nn.LayerNorm of HF BertSelfOutput / BertOutput (reached from
- * drl_classifier_ec_mmd_final_mul.py:202-206) in ONE kernel: each workgroup owns 32 complete rows, so the pre-LayerNorm sum never
- * makes a round trip through memory.  Bit-identical to carel_gemm_bf16(CAREL_EPI_BIAS_DROP_RESID) followed by carel_layernorm_fwd.
- * Every workgroup streams the whole weight matrix from L2, so it pays only when M / 32 workgroups fill the chip (M >= ~6000 rows);
- * the encoder uses it for dense batches and keeps the two-kernel path for packed ECPE batches.
- * ---------------------------------------------------------------------------------------------- */
-typedef struct carel_gemm_rowln_args {
-  const void* A;          /* bf16 [M, K], leading dimension lda (elements, multiple of 8) */
-  const void* W;          /* bf16 [768, K] (nn.Linear weight), leading dimension ldb; or, with w_packed = 1, the same matrix in the
-                             MFMA-operand order written by carel_gemm_rowln_pack (768 * K elements, ldb ignored): the weight stream is
-                             then contiguous per load instruction -- 3-4x the rate of the row-major layout */
-  int64_t lda, ldb;
-  int32_t M, K;           /* any M >= 1; K multiple of 128 */
-  const void* bias;       /* f32 [768] or NULL */
-  const void* resid_f32;  /* f32 [M, 768] */
-  const void* gamma;      /* f32 [768] */
-  const void* beta;       /* f32 [768] */
-  float eps;
-  void* h_f32;            /* out f32 [M, 768]: the pre-LayerNorm sum (what carel_layernorm_bwd reads), or NULL */
-  void* x_f32;            /* out f32 [M, 768] or NULL */
-  void* x_bf16;           /* out bf16 [M, 768] or NULL */
-  void* stats;            /* out f32 [M, 2] (mean, rstd) or NULL */
-  uint32_t drop_seed, drop_site, drop_idx_offset;
-  float drop_p;
-  const void* drop_row_map; /* optional int32 [M], as in carel_gemm_args */
-  int32_t w_packed;       /* 0: W row-major; 1: W packed by carel_gemm_rowln_pack */
-} carel_gemm_rowln_args;
-int carel_gemm_rowln(const carel_gemm_rowln_args* args, void* stream);
-/* out[768 * K] = W[768, K] (leading dimension ldb) re-ordered as [n / 16][k / 64][(k / 32) % 2][(k / 8) % 4][n % 16][k % 8]: what a
- * wave of carel_gemm_rowln loads per instruction is then one contiguous KiB.  Run it whenever the weight changes (after an optimiser step). */
-int carel_gemm_rowln_pack(const void* W, int64_t ldb, int32_t K, void* out, void* stream);
 
 /* out[n] (+)= sum_z slabs[z][n];  n multiple of 4 */
 int carel_slab_reduce_f32(const void* slabs, void* out, int64_t n, int32_t splits, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Grouped weight gradients (ABI 7): up to four dW_g[M_g, N_g] = dY_g^T X_g over the SAME T tokens -- the four nn.Linear weights of an
+ * encoder layer: the dW half of `loss.backward()` (drl_classifier_ec_mmd_final_mul.py:841) for BertSelfAttention q/k/v,
+ * BertSelfOutput.dense, BertIntermediate.dense, BertOutput.dense -- in ONE launch of the 256 x 96 ping-pong kernel + one small
+ * reduction.  The launch's work list holds whole output tiles (full contraction, written straight into dW: no fp32 slabs) for as
+ * many rounds of the 256 CUs as the tile count fills, and splits only the remaining tiles into K slices whose compact partial
+ * tiles go through `workspace` and are summed in slice order (bit-reproducible).  An encoder layer at T = 8192: 288 tiles = 256 whole +
+ * 32 x 8 slices, 25 MB of workspace traffic instead of the 165 MB of slabs that four split-K launches write and read back.
+ * No workgroup waits for another one.  db (optional) = column sums of dY = the bias gradient of the same linear, from ones-vector MFMAs
+ * in the first tile column.  ln[] (optional): the per-block partials of up to two LayerNorm backward passes (carel_layernorm_bwd's scratch
+ * layout), summed into dgamma / dbeta / dbias by the same reduction launch (the arithmetic of carel_layernorm_bwd's own second pass).
+ * M_g multiple of 256 (<= 4096), N_g multiple of 96 (<= 3072), T multiple of 64 (>= 256); every pointer 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct carel_wgrad_problem {
+  const void* dY;   /* bf16 [T, M] row-major */
+  const void* X;    /* bf16 [T, N] row-major */
+  void* dW;         /* f32 [M, N] (nn.Linear weight layout) */
+  void* db;         /* f32 [M] or NULL */
+  int32_t M, N;
+} carel_wgrad_problem;
+typedef struct carel_ln_partial_set {
+  const void* partials;   /* f32 [carel_layernorm_bwd_blocks(rows)][3 * 768] */
+  int64_t rows;
+  void* dgamma; void* dbeta; void* dbias;   /* f32 [768] each; any may be NULL */
+} carel_ln_partial_set;
+typedef struct carel_wgrad_group_args {
+  carel_wgrad_problem prob[4];
+  int32_t n_prob;         /* 1..4 */
+  int64_t T;
+  void* workspace;        /* carel_gemm_wgrad_group_ws_bytes(args) bytes (may be 0: every tile whole) */
+  int64_t workspace_bytes;
+  carel_ln_partial_set ln[2];
+  int32_t n_ln;           /* 0..2 */
+} carel_wgrad_group_args;
+/* workspace size for these shapes (pointers are not read); -1 if the shapes cannot run grouped */
+int64_t carel_gemm_wgrad_group_ws_bytes(const carel_wgrad_group_args* args);
+int carel_gemm_wgrad_group(const carel_wgrad_group_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Embeddings + LayerNorm (HF BertEmbeddings / RobertaEmbeddings.forward) and its backward.
@@ -695,6 +689,9 @@ int carel_sgemm_f32(const void* A, int64_t lda, int32_t ta, const void* B, int64
  * ---------------------------------------------------------------------------------------------- */
 int carel_selftest_layouts(const void* in_bf16_40960, void* out_f32_73728, void* stream);
 
+#ifdef CAREL_EXPERIMENTS
+#include "carel_hip_experiments.h"
+#endif
 #ifdef __cplusplus
 }
 #endif

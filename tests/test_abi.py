@@ -15,8 +15,8 @@ def lib_path():
     return build.build(verbose=False)
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "carel_hip.h")).read()
+def header_functions(name="carel_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"^\s*(?:int|int32_t|int64_t|void\*|const char\*)\s+(carel_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
@@ -37,6 +37,26 @@ def test_every_declared_symbol_is_exported_and_bound(lib_path):
         assert hasattr(lib, n), "missing export: " + n
     assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
     assert _lib.load().carel_abi_version() == _lib.ABI_VERSION
+
+
+def test_product_library_has_no_tuning_hooks_and_the_experiments_build_has_them(lib_path):
+    """the product library exports no mutable tuning state -- carel_gemm_set_variant and the kernels that were built,
+    measured and not adopted (row-band GEMM + LayerNorm, three-group GEMM, pair split-K) exist in libcarel_hip_exp.so only
+    (-DCAREL_EXPERIMENTS, include/carel_hip_experiments.h), which exports the whole product surface as well."""
+    from carel_vae_amd import _lib, build
+    prod = ctypes.CDLL(lib_path)
+    exp_names = header_functions("carel_hip_experiments.h")
+    assert set(exp_names) == set(_lib.EXP_SIGNATURES) and "carel_gemm_set_variant" in exp_names
+    for n in exp_names:
+        assert not hasattr(prod, n), "the product library exports the experiments-only symbol " + n
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
+    for frag in ("gemm_tri", "gemm_rowln", "set_variant", "pair_enable", "gemm_pp_launch_pair"):
+        assert frag not in syms, frag
+    exp = ctypes.CDLL(build.lib_path(build.EXP_TAG))
+    for n in header_functions() + exp_names:
+        assert hasattr(exp, n), "missing export in the experiments library: " + n
+    assert os.path.getsize(lib_path) < os.path.getsize(build.lib_path(build.EXP_TAG))
 
 
 def test_argument_validation_without_a_gpu(lib_path):

@@ -152,6 +152,7 @@ def test_bad_shapes_are_refused():
         gemm(A, A, L.GEMM_NT, L.EPI_BIAS_BF16, 100, 128, 64, out_bf16=out)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("form", ["NT", "NN", "TN"])
 def test_both_tile_variants_agree(variant, form):
@@ -222,6 +223,7 @@ def test_internal_split_k_with_workspace_matches_single_pass():
     assert rel_err(o2, o1) < 1e-6 and rel_err(o2, A2.double() @ W2.double() + r.double()) < TOL
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("M", [1792, 1920, 640])
 def test_internal_split_on_the_ping_pong_kernel_is_bitwise_the_128_tile_split(M):
     """Packed ECPE batches (~1.8 k rows): the K slices of an internally split NT / NN GEMM run on the ping-pong kernel (hook 141, the
@@ -282,6 +284,7 @@ def _ints(shape, seed, lo=-3, hi=4):
 @pytest.mark.parametrize("form", ["NT", "NN"])
 @pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (8192, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 2304),
                                    (256, 96, 256), (2176, 192, 320), (1000, 288, 448), (3000, 576, 1024), (768, 192, 256), (2048, 960, 512)])
+@pytest.mark.experiments
 def test_pp_exact_integers(form, M, N, K, wide):
     """Exact small-integer data at the production shapes (M = 8192 x {768, 2304, 3072}) and at ragged M (edge rows are
     masked) / every npn: any stale LDS tile, wrong fragment map or missed k step shows as an integer difference."""
@@ -295,6 +298,7 @@ def test_pp_exact_integers(form, M, N, K, wide):
     assert torch.equal(out[M:], torch.full((8, N), 7.0, device="cuda"))
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
 def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, wide):
@@ -332,6 +336,7 @@ def test_pp_bitwise_equals_128_tile_every_epilogue(N, K, wide):
             assert torch.equal(res[3][k], res[1][k]), (k, float((res[3][k].float() - res[1][k].float()).abs().max()))
 
 
+@pytest.mark.experiments
 def test_gelu_table_of_the_ping_pong_epilogue_equals_the_arithmetic_on_every_bf16_value():
     """The ping-pong kernel's GELU epilogues look gelu(u) / gelu'(u) up in a table indexed by the bf16 bits of u (gemm_epilogue.h,
     gelu_lut8); the 128x128 kernel evaluates erf and exp.  A GEMM whose pre-activations run through EVERY finite bf16 value (one-hot A
@@ -369,6 +374,7 @@ def test_gelu_table_of_the_ping_pong_epilogue_equals_the_arithmetic_on_every_bf1
     assert float((res[3][1].double().cpu() - ref).abs().max() / 1.0) < 0.07 and rel_err(res[3][1], ref.float()) < TOL_BF16   # and they are GELU
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("wide", [1, 0])
 def test_pp_race_screen_repeated_launches(wide):
     """20 launches of each production shape on fresh random data, compared with the first launch bit for bit while a
@@ -397,6 +403,7 @@ def test_pp_race_screen_repeated_launches(wide):
 
 @pytest.mark.parametrize("T,Nout,Nin,splits", [(8192, 768, 3072, 5), (8192, 3072, 768, 5), (8192, 768, 768, 16), (8192, 2304, 768, 7),
                                               (1920, 768, 768, 3), (1024, 256, 96, 1), (4096, 512, 288, 4)])
+@pytest.mark.experiments
 def test_pp_wgrad_exact_integers_uneven_slices(T, Nout, Nin, splits):
     """A^T B form of the ping-pong kernel (weight gradients): K tiles dealt unevenly to the z slices (T/64 is not a
     multiple of `splits`), exact integer data, slabs summed against the fp64 product; the bias gradient (column sums
@@ -416,6 +423,7 @@ def test_pp_wgrad_exact_integers_uneven_slices(T, Nout, Nin, splits):
     assert torch.equal(slabs[z].double(), dY[k0:k1].double().t() @ X[k0:k1].double())
 
 
+@pytest.mark.experiments
 def test_pp_wgrad_equal_slices_bitwise_equal_128_tile():
     T, Nout, Nin, splits = 4096, 768, 768, 4
     dY, X = _rand((T, Nout), 1, 63).bfloat16(), _rand((T, Nin), 1, 64).bfloat16()
@@ -429,6 +437,7 @@ def test_pp_wgrad_equal_slices_bitwise_equal_128_tile():
     assert torch.equal(out[1][0], out[3][0]) and torch.equal(out[1][1], out[3][1])
 
 
+@pytest.mark.experiments
 def test_wgrad_splits_helper_matches_what_the_kernels_accept():
     lib = L.load()
     for (M, N) in [(768, 3072), (3072, 768), (768, 768), (2304, 768)]:
@@ -444,6 +453,7 @@ def test_wgrad_splits_helper_matches_what_the_kernels_accept():
                         assert rel_err(slabs.sum(0), dY.double().t() @ X.double()) < TOL
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("M", [8192, 1000, 8000 - 37])
 def test_pp_epilogue_inputs_requested_before_the_main_loop_same_bits(M):
     """Round 3: the ping-pong kernel requests the residual rows / saved gelu'(u) values of its epilogue right behind the prologue's DMA
@@ -513,6 +523,7 @@ def _rowln(A, W, bias, resid, gamma, beta, eps, M, K, drop=(0, 0, 0, 0.0), want_
     return out
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("M,K", [(8192, 768), (8192, 3072), (6144 + 32 * 3 + 5, 768), (256, 256), (128, 2304)])
 def test_rowln_equals_gemm_then_layernorm_bitwise(M, K, packed):
@@ -549,6 +560,7 @@ def test_rowln_equals_gemm_then_layernorm_bitwise(M, K, packed):
     assert bool((got0["h"] == 7.0).all())
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("case", ["ffn2 fwd NT", "ffn1 dgrad NN", "qkv dgrad NN"])
 def test_pp_pair_split_k_exact_and_repeatable(case):
     """Pair split-K (round 3): the N = 768, K >= 1536 GEMMs at M = 8192 run as 128 tiles of 256 x 192, two workgroups per tile, each half of
@@ -618,6 +630,7 @@ def _pair_case(case, lib):
         assert rel_err(first, A.double() @ B.double() + resid.double()) < TOL
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("M,K,epi", [(8192, 3072, "drop_resid"), (8192, 768, "bias"), (7936, 768, "add_f32"), (7999, 2304, "drop_resid")])
 def test_three_group_kernel_has_the_ping_pong_kernels_bits(M, K, epi):
     """gemm_tri.hip (hook 221, off by default: an experiment that measured no faster -- its header): the 256 x 96 tile by twelve waves in
@@ -651,6 +664,7 @@ def test_three_group_kernel_has_the_ping_pong_kernels_bits(M, K, epi):
         assert torch.equal(of.double(), Ai.double() @ Bi.double().t() + ri.double())
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("M,K,hook", [(8192, 768, 0), (8192, 3072, 0), (7999, 768, 0), (1664, 3072, 0), (1664, 768, 0), (384, 768, 0), (8192, 3072, 221)])
 def test_residual_recomputed_from_pre_layernorm_rows_same_bits(M, K, hook):
     """carel_gemm_args.resid_ln_* (ABI 6): the residual epilogue given the PRE-LayerNorm rows h, the row statistics and gamma / beta must

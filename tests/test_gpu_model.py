@@ -612,6 +612,7 @@ def test_bench_shape_backward_and_adam_vs_oracle(shape):
             assert float((d <= 0.2 * opt.vae_lr).float().mean()) >= 0.90, (k, float((d <= 0.2 * opt.vae_lr).float().mean()))
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("name,varlen,cls_only", [("zh_small", False, False), ("zh_ragged", True, True), ("zh_full12", True, True), ("zh_full12", False, False)])
 def test_layernorm_residual_recomputed_in_the_next_epilogue_is_bitwise_identical(golden_dir, name, varlen, cls_only):
     """The encoder's LayerNorms no longer write their f32 output (hook 231, default): the out-projection / FFN2 epilogue that adds it as the

@@ -3,14 +3,9 @@
 # usage: tools/ab_hook.sh <hook number that switches the feature OFF> [rounds] [steps]
 hook=$1; rounds=${2:-2}; steps=${3:-40}
 for i in $(seq $rounds); do
-  python - $hook --no-cpu-baseline --steps $steps > gpurun_out/b_off.json 2>/dev/null <<'PY' || exit 1
-import sys, runpy
-from carel_vae_amd import _lib as L
-L.check(L.load().carel_gemm_set_variant(int(sys.argv[1])))
-sys.argv = ["bench.py"] + sys.argv[2:]
-runpy.run_path("bench.py", run_name="__main__")
-PY
-  python bench.py --no-cpu-baseline --steps $steps > gpurun_out/b_on.json 2>/dev/null || exit 1
+  # (both legs on the experiments library -- the product library has no hooks: "on" = hook 0 = automatic kernel choice, a no-op)
+  python bench.py --gemm-variant $hook --no-cpu-baseline --steps $steps > gpurun_out/b_off.json 2>/dev/null || exit 1
+  python bench.py --gemm-variant 0 --no-cpu-baseline --steps $steps > gpurun_out/b_on.json 2>/dev/null || exit 1
   python - <<'PY'
 import json
 for t in ("off", "on"):

@@ -2,6 +2,7 @@
 """Where the ping-pong GEMM's time goes: timing ablations (wrong results) of the QKV-forward (npn 3) and FFN2-forward-like
 (npn 1) launches.  Needs a library built with CAREL_BUILD_TAG=ablate CAREL_EXTRA_FLAGS=-DCAREL_GEMM_ABLATE python -m carel_vae_amd.build and loaded with CAREL_HIP_LIB=carel_vae_amd/libcarel_hip_ablate.so (the product library is not touched)."""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

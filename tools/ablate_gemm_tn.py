@@ -3,6 +3,7 @@
 768 x 3072 x 8192 / 3072 x 768 x 8192 at split-K 5 (240 workgroups of the 256 x 192 tile: the production launch).  Needs a library built with
 CAREL_BUILD_TAG=ablate CAREL_EXTRA_FLAGS=-DCAREL_GEMM_ABLATE python -m carel_vae_amd.build, loaded through CAREL_HIP_LIB."""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing ablations (wrong results; ablation build) of the three-group GEMM kernel on the FFN2-forward shape, next to the ping-pong kernel."""
 import sys, os, statistics, torch
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from carel_vae_amd import _lib as L
 from tests.gpu_util import gemm

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the encoder GEMM shapes (T = 8192) for both tile variants; random data."""
 import os, sys
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

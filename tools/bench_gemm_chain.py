@@ -4,6 +4,7 @@ each launch bracketed by events: why does FFN2 forward take ~57 us inside the st
 stand-alone launch takes 45-47?  Variants separate the candidates: which of FFN2's buffers are per-layer (cold lines to WRITE /
 fresh lines to READ) and which are shared by all layers.  python tools/bench_gemm_chain.py"""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

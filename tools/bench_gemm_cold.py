@@ -4,6 +4,7 @@ Cache, which is what tools/bench_gemm_pp.py measures) against COLD operands (NSE
 robin, as the layers of a training step do; the weights rotate too).  Answers: how much of the in-step GEMM time (tools/trace_step_seq.py)
 is the memory system rather than the main loop.  NSETS=12 python tools/bench_gemm_cold.py"""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

@@ -3,6 +3,7 @@
 interleaved rounds in one process (median of 5 rounds x 20 launches), plus the vendor BLAS (torch.mm, plain GEMM without
 epilogue) as the reference point.  Measurement only; the product never calls the vendor library."""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

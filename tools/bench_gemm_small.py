@@ -3,6 +3,7 @@
 (128x128 kernel or split-K slabs on the ping-pong kernel + slab epilogue) against the ping-pong kernel taking every grid of >= 32 tiles
 directly (hook 51) and the 128x128 kernel forced (variant 1).  Median of interleaved rounds, us per call (both launches where two are made)."""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

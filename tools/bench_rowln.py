@@ -3,6 +3,7 @@
 two-kernel path it replaces (ping-pong GEMM with the residual epilogue, then ln_fwd_kernel): hot (one buffer set) and cold (12 sets used
 round robin, as the layers of a step do).  python tools/bench_rowln.py"""
 import os, sys, statistics, ctypes as C
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

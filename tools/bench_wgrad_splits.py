@@ -2,6 +2,7 @@
 """Weight-gradient GEMM + slab reduction at K = T tokens: the 128x128 kernel with its own split factor against the ping-pong
 kernel at every split-K factor (hook 100 + s) -- the data behind gemm_pp_wgrad_splits()."""
 import os, sys, statistics
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

@@ -1,5 +1,7 @@
 """Where does a ping-pong GEMM variant (HOOK = 90: fine, 91: wide phases) differ from fp64 on exact small-integer data?
 Prints the wrong 16x16 blocks per 256 x BN tile and the first wrong element with its per-K-tile partial sums."""
+import os
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only
 import sys
 import torch
 from carel_vae_amd import _lib as L

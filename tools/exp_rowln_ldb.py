@@ -2,6 +2,7 @@
 """Is the fused row-band kernel's weight stream slowed by L2 channel hot-spotting (every workgroup reads the same 16 rows x 64 B at the
 same time, row pitch 1536 / 6144 B)?  Same launch with padded weight leading dimensions.  python tools/exp_rowln_ldb.py"""
 import os, sys, statistics, ctypes as C
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

@@ -3,6 +3,7 @@
 (default 3 = ping-pong kernel; further tuning hooks in argv[3:], e.g. 120 = row-major XCD chunks): the program to put under
 rocprofv3 (tools/pmc_gemm_pp.sh, tools/pmc_gemm_fetch.sh).  The training encoder's epilogues (gelu'(u) saved by FFN1)."""
 import os, sys
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L

@@ -3,6 +3,7 @@
 ping-pong group (needs a -DCAREL_GEMM_ABLATE build: DBG 9).  Per phase: fragment-read issue, DMA issue, counted vmcnt wait,
 lgkmcnt wait, barrier, MFMA issue, barrier."""
 import os, sys
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from carel_vae_amd import _lib as L
