@@ -261,6 +261,70 @@ def _q(x, quant: Quant):
     return x if quant is None else quant(x)
 
 
+class _RoundSTE(torch.autograd.Function):
+    """bf16 rounding in the forward pass, identity in the backward pass (plain `bf16_round` also rounds the GRADIENT that flows back
+    through its bf16 intermediate -- at a point where the HIP path does not round)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GradRound(torch.autograd.Function):
+    """identity in the forward pass; the gradient is rounded to bf16 in the backward pass"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _GeluSaved(torch.autograd.Function):
+    """gelu(u) and its derivative as the FFN1 epilogue stores them: both evaluated on the bf16-rounded pre-activation, both rounded to
+    bf16; the backward pass multiplies by the SAVED derivative (csrc/gemm_epilogue.h, CAREL_EPI_BIAS_GELU_DG / CAREL_EPI_MUL_BF16)."""
+
+    @staticmethod
+    def forward(ctx, u):
+        ur = u.to(torch.bfloat16).to(torch.float32)
+        cdf = 0.5 * (1.0 + torch.erf(ur * (1.0 / math.sqrt(2.0))))
+        dg = cdf + ur * torch.exp(-0.5 * ur * ur) * (1.0 / math.sqrt(2.0 * math.pi))
+        ctx.save_for_backward(dg.to(torch.bfloat16).to(torch.float32))
+        return (ur * cdf).to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dg,) = ctx.saved_tensors
+        return g * dg
+
+
+class Bf16Hip:
+    """`quant=` object that emulates the bf16 storage points of the HIP path in BOTH directions (tests of the backward pass): operands
+    rounded in the forward pass with a straight-through gradient; the gradient signals rounded where the library stores them in bf16 --
+    d(out-projection / FFN2 output) after the dropout mask (dyb, dyb2), d(FFN1 pre-activation) (du), d(context) (dctx), dS and
+    d(q, k, v) (dqkv) -- and GELU with its saved, bf16-rounded derivative (csrc/encoder.hip, carel_encoder_backward_layer)."""
+
+    def __call__(self, x):
+        return _RoundSTE.apply(x)
+
+    @staticmethod
+    def grad(x):
+        return _GradRound.apply(x)
+
+    @staticmethod
+    def gelu(u):
+        return _GeluSaved.apply(u)
+
+
+bf16_hip = Bf16Hip()
+
+
 def layer_norm(x, w, b, eps):
     mu = x.mean(dim=-1, keepdim=True)
     xc = x - mu
@@ -330,6 +394,7 @@ def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: 
     m = dropout_scale_mask(seed, SITE_EMBED, (B, S, H), ph, row_offset)
     if m is not None:
         x = x * m
+    gq = getattr(quant, "grad", None) or (lambda t: t)          # Bf16Hip: gradient signals rounded where the library stores them in bf16
     neg = torch.finfo(torch.float32).min
     mask_add = (1.0 - att_mask.to(torch.float32))[:, None, None, :] * neg      # [B,1,1,S]
     pos_bias = mpnet_position_bias(P["encoder.encoder.relative_attention_bias.weight"], S) if cfg.rel_pos else None
@@ -340,8 +405,8 @@ def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: 
         q = linear(x, P[p + "attention.self.query.weight"], P[p + "attention.self.query.bias"], quant)
         k = linear(x, P[p + "attention.self.key.weight"], P[p + "attention.self.key.bias"], quant)
         v = linear(x, P[p + "attention.self.value.weight"], P[p + "attention.self.value.bias"], quant)
-        q, k, v = (_q(t, quant).view(B, S, nh, dh).transpose(1, 2) for t in (q, k, v))
-        s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+        q, k, v = (_q(gq(t), quant).view(B, S, nh, dh).transpose(1, 2) for t in (q, k, v))
+        s = gq(q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
         if pos_bias is not None:   # MPNetSelfAttention: scores / sqrt(d), += position_bias, += attention_mask
             s = s + pos_bias
         s = s + mask_add
@@ -350,16 +415,16 @@ def encoder_forward(P: Dict[str, torch.Tensor], ids, att_mask, token_type, cfg: 
         if m is not None:
             pr = pr * m
         ctx = (_q(pr, quant) @ v).transpose(1, 2).reshape(B, S, H)
-        ctx = _q(ctx, quant)
-        a = linear(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], quant)
+        ctx = _q(gq(ctx), quant)
+        a = gq(linear(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"], quant))
         m = dropout_scale_mask(seed, site_attn_out(l), (B, S, H), ph, row_offset)
         if m is not None:
             a = a * m
         x1 = layer_norm(a + x, P[p + "attention.output.LayerNorm.weight"],
                         P[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
-        u = linear(x1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"], quant)
-        g = _q(gelu_erf(u), quant)
-        f = linear(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], quant)
+        u = gq(linear(x1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"], quant))
+        g = quant.gelu(u) if hasattr(quant, "gelu") else _q(gelu_erf(u), quant)
+        f = gq(linear(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"], quant))
         m = dropout_scale_mask(seed, site_ffn_out(l), (B, S, H), ph, row_offset)
         if m is not None:
             f = f * m

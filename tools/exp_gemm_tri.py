@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only
 import sys, statistics, torch
 sys.path.insert(0, "/root/repo")
 from carel_vae_amd import _lib as L
