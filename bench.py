@@ -87,14 +87,17 @@ def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
     `value` is the best of the legs (the most favourable to the CPU).  Also returns the ELBO agreement of the HIP path."""
     import statistics
     from oracle import carel_oracle as O
-    # the GPU box gives one job a 16-CPU share of a much larger host: os.cpu_count() over-reports
+    # The GPU box shows a one-GPU job every CPU of a much larger host (sched_getaffinity: 256 on the boxes seen so far), but the pool's
+    # rule for it is a 16-CPU share per GPU ("size worker pools to the box's CPU share: 16 for one GPU"): the baseline uses
+    # min(affinity, 16) threads and records both numbers (CAREL_CPU_BASELINE_THREADS overrides the share).
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+        affinity = os.cpu_count() or 1
+    share = int(os.environ.get("CAREL_CPU_BASELINE_THREADS", "16"))
+    cores = max(1, min(affinity, share))
     torch.set_num_threads(cores)
-    log("cpu_baseline: %d threads (os.cpu_count() = %s), %s" % (cores, os.cpu_count(), _cpu_model()))
+    log("cpu_baseline: %d threads (affinity %d CPUs, os.cpu_count() = %s), %s" % (cores, affinity, os.cpu_count(), _cpu_model()))
     cfg, opt = O.EncoderConfig(**cfg_kw), O.Opt(**opt_kw)
     g = torch.Generator().manual_seed(3)
     eps_e, eps_c = torch.randn(opt.ec_dim, generator=g), torch.randn(opt.ec_dim, generator=g)
@@ -146,7 +149,11 @@ def cpu_baseline(cfg_kw, opt_kw, hip_loss_fn):
                       "a near-cancellation of its weighted terms (loss_share_of_term_scale): every term still agrees to ~3e-4.  *_fp32_debug: the same comparison "
                       "with the encoder in the library's fp32 debug mode (model.debug_fp32): what is left there is kernel error, not bf16 rounding.")
     parity["small_batch_B8"] = p8
-    return {"value": best["clause_pairs_per_s"], "unit": "clause-pairs/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+    return {"value": best["clause_pairs_per_s"], "unit": "clause-pairs/s", "cores": cores, "affinity_cpus": affinity, "torch_threads": torch.get_num_threads(),
+            "cores_note": "threads actually used = min(sched_getaffinity, the pool's 16-CPU share per GPU); the B = 64 leg is slower PER PAIR than the B = 8 "
+                          "legs on these hosts: its ~6 GB of saved fp32 activations stream from DRAM through the memory-bound elementwise / softmax / "
+                          "LayerNorm passes of eager PyTorch, the B = 8 leg's ~0.7 GB largely stay in the last-level cache; `value` is the best leg",
+            "cpu_model": _cpu_model(), "kind": "port",
             "sample": "oracle train_step (fwd+bwd+Adam, fp32, 12 layers, S=128): best of the legs below (B=%d, set_detect_anomaly %s), median "
                       "step time" % (best["batch"], "on as ref :837" if best["set_detect_anomaly"] else "off"),
             "legs": legs}, parity
@@ -683,6 +690,7 @@ def main():
         out["cpu_baseline"] = base
         out["elbo_parity"] = parity
         out["speedup_vs_cpu_baseline"] = pairs_per_s / base["value"]
+    out["ranks_seen"] = world            # (self-check for a scaling run: must equal n_gpus and the --gpus argument; launch_ranks() asserts it)
     if rank == 0:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

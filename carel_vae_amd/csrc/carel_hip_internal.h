@@ -50,7 +50,12 @@ int gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream);
 // largest value carel_gemm_wgrad_splits(M, N, T) can take under any tuning-hook setting (slab buffer sizing); gemm.hip
 int gemm_wgrad_splits_max(int M, int N, long T);
 int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,
-                    void* partials, void* row_scratch, hipStream_t stream);
+                    void* partials, void* row_scratch, hipStream_t stream, const void* sort_ws = nullptr);
+// ln.hip: the embedding tables' gradients from sorted (id, row) keys instead of float atomics (deterministic); the keys are made in the forward pass
+int embed_sort_supported(const carel_embed_args* a);
+size_t embed_sort_bytes();
+int embed_ln_fwd_keys(const carel_embed_args* a, void* sort_ws, hipStream_t stream);
+int embed_sort_rows(const carel_embed_args* a, void* sort_ws, hipStream_t stream);
 
 // grouped weight gradients (gemm_pp.hip, round 4): up to four dW[M, N] = dY^T X over the same T tokens in ONE launch + one small reduction
 struct WgradGroupProb { const void* dY; const void* X; void* dW; void* db; int M, N; };      // dY bf16 [T, M], X bf16 [T, N], dW f32 [M, N], db f32 [M] or null

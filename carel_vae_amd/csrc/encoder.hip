@@ -62,7 +62,7 @@ struct Scratch { char* dy; char* dyb; char* dyb2; char* du; char* dctx; char* dq
 // The operands of a layer's weight gradients -- dyb, dyb2, du, dqkv and the two LayerNorm-backward partial buffers -- exist TWICE, used by
 // layers of even / odd index: the layer's weight gradients run as one grouped launch on the side stream after its attention backward
 // and may still be reading them while the main stream is already writing the next layer's (round 4; 113 MB at T = 8192).
-struct ScratchLayout { size_t o_dy, o_dyb[2], o_dyb2[2], o_du[2], o_dctx, o_dqkv[2], o_slabs, o_ws, o_part[2], o_part2, o_part3[2], ws_bytes, slab_bytes, total; };
+struct ScratchLayout { size_t o_dy, o_dyb[2], o_dyb2[2], o_du[2], o_dctx, o_dqkv[2], o_slabs, o_ws, o_part[2], o_part2, o_part3[2], o_sort, ws_bytes, slab_bytes, total; };
 
 // split-K factor of the weight-gradient GEMMs (K = tokens): chosen by the GEMM library for the kernel it will run
 int wgrad_splits(long T, int M, int N) { return carel_gemm_wgrad_splits(M, N, T); }
@@ -100,6 +100,7 @@ ScratchLayout scratch_layout(long B, long S) {
     s.o_part3[par] = o; o += al(part);      // LN1-backward partials          } their reductions run on the side stream while the main stream moves on
   }
   s.o_part2 = o; o += al(part);             // DGELU column-sum partials
+  s.o_sort = o; o += al(embed_sort_bytes());  // (token id, position id) of every row + their sorted keys: the embedding tables' gradients without atomics
   s.total = o;
   return s;
 }
@@ -352,7 +353,19 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
   const size_t ws_bytes = a->scratch ? sl.ws_bytes : 0;
   LayerAct la = layer_act(l, (char*)a->act, 0, a->inference);
   carel_embed_args e = embed_args_of(a, l, la);
-  if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
+  if (!a->inference && a->scratch && embed_sort_supported(&e)) {
+    // a backward pass will follow: leave every row's (token id, position id) behind and sort them now -- on the weight-gradient side
+    // stream when there is one (idle during the forward pass; carel_encoder_backward_embeddings joins it), so that the embedding tables'
+    // gradients come from fixed-order segment sums instead of float atomics without a sort on the backward pass's critical path
+    void* sort_ws = (char*)a->scratch + sl.o_sort;
+    if ((rc = embed_ln_fwd_keys(&e, sort_ws, (hipStream_t)stream))) return rc;
+    SideStream* ss = (a->overlap_wgrad & 1) ? side_stream() : nullptr;
+    if (ss) {
+      if (hipEventRecord(ss->ev[8], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->ev[8], 0) != hipSuccess)
+        return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event fork failed");
+      if ((rc = embed_sort_rows(&e, sort_ws, ss->stream))) return rc;
+    } else if ((rc = embed_sort_rows(&e, sort_ws, (hipStream_t)stream))) return rc;
+  } else if ((rc = carel_embed_ln_fwd(&e, stream))) return rc;
   // Samples are independent through the whole encoder: with a->overlap_wgrad (dense rows, even batch) the two halves of
   // the batch run as two chains, one on `stream`, one on a peer stream of the same priority, so that each chain's launch gaps, tile-count
   // tails and memory-bound kernels are filled by the other's GEMMs.  The (optionally [CLS]-only) last layer runs whole.
@@ -557,7 +570,10 @@ extern "C" int carel_encoder_backward_embeddings(const carel_encoder_args* a, vo
   if (he == hipSuccess) he = hipMemsetAsync(a->d_pos_emb, 0, (size_t)a->max_pos * EH * 4, (hipStream_t)stream);
   if (he != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_encoder_backward_embeddings: memset: %s", hipGetErrorString(he));
   // s.dy (f32 [T, 768]) is free here: scratch for the fixed-order position-table reduction
-  return embed_ln_bwd_ex(&e, a->dx, a->d_word_emb, a->d_pos_emb, a->d_type_emb, a->d_emb_ln_g, a->d_emb_ln_b, s.part, s.dy, (hipStream_t)stream);
+  // (the sorted keys were made by carel_encoder_forward for this batch: same condition here as there)
+  const ScratchLayout sl = scratch_layout(B, S);
+  const void* sort_ws = embed_sort_supported(&e) ? (const char*)a->scratch + sl.o_sort : nullptr;
+  return embed_ln_bwd_ex(&e, a->dx, a->d_word_emb, a->d_pos_emb, a->d_type_emb, a->d_emb_ln_g, a->d_emb_ln_b, s.part, s.dy, (hipStream_t)stream, sort_ws);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1007,6 +1007,7 @@ int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi) {
   return 1;
 }
 int gemm_pp_launch_pair(const GemmParams& p0, bool bt, int epi, hipStream_t s) {
+  if (p0.resid_stats) return set_error(CAREL_ERR_ARG, "gemm_pp_launch_pair: no recomputed-LayerNorm residual on the 256 x 192 pair tiles");
   static std::atomic<unsigned> seq{0};
   GemmParams p = p0;
   unsigned v = seq.fetch_add(1, std::memory_order_relaxed) + 1;
@@ -1037,6 +1038,9 @@ int gemm_pp_launch_tn_dbg(const GemmParams& p, int npn, int splits, int dbg, hip
 #endif
 
 int gemm_pp_launch(const GemmParams& p, bool bt, int epi, int npn, hipStream_t s) {
+  // the wider tiles' epilogues are instantiated WITHOUT the recomputed-LayerNorm residual (no registers for its statistics and gamma / beta):
+  // they would add the pre-LayerNorm rows as the residual.  gemm_pp_pick never proposes such a pair; a caller that bypasses it is refused.
+  if (p.resid_stats && npn != 1) return set_error(CAREL_ERR_ARG, "gemm_pp_launch: resid_ln_* (recomputed LayerNorm residual) exists on the 96-wide tile only (npn = %d)", npn);
   if (!bt) {
     switch (epi) {
       case EPI_BIAS_BF16: return launch_pp_n<false, EPI_BIAS_BF16>(p, npn, s);

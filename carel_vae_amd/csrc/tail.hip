@@ -765,10 +765,23 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
     if (e != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   c.mmd_part = nullptr; c.mmd_nblk = 0; c.dz_mmd = nullptr;
+  // (every shape check comes BEFORE the fork below -- ADVICE r03: an error return between fork and join would leave the side stream un-joined)
+  if (c.z_global && c.dis_mode == 0 && (2 * c.n_global + 31) / 32 > MMD_MAX_BLOCKS)
+    return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: global batch too large for the MMD partial buffer");
   // The loss kernel and the decoder passes only share their input z and meet again in decoder_total_kernel (terms[0]) and tail_dlat_kernel:
   // fork the former onto the side stream (the profiling hook keeps the serial order)
   hipStream_t core_stream = stream;
   TailEvents* tev = nullptr;
+  // after the fork every early return first joins the side stream back into the caller's stream (whatever was enqueued there completes
+  // before the caller's next kernel); the fork / join events are one pair per device: carel_tail_losses with serial = 0 is NOT re-entrant
+  // per device (two host threads, or two models interleaving calls on one device, must pass serial = 1)
+  auto join_on_error = [&](int code) -> int {
+    if (tev && core_stream != stream) {
+      (void)hipEventRecord(tev->join, core_stream);
+      (void)hipStreamWaitEvent(stream, tev->join, 0);
+    }
+    return code;
+  };
   if (g_tail_overlap && !a->serial && !g_tail_prof) {
     hipStream_t side = (hipStream_t)carel_side_stream(0);     // the weight-gradient stream (idle here: the backward pass has not started); a THIRD stream in play made every later kernel slower
     tev = side ? tail_events() : nullptr;
@@ -785,15 +798,14 @@ extern "C" int carel_tail_losses(const carel_tail_args* a, void* stream_) {
     g.zg = c.z_global; g.n = c.n_global; g.B = B; g.D = D; g.rank_stride = c.rank_stride; g.row_offset = c.row_offset;
     g.alpha = c.alpha; g.eps = c.mmd_eps; g.gscale = -c.w_mmd * c.mmd_grad_scale; g.part = w.mmd_part; g.dz = w.dz_mmd;
     const int nblk = (2 * c.n_global + 31) / 32;
-    if (nblk > MMD_MAX_BLOCKS) return set_error(CAREL_ERR_SHAPE, "carel_tail_losses: global batch too large for the MMD partial buffer");
     if (D == 24) hipLaunchKernelGGL(mmd_global_kernel<24>, dim3(nblk), dim3(256), 0, core_stream, g);
     else hipLaunchKernelGGL(mmd_global_kernel<32>, dim3(nblk), dim3(256), 0, core_stream, g);
-    if ((rc = check_launch("mmd_global_kernel"))) return rc;
+    if ((rc = check_launch("mmd_global_kernel"))) return join_on_error(rc);
     c.mmd_part = w.mmd_part; c.mmd_nblk = nblk; c.dz_mmd = w.dz_mmd;
   }
   c.prof = g_tail_prof;
   hipLaunchKernelGGL(tail_core_kernel, dim3(1), dim3(1024), lds, core_stream, c);
-  if ((rc = check_launch("tail_core_kernel"))) return rc;
+  if ((rc = check_launch("tail_core_kernel"))) return join_on_error(rc);
   if (tev && hipEventRecord(tev->join, core_stream) != hipSuccess) return set_error(CAREL_ERR_HIP, "carel_tail_losses: event record failed");
 
   DecArgs d;

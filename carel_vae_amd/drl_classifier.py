@@ -8,6 +8,7 @@ calling the model with CPU tensors raises.
 """
 import ctypes as C
 import math
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -1001,7 +1002,7 @@ class FusedAdam:
         self._skip_count = None
         self._aux = None
         if fuse_into_backward:
-            ptr = L.load().carel_side_stream(1)
+            ptr = L.load().carel_side_stream(int(os.environ.get("CAREL_ADAM_STREAM", "1")))      # (0: experiment -- queue the updates behind the weight gradients on their stream)
             if not ptr:
                 raise L.CarelError("carel_side_stream: " + L.load().carel_last_error().decode("utf8", "replace"))
             self._aux = torch.cuda.ExternalStream(ptr, device=model._flat.device)

@@ -41,9 +41,9 @@ def _build():
     return M, model, batch, eps, opt
 
 
-def _step(M, model, batch, eps, opt, lo, hi):
+def _step(M, model, batch, eps, opt, lo, hi, fuse=False):
     b = {k: v[lo:hi].cuda() for k, v in batch.items()}
-    optim = M.FusedAdam(model, lr=1e-3)
+    optim = M.FusedAdam(model, lr=1e-3, fuse_into_backward=fuse)
     model.set_noise(*eps)
     loss = model(b["input_ids"], b["attention_masks"], b["token_type_ids"], b["emo_labels"], b["cau_labels"], b["labels"], b["bow_reps"], 3)
     optim.zero_grad()
@@ -57,7 +57,7 @@ def _step(M, model, batch, eps, opt, lo, hi):
     return float(loss.detach()), terms, grads, weights
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="plain"):
     try:
         import torch.distributed as dist
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -65,10 +65,14 @@ def _worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from carel_vae_amd.dp import DataParallel
         M, model, batch, eps, opt = _build()
-        DataParallel(model)
+        # "fused_bf16_wire" (ADVICE r03): the gradient buckets travel as bf16 (rounded once, summed by the collective, widened back into the
+        # fp32 gradient buffer) AND each layer's fused Adam update runs inside backward() on the auxiliary stream behind its own bucket's
+        # all-reduce -- dp.backward_done with the real FusedAdam hook, embedding bucket in pieces
+        fused = mode == "fused_bf16_wire"
+        DataParallel(model, wire_dtype=torch.bfloat16) if fused else DataParallel(model)
         B = batch["input_ids"].shape[0]
         n = B // world
-        loss, terms, grads, weights = _step(M, model, batch, eps, opt, rank * n, (rank + 1) * n)
+        loss, terms, grads, weights = _step(M, model, batch, eps, opt, rank * n, (rank + 1) * n, fuse=fused)
         # plain numpy through the queue (torch tensors would travel as shared-memory handles that die with this process)
         q.put((rank, (loss, terms, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in weights.items()})))
         dist.barrier()
@@ -78,12 +82,16 @@ def _worker(rank, world, port, q):
         q.put((rank, "ERROR: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch(world):
+@pytest.mark.parametrize("world,mode", [(2, "plain"), (4, "plain"), (2, "fused_bf16_wire")])
+def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch(world, mode):
+    """mode "fused_bf16_wire": DataParallel(wire_dtype=bfloat16) + FusedAdam(fuse_into_backward=True) against the plain single-process
+    step -- the bf16 wire perturbs every averaged gradient by up to 2^-9 relative per element (stated tolerance: 6e-3 of the tensor's norm
+    instead of 2e-3), the ranks still hold bit-identical gradients and weights, and the weights agree with the unfused single-process
+    update to the same lr-level bound."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -107,7 +115,7 @@ def test_two_rank_data_parallel_equals_single_process_on_the_whole_batch(world):
         for r in range(2, world):
             assert torch.equal(g0, torch.from_numpy(res[r][2][k])), (k, r)
         den = float(g.norm()) + 1e-12
-        assert float((g0 - g).norm()) / den < 2e-3, (k, float((g0 - g).norm()) / den)
+        assert float((g0 - g).norm()) / den < (6e-3 if mode == "fused_bf16_wire" else 2e-3), (k, float((g0 - g).norm()) / den)
         w0, w1 = torch.from_numpy(res[0][3][k]), torch.from_numpy(res[1][3][k])
         assert torch.equal(w0, w1), k
         assert float((w0 - weights[k]).abs().max()) <= 2.2e-3, k      # Adam: |update| <= lr, sign flips at ~0 gradients
@@ -202,7 +210,7 @@ def test_english_adversarial_two_ranks_equal_single_process():
         g0, g1, g = torch.from_numpy(res[0][1][k]), torch.from_numpy(res[1][1][k]), grads[k]
         assert torch.equal(g0, g1), k
         den = float(g.norm()) + 1e-12
-        assert float((g0 - g).norm()) / den < 2e-3, (k, float((g0 - g).norm()) / den)
+        assert float((g0 - g).norm()) / den < (6e-3 if mode == "fused_bf16_wire" else 2e-3), (k, float((g0 - g).norm()) / den)
         w0, w1 = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
         assert torch.equal(w0, w1), k
         step = 1e-2 if k.split(".")[0].endswith("disc") else 1e-3          # RMSprop: lr / sqrt(1 - alpha); Adam: lr
