@@ -55,12 +55,13 @@ def parse():
     ap.add_argument("--no-ecpe", action="store_true", help="skip the secondary ECPE-shaped leg")
     ap.add_argument("--no-varlen", action="store_true", help="run padded positions through the encoder like the reference does")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
-    ap.add_argument("--adam-in-backward", action="store_true",
-                    help="run the fused Adam layer by layer beside the backward pass (auxiliary stream) instead of in optim.step(); measured "
-                         "1 % slower than the plain order since the round-2 GEMMs fill the chip (tools/ab_bench.sh)")
+    ap.add_argument("--adam-in-backward", action="store_true", help=argparse.SUPPRESS)        # (accepted: the default since round 4)
+    ap.add_argument("--adam-in-step", action="store_true",
+                    help="run the fused Adam as one pass in optim.step() instead of layer by layer inside backward() on the weight-gradient "
+                         "stream (FusedAdam(fuse_into_backward=True), the default here: tools/ab_adam_stream.sh measured -2 %% dense, -2.5 %% ECPE-shaped)")
     ap.add_argument("--forward-chains", action="store_true",
                     help="forward pass as two half-batch chains on two streams (results identical); measured ~1 % slower with the round-2 GEMMs")
-    ap.add_argument("--no-adam-in-backward", action="store_true", help=argparse.SUPPRESS)      # (accepted: these are the defaults now)
+    ap.add_argument("--no-adam-in-backward", action="store_true", help=argparse.SUPPRESS)      # (accepted; same as --adam-in-step)
     ap.add_argument("--no-forward-chains", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gemm-variant", type=int, action="append", default=[],
                     help="A/B runs: tuning hook passed to carel_gemm_set_variant before the run (repeatable; switches the run to the EXPERIMENTS "
@@ -380,6 +381,7 @@ def sentence_transformer_leg(dev, steps):
 
 def main():
     a = parse()
+    a.adam_in_step = a.adam_in_step or a.no_adam_in_backward
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a)
     # Libraries chat on stdout (RCCL prints a five-line version banner at the first collective, gloo its peer counts): the
@@ -426,7 +428,7 @@ def main():
         dp = DataParallel(model)
     # N > 1: each layer's Adam update starts as soon as that layer's gradient bucket has been all-reduced (dp.py), so the optimiser pass
     # hides behind the remaining backward kernels and collectives instead of trailing the last (embedding) bucket
-    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=(a.adam_in_backward or world > 1) and not a.no_overlap)
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=not a.adam_in_step and not a.no_overlap)
 
     batches, lengths = [], []
     for i in range(4):
@@ -483,14 +485,18 @@ def main():
         optim.step()
         return loss
 
-    log("model ready on %s; warm-up" % dev)
-    for i in range(a.warmup):
-        step_fed(i)
-    sync()
-    log("timing %d steps (H2D of every batch + loss read-back every 10 steps inside)" % a.steps)
+    # (everything the timed region needs is allocated BEFORE the warm-up: a page-locked allocation right in front of the timed steps --
+    # RunningLoss's read-back slots -- re-maps host memory into the GPU's page tables and made the second timed step 3 ms slower)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # step boundaries on the main stream (no host sync)
     loss_lines = []
     running = RunningLoss(dev, every=10, log=loss_lines.append)
+    warm_running = RunningLoss(dev, every=10, log=lambda *_: None)
+    log("model ready on %s; warm-up" % dev)
+    for i in range(a.warmup):
+        warm_running.add(step_fed(i).detach(), 0, i)
+    warm_running.flush(wait=True)
+    sync()
+    log("timing %d steps (H2D of every batch + loss read-back every 10 steps inside)" % a.steps)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
@@ -512,9 +518,12 @@ def main():
     for i in range(3):
         step(i)
     sync()
+    marks_r = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t_r = time.perf_counter()
+    marks_r[0].record()
     for i in range(a.steps):
         step(3 + i)
+        marks_r[i + 1].record()
     sync()
     dtr = time.perf_counter() - t_r
     if world > 1:
@@ -522,7 +531,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dtr = float(t.item())
     resident = {"value": world * a.batch * a.steps / dtr, "unit": "clause-pairs/s", "ms_per_step": 1e3 * dtr / a.steps, "steps": a.steps,
-                "headline_over_resident": dt / dtr,
+                "headline_over_resident": dt / dtr, "ms_per_step_in_order": [round(marks_r[i].elapsed_time(marks_r[i + 1]), 3) for i in range(a.steps)],
                 "note": "same step on batches that already sit in HBM, no loss read-back (rounds 1-3 quoted this as `value`); "
                         "headline_over_resident = what the H2D copy + read-back cost on this box"}
     log("resident inputs: %.3f ms/step (headline / resident = %.3f)" % (1e3 * dtr / a.steps, dt / dtr))
@@ -661,7 +670,7 @@ def main():
 
     out = {"metric": "clause-pairs/sec (training step)", "value": pairs_per_s, "unit": "clause-pairs/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_median": median_ms,
-           "ms_per_step_min_max": [per_step[0], per_step[-1]], "higher_is_better": True, "scaling": "weak",
+           "ms_per_step_min_max": [per_step[0], per_step[-1]], "ms_per_step_in_order": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(a.steps)], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "zh ECPE training step (H2D of a ready batch + fwd + bwd + Adam, loss read back every 10 steps), BERT-base "
                                   "vocab 21128, S=128 shape-%s, B=%d/GPU, bow V=23771, dropout on, random-init weights" % (a.shape, a.batch),

@@ -359,7 +359,9 @@ extern "C" int carel_encoder_forward(const carel_encoder_args* a, void* stream) 
     // gradients come from fixed-order segment sums instead of float atomics without a sort on the backward pass's critical path
     void* sort_ws = (char*)a->scratch + sl.o_sort;
     if ((rc = embed_ln_fwd_keys(&e, sort_ws, (hipStream_t)stream))) return rc;
-    SideStream* ss = (a->overlap_wgrad & 1) ? side_stream() : nullptr;
+    // (not beside the two forward chains: a third stream at work during the forward pass made that mode 1.8x slower -- HIP maps streams
+    // onto four hardware queues)
+    SideStream* ss = ((a->overlap_wgrad & 1) && !(a->overlap_wgrad & 2)) ? side_stream() : nullptr;
     if (ss) {
       if (hipEventRecord(ss->ev[8], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->ev[8], 0) != hipSuccess)
         return set_error(CAREL_ERR_HIP, "carel_encoder_forward: event fork failed");

@@ -1002,10 +1002,17 @@ class FusedAdam:
         self._skip_count = None
         self._aux = None
         if fuse_into_backward:
-            ptr = L.load().carel_side_stream(int(os.environ.get("CAREL_ADAM_STREAM", "1")))      # (0: experiment -- queue the updates behind the weight gradients on their stream)
-            if not ptr:
+            # Two library streams.  Without collectives the updates are queued on the WEIGHT-GRADIENT stream (0), behind the layer's grouped
+            # weight-gradient launch that already runs there: measured on one box, alternating (tools/ab_adam_stream.sh, round 4): dense step
+            # 7.80-7.85 ms with the update in step(), 7.69-7.72 on the auxiliary stream (1), 7.63-7.71 on the weight-gradient stream;
+            # ECPE-shaped 4.38-4.40 / 4.34 / 4.27-4.31.  Under DataParallel an update waits for its bucket's all-reduce, which must not
+            # hold up the weight gradients queued behind it: those updates go to the auxiliary stream.
+            ptrs = [L.load().carel_side_stream(i) for i in (0, 1)]
+            if not all(ptrs):
                 raise L.CarelError("carel_side_stream: " + L.load().carel_last_error().decode("utf8", "replace"))
-            self._aux = torch.cuda.ExternalStream(ptr, device=model._flat.device)
+            self._side = torch.cuda.ExternalStream(ptrs[0], device=model._flat.device)
+            self._aux = torch.cuda.ExternalStream(ptrs[1], device=model._flat.device)
+            self._used = set()
             self._ev = torch.cuda.Event()
             offs, nl = model._offs, model.cfg.layers
             starts = [offs[f"encoder.encoder.layer.{l}.attention.self.query.weight"] for l in range(nl)]
@@ -1048,17 +1055,22 @@ class FusedAdam:
         collective behind the handle `after` (its wait() orders the auxiliary stream only)."""
         lo, hi = rng
         if after is not None:
-            with torch.cuda.stream(self._aux):
+            st = self._aux
+            with torch.cuda.stream(st):
                 after.wait()                 # stream-side wait: the auxiliary stream blocks until the collective is done
         else:
+            st = self._side
             self._ev.record()
-            self._aux.wait_event(self._ev)
-        self._launch(lo, hi, C.c_void_p(self._aux.cuda_stream), with_skip=False)
+            st.wait_event(self._ev)
+        self._used.add(st)
+        self._launch(lo, hi, C.c_void_p(st.cuda_stream), with_skip=False)
         self._done.append((lo, hi))
 
     def _join(self):
         if self._aux is not None and self._done:
-            torch.cuda.current_stream().wait_stream(self._aux)
+            for st in self._used:
+                torch.cuda.current_stream().wait_stream(st)
+            self._used.clear()
 
     def step(self):
         m = self.model
