@@ -29,8 +29,8 @@ def log(msg):
 
 T_START = time.time()
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC_CSV = "r03_pmc_hbm_traffic.csv"      # regenerated every round for the final code (tools/pmc_traffic.sh)
-PMC_MFMA_CSV = "r03_pmc_mfma_util.csv"           # (tools/pmc_mfma.sh)
+PMC_TRAFFIC_CSV = "r04_pmc_hbm_traffic.csv"      # regenerated every round for the final code (tools/pmc_traffic.sh)
+PMC_MFMA_CSV = "r04_pmc_mfma_util.csv"           # (tools/pmc_mfma.sh)
 FLOP_PER_PAIR = 67.05e9       # fwd+bwd algorithmic FLOPs per clause pair
 
 
