@@ -1059,7 +1059,7 @@ class FusedAdam:
             with torch.cuda.stream(st):
                 after.wait()                 # stream-side wait: the auxiliary stream blocks until the collective is done
         else:
-            st = self._side
+            st = self._aux if os.environ.get("CAREL_ADAM_STREAM") == "1" else self._side      # (the variable: A/B tool only, tools/ab_adam_stream.sh)
             self._ev.record()
             st.wait_event(self._ev)
         self._used.add(st)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# (round 4) A/B on ONE box, alternating: the fused Adam in optim.step() (default) | per layer inside backward() on the auxiliary stream |
+# (round 4) A/B on ONE box, alternating: the fused Adam in optim.step() (--adam-in-step) | per layer inside backward() on the auxiliary stream |
 # per layer inside backward() queued on the weight-gradient side stream.  Dense and ECPE-shaped step (resident inputs + headline).
 rounds=${1:-2}
 for i in $(seq $rounds); do
-  for v in "default:" "aux:--adam-in-backward" "side:--adam-in-backward"; do
+  for v in "default:--adam-in-step" "aux:" "side:"; do
     name=${v%%:*}; flag=${v#*:}
-    if [ $name = side ]; then export CAREL_ADAM_STREAM=0; else unset CAREL_ADAM_STREAM; fi
+    if [ $name = aux ]; then export CAREL_ADAM_STREAM=1; else unset CAREL_ADAM_STREAM; fi
     python bench.py --no-cpu-baseline --steps 40 $flag > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err || exit 1
     python - $name <<'PY'
 import json, sys
