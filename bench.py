@@ -55,7 +55,9 @@ def parse():
     ap.add_argument("--no-ecpe", action="store_true", help="skip the secondary ECPE-shaped leg")
     ap.add_argument("--no-varlen", action="store_true", help="run padded positions through the encoder like the reference does")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam")
-    ap.add_argument("--adam-in-backward", action="store_true", help=argparse.SUPPRESS)        # (accepted: the default since round 4)
+    ap.add_argument("--adam-in-backward", action="store_true",
+                    help="N > 1 only (the default at N = 1): each layer's fused Adam update inside backward(), behind its bucket's all-reduce, on the "
+                         "auxiliary stream; off by default under DataParallel (stream budget: carel_vae_amd/dp.py)")
     ap.add_argument("--adam-in-step", action="store_true",
                     help="run the fused Adam as one pass in optim.step() instead of layer by layer inside backward() on the weight-gradient "
                          "stream (FusedAdam(fuse_into_backward=True), the default here: tools/ab_adam_stream.sh measured -2 %% dense, -2.5 %% ECPE-shaped)")
@@ -428,7 +430,7 @@ def main():
         dp = DataParallel(model)
     # N > 1: each layer's Adam update starts as soon as that layer's gradient bucket has been all-reduced (dp.py), so the optimiser pass
     # hides behind the remaining backward kernels and collectives instead of trailing the last (embedding) bucket
-    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=not a.adam_in_step and not a.no_overlap)
+    optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=(a.adam_in_backward if dp is not None else not a.adam_in_step) and not a.no_overlap)
 
     batches, lengths = [], []
     for i in range(4):
@@ -436,7 +438,8 @@ def main():
         lengths.append(b["attention_masks"].sum(1).tolist())     # known on the host before the H2D copy (as in a DataLoader)
         batches.append({k: v.to(dev) for k, v in b.items()})
     model.varlen = not a.no_varlen
-    model.overlap_wgrad = not a.no_overlap
+    if dp is None:          # (DataParallel keeps the weight gradients on the main stream: its stream budget, carel_vae_amd/dp.py)
+        model.overlap_wgrad = not a.no_overlap and os.environ.get("CAREL_BENCH_SERIAL_WGRAD") != "1"      # (the variable: A/B tool only)
     model.forward_chains = a.forward_chains and dp is None        # DataParallel switches the second chain off (dp.py)
 
     def step(i):
@@ -543,6 +546,7 @@ def main():
     nprof = 3
 
     def gemm_event_replay(first_step):
+        keep_overlap = model.overlap_wgrad
         model.overlap_wgrad = False
         hook, model._adam_hook = model._adam_hook, None
         L.check(lib.carel_profile_gemm(1, 260 * nprof))
@@ -553,7 +557,7 @@ def main():
         ov_e, ov_p = C.c_double(), C.c_double()
         L.check(lib.carel_profile_gemm_overheads(C.byref(ov_e), C.byref(ov_p)))
         L.check(lib.carel_profile_gemm(0, 0))
-        model.overlap_wgrad = not a.no_overlap
+        model.overlap_wgrad = keep_overlap
         model._adam_hook = hook
         return ev, ov_e.value, ov_p.value
     def gemm_roofline(ev, ov_e, ov_p):

@@ -95,7 +95,7 @@ class DataParallel:
     """Attach to a DrlClassifier: `dp = DataParallel(model)`; then train as usual (same forward / backward /
     optimiser calls).  Every rank must call forward with the same local batch size."""
 
-    def __init__(self, model, group=None, global_batch_terms=True, wire_dtype=None, embed_chunks=4):
+    def __init__(self, model, group=None, global_batch_terms=True, wire_dtype=None, embed_chunks=4, overlap_wgrad=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (init_process_group) before DataParallel")
         self.model, self.group = model, group
@@ -107,6 +107,14 @@ class DataParallel:
         # (measured with one RCCL rank: 10.9 ms per step with it, 10.0 ms without), so it is switched off under DP.
         if hasattr(model, "forward_chains"):
             model.forward_chains = False
+        # Round 4: the weight gradients stay on the MAIN stream under DP (overlap_wgrad=True re-enables the side stream).  The stream budget
+        # again: main + RCCL's stream + the input copy stream are three; the weight-gradient stream and the Adam stream would make five
+        # on four hardware queues.  Measured with one RCCL rank on one box (bench.py, CAREL_FORCE_DP=1; the one-rank "all-reduce" is a
+        # 414-MB copy per step): 15.6 ms per step with the weight-gradient side stream, 8.5 ms with the weight gradients on the main
+        # stream and Adam in step(), 9.2 ms with Adam per layer on the auxiliary stream; 7.7 ms without DataParallel.  What DP needs to
+        # overlap is the gradient all-reduce with the remaining backward pass -- asynchronous on RCCL's stream either way.
+        if hasattr(model, "overlap_wgrad"):
+            model.overlap_wgrad = bool(overlap_wgrad)
         dist.broadcast(model._flat, src=0, group=group)        # identical replicas
         seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(model._flat.device)
         dist.broadcast(seed, src=0, group=group)
