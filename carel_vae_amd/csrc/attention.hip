@@ -133,8 +133,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const bf16_t* qbase = p.qkv + row0 * QKV_LD + h * HD;
   stage_att(qbase + HID, QKV_LD, rows, kimg);
   stage_att(qbase + 2 * HID, QKV_LD, rows, vimg);
-  for (int k = threadIdx.x; k < rows; k += 256)
-    maskadd[k] = p.cu ? (k < len ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f);
+  int masked_here = 0;
+  for (int k = threadIdx.x; k < rows; k += 256) {
+    const float ma = p.cu ? (k < len ? 0.f : MASK_NEG) : ((p.att_mask && p.att_mask[row0 + k] == 0) ? MASK_NEG : 0.f);
+    maskadd[k] = ma;
+    masked_here |= ma != 0.f;
+  }
   if (REL) relb[threadIdx.x] = p.rel[h * 256 + threadIdx.x];
   const int q0 = wave * 32;
   const int hh = lane >> 5;
@@ -146,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int s = 0; s < 4; ++s) qf[s] = load_frag_global(qbase + (long)(q0 + (lane & 31)) * QKV_LD + 16 * s + 8 * hh);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // (the barrier also tells every wave whether ANY key of this sample is masked: dense batches without padding -- the bench shape -- and
+  // every key tile of a packed sample but a ragged last one then skip the mask term's LDS read and add: 64 of each per lane)
+  const int any_masked = __syncthreads_or(masked_here);
   if (!qact) return;                             // no barrier below this point
 
   f32x16 x[4];
@@ -159,19 +165,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       for (int s = 0; s < 4; ++s) x[kt] = mfma32(frag32_row(kimg, kt * 32, s), qf[s], x[kt]);
     }
   }
-  // softmax over keys: this lane holds, for query q0+(l&31), keys kt*32 + acc32_row(r, lane)
+  // softmax over keys: this lane holds, for query q0+(l&31), keys kt*32 + acc32_row(r, lane).  The scores are kept in the log2 domain
+  // (scale and log2(e) in one multiply, exp2 instead of exp: one VALU instruction less per element; the backward pass has always recomputed the
+  // probabilities that way); a masked key adds finfo.min exactly as HF does, so a sample with no attended key still gets the uniform row.
+  constexpr float SC2 = 0.125f * 1.4426950408889634f;
   float m = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     if (kt < nkt) {
+      // wave-uniform: does this key tile hold a masked key?  (packed: only a ragged last tile; dense: unknown per tile, any tile may)
+      const bool tile_masked = p.cu ? (kt == nkt - 1 && (len & 31) != 0) : (any_masked != 0);
+      if (tile_masked) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + acc32_row(r, lane);
-        float v = x[kt][r] * 0.125f;
-        if (REL) v += relb[127 + key - (q0 + (lane & 31))];
-        v += maskadd[key];
-        x[kt][r] = v;
-        m = fmaxf(m, v);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + acc32_row(r, lane);
+          float v = fmaf(x[kt][r], SC2, maskadd[key]);
+          if (REL) v = fmaf(relb[127 + key - (q0 + (lane & 31))], 1.4426950408889634f, v);
+          x[kt][r] = v;
+          m = fmaxf(m, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = x[kt][r] * SC2;
+          if (REL) v = fmaf(relb[127 + kt * 32 + acc32_row(r, lane) - (q0 + (lane & 31))], 1.4426950408889634f, v);
+          x[kt][r] = v;
+          m = fmaxf(m, v);
+        }
       }
     }
   }
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (kt < nkt) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {          // keys acc32_row(r), acc32_row(r + 1) are an aligned pair: one hash (ebase, S and the offset are even)
-        const float e0 = __expf(x[kt][r] - m), e1 = __expf(x[kt][r + 1] - m);
+        const float e0 = __builtin_amdgcn_exp2f(x[kt][r] - m), e1 = __builtin_amdgcn_exp2f(x[kt][r + 1] - m);
         lsum += e0; lsum += e1;
         float d0 = 1.0f, d1 = 1.0f;
         if constexpr (DROP) {       // (a template parameter: tested at run time, every pair sat in its own basic block)
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
   lsum += __shfl_xor(lsum, 32, 64);
   const bool qlive = q0 + (lane & 31) < len;
-  if (hh == 0 && qlive) p.lse[((long)b * NH + h) * S + q0 + (lane & 31)] = m + __logf(lsum);
+  if (hh == 0 && qlive) p.lse[((long)b * NH + h) * S + q0 + (lane & 31)] = (m + __builtin_amdgcn_logf(lsum)) * 0.6931471805599453f;      // natural log-sum-exp, as before
   const float inv = 1.0f / lsum;
   // O^T[d][q] = sum_k V^T[d][k] P^T[k][q]
   f32x16 o[2];
