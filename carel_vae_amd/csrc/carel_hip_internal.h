@@ -29,6 +29,7 @@ inline int gemm_rowln_wanted(long) { return 0; }      // (the row-band kernel ex
 inline int gemm_rowln_wanted_k(int) { return 0; }
 #endif
 void encoder_ln_resid_enable(int on);      // encoder.hip: LayerNorm residuals recomputed by the next epilogue (tuning hook 230 / 231)
+void encoder_ln_slab_fusion_enable(int on); // encoder.hip: split-K slab epilogues fused into the following LayerNorm (tuning hook 270 / 271)
 void encoder_wgrad_group_enable(int on);    // encoder.hip: one grouped weight-gradient launch per layer (tuning hook 240 / 241)
 void tail_overlap_enable(int on);          // tail.hip: loss kernel beside the decoder passes (tuning hook 210 / 211)
 int gemm_pp_init_device(int device);      // gemm_pp.hip: fills the GELU table (carel_init)
@@ -41,12 +42,23 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32, void* dy_bf16, void* partials,
                        hipStream_t stream);
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);
+// the same row kernel with its input gradient rows taken as  sum_z slabs[z][row] (+ resid[row])  -- the deferred epilogue (CAREL_EPI_ADD_F32) of a
+// split-K data-gradient GEMM, with that epilogue's order of additions (bit-identical to slab epilogue + layernorm_bwd_rows)
+int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, const void* h, const void* stats, const void* gamma, int64_t rows,
+                             uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32,
+                             void* dy_bf16, void* partials, hipStream_t stream);
 
 // carel_gemm_bf16 with the split-K heuristic told that `split_tile_factor` equal GEMMs run side by side (the forward's
 // half-batch chains): the split factor is then chosen as for ONE GEMM over all their rows -- same K partition, same bits; gemm.hip
 // (| GEMM_EX_FIXED_ROWS: M is the same whatever the batch -- the [CLS]-only last layer -- so a finer K partition is allowed)
 constexpr int GEMM_EX_FIXED_ROWS = 0x100;
+// (round 4) | GEMM_EX_DEFER_EPILOGUE: if this GEMM runs split-K into slabs, do NOT launch its slab epilogue: the caller's next kernel reads
+// the slabs itself (LayerNorm fused behind the split GEMMs of packed ECPE batches: layernorm_bwd_rows_slabs / layernorm_fwd_slabs).  Only
+// together with a plan: gemm_bf16_split_plan() tells how many slabs the same call would write (1 = it does not split: do not defer).
+constexpr int GEMM_EX_DEFER_EPILOGUE = 0x200;
+constexpr int GEMM_EX_PLAN_ONLY = 0x400;       // (internal to gemm.hip)
 int gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream);
+int gemm_bf16_split_plan(const carel_gemm_args* a, int split_tile_factor);       // slabs the internal split-K path would write for this call; 1 = single pass
 // largest value carel_gemm_wgrad_splits(M, N, T) can take under any tuning-hook setting (slab buffer sizing); gemm.hip
 int gemm_wgrad_splits_max(int M, int N, long T);
 int embed_ln_bwd_ex(const carel_embed_args* a, const void* dx0, void* dword, void* dpos, void* dtype_, void* dgamma, void* dbeta,

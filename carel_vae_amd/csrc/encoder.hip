@@ -157,6 +157,8 @@ SideStream* side_stream() {
 // lnres != null (residual epilogue): `resid` holds the pre-LayerNorm rows of the LayerNorm whose output is the residual; the epilogue
 // recomputes it (carel_gemm_args.resid_ln_*), so that LayerNorm never writes its f32 output
 struct LnResid { const void* stats; const void* gamma; const void* beta; };
+CAREL_TUNABLE(int, g_ln_slab_fusion, 1);   // (experiments build: hook 270 / 271) slab epilogues of the split-K GEMMs as their own launch / fused into the LayerNorm that follows
+int ln_slab_fusion_enabled() { return g_ln_slab_fusion; }
 CAREL_TUNABLE(int, g_wgrad_group, 1);       // (experiments build: hook 240 / 241) one GEMM + reduction per weight gradient / the grouped launch
 int wgrad_group_enabled() { return g_wgrad_group; }
 CAREL_TUNABLE(int, g_ln_resid, 1);          // tuning hook (carel_gemm_set_variant(230 / 231)): LayerNorm f32 outputs written and read back / recomputed by the next epilogue
@@ -164,7 +166,7 @@ int ln_resid_enabled() { return g_ln_resid; }
 int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, int K, int form, int epi, int splits, void* out_bf16,
               void* out2, void* out_f32, const void* bias, const void* resid, const void* aux, uint32_t seed, uint32_t site,
               uint32_t off, float p, void* stream, void* colsum_part = nullptr, const void* row_map = nullptr, void* ws = nullptr,
-              size_t ws_bytes = 0, int split_tile_factor = 1, const LnResid* lnres = nullptr) {
+              size_t ws_bytes = 0, int split_tile_factor = 1, const LnResid* lnres = nullptr, int* plan = nullptr) {
   carel_gemm_args g;
   g.resid_ln_stats = lnres ? lnres->stats : nullptr; g.resid_ln_gamma = lnres ? lnres->gamma : nullptr; g.resid_ln_beta = lnres ? lnres->beta : nullptr;
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K; g.form = form; g.epilogue = epi; g.splits = splits;
@@ -175,6 +177,7 @@ int gemm_call(const void* A, const void* B, long lda, long ldb, int M, int N, in
   // written by nobody else: pair split-K may keep its flags there.  Not for the second forward chain, whose workspace is the
   // weight-gradient slab area.
   g.splitk_ws_zeroed = (ws != nullptr && (split_tile_factor & 0xff) == 1) ? 1 : 0;
+  if (plan) { *plan = gemm_bf16_split_plan(&g, split_tile_factor); return CAREL_OK; }      // no launch: how many slabs would this call write?
   return gemm_bf16_ex(&g, split_tile_factor, stream);
 }
 
@@ -211,7 +214,8 @@ int wgrad_call(const void* dY, const void* X, long T, int M, int N, void* slabs,
 }  // namespace
 
 #ifdef CAREL_EXPERIMENTS
-namespace carel { void encoder_ln_resid_enable(int on) { g_ln_resid = on ? 1 : 0; } void encoder_wgrad_group_enable(int on) { g_wgrad_group = on ? 1 : 0; } }
+namespace carel { void encoder_ln_resid_enable(int on) { g_ln_resid = on ? 1 : 0; } void encoder_wgrad_group_enable(int on) { g_wgrad_group = on ? 1 : 0; }
+                  void encoder_ln_slab_fusion_enable(int on) { g_ln_slab_fusion = on ? 1 : 0; } }
 #endif
 
 extern "C" void* carel_side_stream(int32_t which) {
@@ -460,9 +464,24 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
     const int64_t need = carel_gemm_wgrad_group_ws_bytes(&ga);
     grouped = need >= 0 && need <= (int64_t)sl.slab_bytes;
   }
+  // Packed ECPE batches (~1.8 k rows): the N = 768 data-gradient GEMMs run split-K into slabs + a slab epilogue.  Where the only reader of that
+  // epilogue's f32 output is the LayerNorm backward that follows (FFN1 data gradient -> LayerNorm 1; QKV data gradient -> LayerNorm 2 of the
+  // layer below, i.e. the NEXT call), the epilogue is deferred into that kernel (GEMM_EX_DEFER_EPILOGUE, layernorm_bwd_rows_slabs): same bits,
+  // one launch and one round trip of the rows fewer per sub-layer.  The decision is a function of the shapes only, so this call knows what
+  // the previous one did.  Layer 0's QKV data gradient feeds the embedding backward and is never deferred.
+  int qkv_slabs = 1;
+  if (ln_slab_fusion_enabled()) {
+    if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
+                        s.dy, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1, nullptr, &qkv_slabs))) return rc;
+  }
+  // (did the call for layer + 1 defer its QKV epilogue?  then dx = sum of the slabs + s.dy; a [CLS]-only last layer never defers)
+  const bool dx_in_slabs = qkv_slabs > 1 && layer + 1 < a->n_layers && !(a->n_cls > 0 && layer + 2 == a->n_layers);
   // LN2 backward: dx -> dh2 (s.dy), dyb (dropout-masked, bf16), dgamma/dbeta, FFN2 bias grad
   if ((rc = wait_group(0))) return rc;
-  if ((rc = layernorm_bwd_rows(a->dx, la.h2, la.st2, w.ln2_g, R, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb,
+  if (dx_in_slabs) {
+    if ((rc = layernorm_bwd_rows_slabs(s.ws, qkv_slabs, s.dy, la.h2, la.st2, w.ln2_g, R, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy,
+                                       s.dyb, s.part, (hipStream_t)stream))) return rc;
+  } else if ((rc = layernorm_bwd_rows(a->dx, la.h2, la.st2, w.ln2_g, R, a->drop_seed, 3 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb,
                                s.part, (hipStream_t)stream))) return rc;
   // FFN2: du = (dyb W2) * gelu'(u) ; dW2 = dyb^T g
   //       the FFN1 bias gradient (column sums of du) comes out of the same epilogue as per-row-tile partials
@@ -482,11 +501,20 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
     if ((rc = wgrad_call(s.du, la.x1_bf16, R, EI, EH, s.slabs, g.ffn1_w, wstream, g.ffn1_b))) return rc;
     if ((rc = group_done(1))) return rc;
   }
+  int ffn1_slabs = 1;
+  if (ln_slab_fusion_enabled() && !cls_only) {
+    if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
+                        nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1, nullptr, &ffn1_slabs))) return rc;
+  }
   if ((rc = gemm_call(s.du, w.ffn1_w, EI, EH, (int)R, EH, EI, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr, s.dy,
-                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0)))) return rc;
+                      nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes,
+                      1 | (cls_only ? GEMM_EX_FIXED_ROWS : 0) | (ffn1_slabs > 1 ? GEMM_EX_DEFER_EPILOGUE : 0)))) return rc;
   // LN1 backward (its bf16 output goes to a second buffer: the FFN2 weight gradient may still be reading dyb)
   if ((rc = wait_group(2))) return rc;
-  if ((rc = layernorm_bwd_rows(a->dx, la.h1, la.st1, w.ln1_g, R, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb2,
+  if (ffn1_slabs > 1) {          // dx = sum of the FFN1 data gradient's slabs + dh2 (s.dy), never stored
+    if ((rc = layernorm_bwd_rows_slabs(s.ws, ffn1_slabs, s.dy, la.h1, la.st1, w.ln1_g, R, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy,
+                                       s.dyb2, s.part3, (hipStream_t)stream))) return rc;
+  } else if ((rc = layernorm_bwd_rows(a->dx, la.h1, la.st1, w.ln1_g, R, a->drop_seed, 2 + 3 * layer, hoff, a->hidden_dropout, rmap, s.dy, s.dyb2,
                                s.part3, (hipStream_t)stream))) return rc;
   // out-proj: dctx = dyb Wo ; dWo = dyb^T ctx
   void* dctx_rows = cls_only ? (void*)s.dqkv : (void*)s.dctx;     // compact result parks in the (still free) dqkv buffer
@@ -530,8 +558,10 @@ extern "C" int carel_encoder_backward_layer(const carel_encoder_args* a, int32_t
   if ((rc = fork())) return rc;
   if (grouped) { if ((rc = carel_gemm_wgrad_group(&ga, wstream))) return rc; }
   else if ((rc = wgrad_call(s.dqkv, la.xin_bf16, T, 3 * EH, EH, s.slabs, g.qkv_w, wstream, g.qkv_b))) return rc;
+  // (deferred: the next call's LayerNorm-2 backward adds the slabs and dh1 itself -- dh1 must then be s.dy, i.e. not the [CLS]-only layer's scattered rows)
+  const bool defer_qkv = qkv_slabs > 1 && layer > 0 && !cls_only;
   if ((rc = gemm_call(s.dqkv, w.qkv_w, 3 * EH, EH, (int)T, EH, 3 * EH, CAREL_GEMM_NN, CAREL_EPI_ADD_F32, 1, nullptr, nullptr, a->dx, nullptr,
-                      dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes))) return rc;
+                      dh1_full, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, s.ws, ws_bytes, 1 | (defer_qkv ? GEMM_EX_DEFER_EPILOGUE : 0)))) return rc;
   if (!grouped && (rc = group_done(3))) return rc;
   if (sd) {
     // side stream: this layer's weight gradients are enqueued; main stream: those of the PREVIOUS call (layer + 1) are complete from here

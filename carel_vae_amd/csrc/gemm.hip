@@ -454,8 +454,21 @@ static bool big_auto(const GemmParams& p, int splits) {
   return tiles >= 192 && (p.N >= 2304 || splits > 1);
 }
 
+static thread_local int tl_split_plan = 1;      // result of the last GEMM_EX_PLAN_ONLY pass (gemm_bf16_split_plan)
 template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
+  const bool plan_only = (p.split_tile_factor & GEMM_EX_PLAN_ONLY) != 0, defer = (p.split_tile_factor & GEMM_EX_DEFER_EPILOGUE) != 0;
+  if (plan_only) {          // the decisions below without a launch: does this call take the internal split-K path, and with how many slabs?
+    tl_split_plan = 1;
+    if (!AT && g_gemm_variant == 0) {
+      const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
+      if (gemm_pp_pick(p, BT, EPI, only_pp ? 1 : -g_pp_min_tiles)) return CAREL_OK;
+      const bool big_ok = (p.M % 256 == 0) && (p.N % 192 == 0), v1_ok = (p.M % 128 == 0) && (p.N % 128 == 0);
+      if ((big_ok && !v1_ok) || !v1_ok) return CAREL_OK;
+      if (EPI != EPI_SLAB_F32 && p.splitk_ws) tl_split_plan = auto_splits(p, p.splitk_ws_bytes);
+    }
+    return CAREL_OK;
+  }
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
 #ifdef CAREL_EXPERIMENTS
@@ -514,14 +527,17 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
         q.K = p.K;                       // the ping-pong kernel slices K by gridDim.z itself
         int rc = gemm_pp_launch_slab(q, BT, pp_npn, sp, s);
         if (rc) return rc;
+        if (defer) return CAREL_OK;          // the caller's next kernel consumes the slabs (GEMM_EX_DEFER_EPILOGUE)
         hipLaunchKernelGGL((slab_epilogue_kernel<EPI>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, p, (const float*)p.splitk_ws, sp);
         return check_launch("gemm_pp_kernel split-K + slab_epilogue_kernel");
       }
       hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI_SLAB_F32>), dim3(p.tiles_m * p.tiles_n, 1, sp), dim3(256), 0, s, q);
+      if (defer) return check_launch("gemm_kernel split-K (epilogue deferred)");
       hipLaunchKernelGGL((slab_epilogue_kernel<EPI>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, p, (const float*)p.splitk_ws, sp);
       return check_launch("gemm_kernel split-K + slab_epilogue_kernel");
     }
   }
+  if (defer) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: internal: epilogue deferred for a GEMM that does not split (plan / launch disagree)");
   hipLaunchKernelGGL((gemm_kernel<AT, BT, EPI>), grid, dim3(256), 0, s, p);
   return check_launch("gemm_kernel");
 }
@@ -598,7 +614,7 @@ __global__ void prof_empty_kernel() {}
 struct ProfScope {
   hipStream_t s; bool active;
   ProfScope(hipStream_t st, double fl) : s(st), active(false) {
-    if (!g_prof.on || g_prof.used + 2 > g_prof.ev.size()) return;
+    if (!g_prof.on || fl < 0.0 || g_prof.used + 2 > g_prof.ev.size()) return;
     if (!g_prof.calibrated) {        // once, on the stream being profiled: what an event pair around a kernel costs by itself
       g_prof.calibrated = true;
       for (size_t i = 0; i + 1 < g_prof.cal.size(); i += 2) {
@@ -739,6 +755,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 160 || v == 161) { gemm_pp_gelu_lut(v - 160); return CAREL_OK; }
   if (v >= 190 && v <= 192) { g_rowln_mode = v - 190; return CAREL_OK; }
   if (v >= 193 && v <= 195) { gemm_rowln_dbg(v - 193); return CAREL_OK; }                 // (ablation builds: 194 no MFMA, 195 no weight loads)
+  if (v == 270 || v == 271) { encoder_ln_slab_fusion_enable(v - 270); return CAREL_OK; }   // split-K slab epilogues as their own launch / fused into the following LayerNorm (default)
   if (v >= 250 && v <= 252) { gemm_pp_group_mode(v - 250); return CAREL_OK; }             // grouped weight gradients: 256 x 96 tiles + split remainder (default) / 256 x 192 whole / 256 x 96 whole
   if (v == 240 || v == 241) { encoder_wgrad_group_enable(v - 240); return CAREL_OK; }   // one GEMM + reduction per weight gradient / one grouped launch per layer (default)
   if (v == 230 || v == 231) { encoder_ln_resid_enable(v - 230); return CAREL_OK; }     // encoder forward: LayerNorm f32 outputs stored and re-read / recomputed by the next residual epilogue (default)
@@ -754,6 +771,12 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
 #endif   // CAREL_EXPERIMENTS
 
 extern "C" int carel_gemm_bf16(const carel_gemm_args* a, void* stream_) { return carel::gemm_bf16_ex(a, 1, stream_); }
+
+int carel::gemm_bf16_split_plan(const carel_gemm_args* a, int split_tile_factor) {
+  tl_split_plan = 1;
+  if (carel::gemm_bf16_ex(a, (split_tile_factor & ~GEMM_EX_DEFER_EPILOGUE) | GEMM_EX_PLAN_ONLY, nullptr)) return 1;
+  return tl_split_plan;
+}
 
 int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -806,7 +829,7 @@ int carel::gemm_bf16_ex(const carel_gemm_args* a, int split_tile_factor, void* s
     default: return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: unknown epilogue %d", epi);
   }
 #undef NEED
-  ProfScope prof_scope(stream, 2.0 * (double)a->M * (double)a->N * (double)a->K);
+  ProfScope prof_scope(stream, (split_tile_factor & GEMM_EX_PLAN_ONLY) ? -1.0 : 2.0 * (double)a->M * (double)a->N * (double)a->K);
   if (form == CAREL_GEMM_NT) {
     switch (epi) {
       case EPI_BIAS_BF16: return launch<false, false, EPI_BIAS_BF16>(p, 1, stream);

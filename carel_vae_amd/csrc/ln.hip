@@ -153,11 +153,16 @@ __device__ __forceinline__ void write_partials(float* lds /*[4][H]*/, const Row&
 // dy_out: grad w.r.t. the LN output (f32).  Outputs: dh (f32, grad w.r.t. the LN input = residual-path
 // gradient), dyb (bf16, dh * dropout-mask of the sub-layer output = grad w.r.t. the GEMM result),
 // partials[blk][3][H] = {dgamma, dbeta, dbias}.
+// SLAB (round 4, packed ECPE batches): dy_out is not a stored array but the deferred epilogue of a split-K data-gradient GEMM --
+// sum_z slabs[z][row] (+ resid[row]), added in the order slab_epilogue_kernel<CAREL_EPI_ADD_F32> uses -- so that the f32 rows never make a
+// round trip through memory and one launch per sub-layer goes away (at ~1.8 k rows every launch is ~6-10 us of mostly latency).
+struct LnSlabSrc { int splits; long plane; const float* resid; };
+template <bool SLAB>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy_out, const float* __restrict__ h,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      long rows, Dropout drop, const int* __restrict__ row_map,
                                                      float* __restrict__ dh, bf16_t* __restrict__ dyb,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, LnSlabSrc src) {
   __shared__ float lds[4 * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const Row G = load_row(gamma, lane);
@@ -178,6 +183,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const long row = (long)blockIdx.x * LNB_ROWS + wave + 4 * k;
     const long lrow = row < rows ? row : rows - 1;
     DYr[k] = load_row(dy_out + lrow * H, lane);
+    if constexpr (SLAB) {
+      for (int z = 1; z < src.splits; ++z) {
+        const Row Z = load_row(dy_out + (long)z * src.plane + lrow * H, lane);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { DYr[k].v[i].x += Z.v[i].x; DYr[k].v[i].y += Z.v[i].y; DYr[k].v[i].z += Z.v[i].z; DYr[k].v[i].w += Z.v[i].w; }
+      }
+      if (src.resid) {
+        const Row R = load_row(src.resid + lrow * H, lane);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { DYr[k].v[i].x += R.v[i].x; DYr[k].v[i].y += R.v[i].y; DYr[k].v[i].z += R.v[i].z; DYr[k].v[i].w += R.v[i].w; }
+      }
+    }
     XHr[k] = load_row(h + lrow * H, lane);
     mr[k] = stats[lrow * 2]; rr[k] = stats[lrow * 2 + 1];
     dr[k] = rm[lrow];                               // (a load issued after a row's stores would wait for their acknowledgement)
@@ -612,10 +629,20 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        hipStream_t stream) {
   if (!dy || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_bwd: bad arguments");
   const int nblk = carel_layernorm_bwd_blocks(rows);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
+  hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
                      (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
-                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials);
+                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, LnSlabSrc{1, 0, nullptr});
   return check_launch("ln_bwd_kernel");
+}
+int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, const void* h, const void* stats, const void* gamma, int64_t rows,
+                             uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32,
+                             void* dy_bf16, void* partials, hipStream_t stream) {
+  if (!slabs || splits < 2 || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "layernorm_bwd_rows_slabs: bad arguments");
+  const int nblk = carel_layernorm_bwd_blocks(rows);
+  hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, (const float*)slabs, (const float*)h, (const float*)stats,
+                     (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
+                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, LnSlabSrc{splits, (long)rows * H, (const float*)resid});
+  return check_launch("ln_bwd_kernel<slabs>");
 }
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream) {
   const int nblk = carel_layernorm_bwd_blocks(rows);

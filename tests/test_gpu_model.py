@@ -652,6 +652,40 @@ def test_embedding_table_gradients_are_bit_reproducible(shape, variant):
         assert torch.equal(runs[0][k].cpu().abs().sum(1) > 0, touched), k          # exactly the rows the batch uses, no others
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize("cls_only", [True, False])
+def test_split_k_epilogues_fused_into_the_layernorm_backward_same_bits(cls_only):
+    """Round 4, packed ECPE batches: the slab epilogue of the split-K FFN1 / QKV data-gradient GEMMs is deferred into the LayerNorm backward
+    that reads it (hook 271, the default; 270 = its own launch as before).  Same order of additions: the loss and EVERY gradient bit-identical,
+    three layers (so that a middle layer both consumes the layer above's deferred rows and defers its own), with and without the [CLS]-only
+    last layer, dropout on, side stream on and off."""
+    lib = L.load()
+    cfg, opt = O.EncoderConfig(layers=3, vocab_size=2000), O.Opt(pair_bow_dim=513, dropout=0.3)
+    batch = O.synthetic_batch(64, 128, cfg, opt.pair_bow_dim, seed=9, shape="B")
+    g = torch.Generator().manual_seed(3)
+    eps_e, eps_c = torch.randn(opt.ec_dim, generator=g), torch.randn(opt.ec_dim, generator=g)
+    res = {}
+    for hook in (270, 271):
+        for overlap in (False, True):
+            L.check(lib.carel_gemm_set_variant(hook))
+            try:
+                model, P = build(cfg, opt, 5, train_dropout=True)
+                model.train()
+                model.overlap_wgrad, model.cls_only_last = overlap, cls_only
+                model.set_noise(eps_e, eps_c)
+                loss = model(*call(model, batch, 3))
+                loss.backward()
+                torch.cuda.synchronize()
+                res[(hook, overlap)] = (loss.detach().clone(), {k: p_.grad.detach().clone() for k, p_ in model.named_parameters() if p_.grad is not None})
+            finally:
+                L.check(lib.carel_gemm_set_variant(271))
+    base = res[(270, False)]
+    for key, (loss, grads) in res.items():
+        assert torch.equal(loss, base[0]), key
+        for k, v in base[1].items():
+            assert torch.equal(v, grads[k]), (key, k)
+
+
 def _report(name, payload):
     """measured figures of the tight parity tests, for DESIGN.md (written beside the other GPU-box outputs when that directory exists)"""
     import json
