@@ -771,9 +771,19 @@ static int wgrad_group_plan(const WgradGroupProb* pb, int n, long T, PPGroup& g,
   if (nk < 4 || n_full + P * s > PP_GROUP_MAX_ITEMS) return 0;
   unsigned short lin[PP_GROUP_MAX_ITEMS];
   int k = 0;
-  for (int i = 0; i < n; ++i)
-    for (int tm = 0; tm < pb[i].M / 256; ++tm)
-      for (int tn = 0; tn < pb[i].N / BN; ++tn) lin[k++] = (unsigned short)(i | (tm << 2) | (tn << 6));
+  // linear tile order per problem: an XCD's run of 32 consecutive tiles should stage few distinct operand blocks (256 dY columns per tile row,
+  // 96 X columns per tile column).  Few tile rows (FFN2: 3 x 32) -> tile rows innermost: a run is all 3 rows x ~11 columns (233 KB per K
+  // tile into that XCD's L2 instead of 425 KB for 1 row x 32 columns); otherwise tile columns innermost (FFN1 12 x 8, QKV 9 x 8: 4 rows x 8 columns)
+  for (int i = 0; i < n; ++i) {
+    const int ntm = pb[i].M / 256, ntn = pb[i].N / BN;
+    if (ntm <= 4 && ntn > 8) {
+      for (int tn = 0; tn < ntn; ++tn)
+        for (int tm = 0; tm < ntm; ++tm) lin[k++] = (unsigned short)(i | (tm << 2) | (tn << 6));
+    } else {
+      for (int tm = 0; tm < ntm; ++tm)
+        for (int tn = 0; tn < ntn; ++tn) lin[k++] = (unsigned short)(i | (tm << 2) | (tn << 6));
+    }
+  }
   // whole tiles: round r (cus tiles) of the linear order, XCD x takes the run [x * cus / 8, (x + 1) * cus / 8) of it; dispatch slot 8 q + x
   const int per = cus / 8, full_rounds = (n_full / cus) * cus;
   for (int f = 0; f < full_rounds; ++f) {
