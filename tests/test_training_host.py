@@ -232,3 +232,29 @@ def test_prf1_equals_sklearn_fixtures():
     for m in _golden_selftrain()["metrics"]:
         p, r, f = T._prf1([[v] for v in m["labels"]], [[float(v)] for v in m["preds"]])
         assert abs(p - m["precision"]) < 1e-12 and abs(r - m["recall"]) < 1e-12 and abs(f - m["f1"]) < 1e-12, m
+
+
+def test_running_loss_prints_the_reference_lines_in_order_without_reading_the_loss_each_step():
+    """training.RunningLoss (round 4): the reference's `running_loss += loss.item()` ... every 10 iterations print running_loss / 10 (:845-851),
+    kept as a tensor sum and read back in blocks of ten.  Same numbers, same order, same format; a partial last block prints nothing (the
+    reference's `if iteration % 10 == 9`); more blocks pending than read-back slots forces an early flush, never a lost line."""
+    logs = []
+    rl = T.RunningLoss("cpu", every=10, log=logs.append, slots=4)
+    vals = [0.5 * i - 3.0 for i in range(57)]
+    for it, v in enumerate(vals):
+        rl.add(torch.tensor(v), 2, it)
+    rl.flush(wait=True)
+    want = ["[%d, %5d] training loss: %.4f" % (2, 10 * (b + 1), sum(vals[10 * b:10 * b + 10]) / 10) for b in range(5)]
+    assert logs == want and len(rl.values) == 5
+    assert abs(rl.values[2] - sum(vals[20:30]) / 10) < 1e-6
+
+
+def test_train_loop_logs_the_running_loss_like_the_reference(tmp_path):
+    opt = make_opt(epochs=1, self_epochs=1, best_model_path=str(tmp_path / "ckpt"), model_id="t2")
+    model = TinyModel()
+    optim = torch.optim.SGD(model.parameters(), lr=0.0)
+    logs = []
+    T.train(list(batches(25 * 2, 2)), list(batches(4, 4)), model, [optim], "cpu", num_unpred_pairs=0, opt=opt, log=logs.append)
+    lines = [l for l in logs if "training loss" in l]
+    assert lines == ["[1,    10] training loss: 1.0000", "[1,    20] training loss: 1.0000"]       # 25 steps: two full blocks, like ref :848-851
+    assert logs.index(lines[-1]) < next(i for i, l in enumerate(logs) if "precision" in l)        # printed before the epoch's evaluation line
