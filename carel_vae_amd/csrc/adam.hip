@@ -122,9 +122,15 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 using namespace carel;
 
-static unsigned grid_for(long n) {
+// Grid of the Adam launch (tuning hook 280 + k in the experiments build: cap = 32 << k workgroups, 292 = none): one float4 per thread up to 134 M
+// elements streams fastest stand-alone (tools/ubench/adam_stream.hip: a capped, grid-striding launch is 8-14 % slower) ...
+CAREL_TUNABLE(long, g_adam_grid_cap, 131072);
+#ifdef CAREL_EXPERIMENTS
+namespace carel { void adam_grid_cap(long cap) { g_adam_grid_cap = cap; } }
+#endif
+static unsigned grid_for(long n, long cap = 131072) {
   long blocks = (n / 4 + 255) / 256;
-  return (unsigned)(blocks < 1 ? 1 : (blocks > 131072 ? 131072 : blocks));     // (one float4 per thread up to 134 M elements: a capped, grid-striding launch streams 8-14 % slower -- tools/ubench/adam_stream.hip)
+  return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
 extern "C" int carel_adam_step(const carel_adam_args* a, void* stream_) {
@@ -145,7 +151,7 @@ extern "C" int carel_adam_step(const carel_adam_args* a, void* stream_) {
   k.decay = (float)(1.0 - (double)a->lr * (double)a->weight_decay);
   k.seg = (const long*)a->decay_segments; k.nseg = a->decay_segments ? a->n_decay_segments : 0;
   if (a->weight_decay != 0.f && !a->decay_segments) return set_error(CAREL_ERR_ARG, "carel_adam_step: weight_decay needs decay_segments");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(k.n)), dim3(256), 0, stream, k);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(k.n, g_adam_grid_cap)), dim3(256), 0, stream, k);
   if (a->skip_count && a->skip_flag)       // after the update: one more frozen step on the range's record if this one was frozen
     hipLaunchKernelGGL(adam_skip_bump_kernel, dim3(1), dim3(1), 0, stream, (const float*)a->skip_flag, (float*)a->skip_count);
   return check_launch("adam_kernel");

@@ -31,6 +31,7 @@ inline int gemm_rowln_wanted_k(int) { return 0; }
 void encoder_ln_resid_enable(int on);      // encoder.hip: LayerNorm residuals recomputed by the next epilogue (tuning hook 230 / 231)
 void encoder_ln_slab_fusion_enable(int on); // encoder.hip: split-K slab epilogues fused into the following LayerNorm (tuning hook 270 / 271)
 void encoder_wgrad_group_enable(int on);    // encoder.hip: one grouped weight-gradient launch per layer (tuning hook 240 / 241)
+void adam_grid_cap(long cap);            // adam.hip: workgroups per Adam launch (tuning hook 280 + k)
 void tail_overlap_enable(int on);          // tail.hip: loss kernel beside the decoder passes (tuning hook 210 / 211)
 int gemm_pp_init_device(int device);      // gemm_pp.hip: fills the GELU table (carel_init)
 // 768-wide row gather / scatter by int32 index (ln.hip); either of the f32 / bf16 pairs may be null
@@ -47,6 +48,12 @@ int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void*
 int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, const void* h, const void* stats, const void* gamma, int64_t rows,
                              uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32,
                              void* dy_bf16, void* partials, hipStream_t stream);
+// ln.hip: the slab epilogue of a split-K out-projection / FFN2 (bias + dropout + residual, stored or recomputed LN(resid)) and the LayerNorm
+// behind it in one launch (packed batches; GEMM_EX_DEFER_EPILOGUE leaves the slabs in the workspace)
+int layernorm_fwd_slabs(const void* slabs, int splits, const void* bias, const void* resid, const void* resid_stats, const void* resid_gamma,
+                        const void* resid_beta, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p, const void* drop_row_map,
+                        void* h_out, const void* gamma, const void* beta, float eps, int64_t rows, void* x_f32, void* x_bf16, void* stats,
+                        hipStream_t stream);
 
 // carel_gemm_bf16 with the split-K heuristic told that `split_tile_factor` equal GEMMs run side by side (the forward's
 // half-batch chains): the split factor is then chosen as for ONE GEMM over all their rows -- same K partition, same bits; gemm.hip

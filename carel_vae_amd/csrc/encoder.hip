@@ -326,9 +326,20 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     if (fuse_ln) {
       if ((rc = linear_ln(Actx, w.out_w, EH, w.out_b, res1, 2 + 3 * i, w.ln1_g, w.ln1_b, a->inference ? nullptr : la.h1, xb, la.x1_bf16, la.st1))) return rc;
     } else {
+    // (packed batches: where the linear runs split-K into slabs, its slab epilogue -- bias, dropout, residual -- is the first half of the LayerNorm
+    // kernel behind it: one launch and one round trip of the rows fewer per sub-layer; ln_fwd_slabs_kernel, same expressions in the same order)
+    int out_slabs = 1;
+    if (ln_slab_fusion_enabled() && ws &&
+        (rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1, w.out_b, res1, nullptr,
+                        a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed, plr1, &out_slabs))) return rc;
     if ((rc = gemm_call(Actx, w.out_w, EH, EH, (int)R, EH, EH, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h1,
-                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed, plr1))) return rc;
-    if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, lnres2 ? nullptr : xb, la.x1_bf16, la.st1, stream))) return rc;
+                        w.out_b, res1, nullptr, a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes,
+                        chains | fixed | (out_slabs > 1 ? GEMM_EX_DEFER_EPILOGUE : 0), plr1))) return rc;
+    if (out_slabs > 1) {
+      if ((rc = layernorm_fwd_slabs(ws, out_slabs, w.out_b, res1, plr1 ? plr1->stats : nullptr, plr1 ? plr1->gamma : nullptr, plr1 ? plr1->beta : nullptr,
+                                    a->drop_seed, 2 + 3 * i, hoff, a->hidden_dropout, rmap, la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, lnres2 ? nullptr : xb,
+                                    la.x1_bf16, la.st1, (hipStream_t)stream))) return rc;
+    } else if ((rc = carel_layernorm_fwd(la.h1, w.ln1_g, w.ln1_b, a->ln_eps, R, EH, lnres2 ? nullptr : xb, la.x1_bf16, la.st1, stream))) return rc;
     }
     if ((rc = gemm_call(la.x1_bf16, w.ffn1_w, EH, EH, (int)R, EI, EH, CAREL_GEMM_NT, a->inference ? CAREL_EPI_BIAS_GELU : CAREL_EPI_BIAS_GELU_DG, 1, a->inference ? nullptr : la.u, la.g, nullptr,
                         w.ffn1_b, nullptr, nullptr, 0, 0, 0, 0.f, stream, nullptr, nullptr, ws, ws_bytes, chains | fixed))) return rc;
@@ -337,10 +348,19 @@ static int forward_layers(const carel_encoder_args* a, int l0, int l1, long b0, 
     if (fuse_ln && gemm_rowln_wanted_k(EI)) {
       if ((rc = linear_ln(la.g, w.ffn2_w, EI, w.ffn2_b, xb, 3 + 3 * i, w.ln2_g, w.ln2_b, a->inference ? nullptr : la.h2, xa, next_bf16, la.st2))) return rc;
     } else {
+    const void* res2 = lnres2 ? (const void*)la.h1 : (const void*)xb;
+    int ffn2_slabs = 1;
+    if (ln_slab_fusion_enabled() && ws &&
+        (rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2, w.ffn2_b, res2, nullptr,
+                        a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws, ws_bytes, chains | fixed, lnres2 ? &lr2 : nullptr, &ffn2_slabs))) return rc;
     if ((rc = gemm_call(la.g, w.ffn2_w, EI, EI, (int)R, EH, EI, CAREL_GEMM_NT, CAREL_EPI_BIAS_DROP_RESID, 1, nullptr, nullptr, la.h2,
-                        w.ffn2_b, lnres2 ? (const void*)la.h1 : (const void*)xb, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws,
-                        ws_bytes, chains | fixed, lnres2 ? &lr2 : nullptr))) return rc;
-    if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, need_xa ? xa : nullptr, next_bf16, la.st2, stream))) return rc;
+                        w.ffn2_b, res2, nullptr, a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, stream, nullptr, rmap, ws,
+                        ws_bytes, chains | fixed | (ffn2_slabs > 1 ? GEMM_EX_DEFER_EPILOGUE : 0), lnres2 ? &lr2 : nullptr))) return rc;
+    if (ffn2_slabs > 1) {
+      if ((rc = layernorm_fwd_slabs(ws, ffn2_slabs, w.ffn2_b, res2, lnres2 ? lr2.stats : nullptr, lnres2 ? lr2.gamma : nullptr, lnres2 ? lr2.beta : nullptr,
+                                    a->drop_seed, 3 + 3 * i, hoff, a->hidden_dropout, rmap, la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, need_xa ? xa : nullptr,
+                                    next_bf16, la.st2, (hipStream_t)stream))) return rc;
+    } else if ((rc = carel_layernorm_fwd(la.h2, w.ln2_g, w.ln2_b, a->ln_eps, R, EH, need_xa ? xa : nullptr, next_bf16, la.st2, stream))) return rc;
     }
   }
   return CAREL_OK;

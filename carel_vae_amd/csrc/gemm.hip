@@ -446,7 +446,7 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
 }
 
 CAREL_TUNABLE(int, g_pp_split, 1);       // carel_gemm_set_variant(140 / 141): internally split NT / NN GEMMs on the 128x128 kernel / on the ping-pong kernel where it fits
-CAREL_TUNABLE(int, g_pp_min_tiles, 192); // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles
+CAREL_TUNABLE(int, g_pp_min_tiles, 96);  // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles (round 4, packed ECPE step, tools/ab_ecpe.sh: 4.23 ms at 96, 4.25 at 128-160, 4.28-4.30 at 192, 4.32 at 64, 4.65 at 32)
 CAREL_TUNABLE(int, g_big_auto, 0);       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
 static bool big_auto(const GemmParams& p, int splits) {
   if (!g_big_auto) return false;
@@ -760,6 +760,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 240 || v == 241) { encoder_wgrad_group_enable(v - 240); return CAREL_OK; }   // one GEMM + reduction per weight gradient / one grouped launch per layer (default)
   if (v == 230 || v == 231) { encoder_ln_resid_enable(v - 230); return CAREL_OK; }     // encoder forward: LayerNorm f32 outputs stored and re-read / recomputed by the next residual epilogue (default)
   if (v >= 220 && v <= 225) { gemm_tri_enable(v - 220); return CAREL_OK; }             // three-group kernel for the N = 768 forward GEMMs off (default) / on
+  if (v >= 280 && v <= 292) { adam_grid_cap(32L << (v - 280)); return CAREL_OK; }         // Adam launch: at most 32 << k workgroups (292: 131072 = one float4 per thread, default)
   if (v == 210 || v == 211) { tail_overlap_enable(v - 210); return CAREL_OK; }           // VAE tail: loss kernel on the side stream beside the decoder passes off / on (default)
   if (v == 200 || v == 201) { gemm_pp_pair_enable(v - 200); return CAREL_OK; }        // pair split-K of the N = 768, K >= 1536 GEMMs off (default: measured slower) / on
   if (v == 170 || v == 171) { gemm_pp_epi_prefetch(v - 170); return CAREL_OK; }       // ping-pong kernel: epilogue inputs requested before the main loop off / on

@@ -28,6 +28,55 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
   if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
 }
 
+// LayerNorm forward behind a split-K out-projection / FFN2 (packed ECPE batches, ~1.8 k rows): the slab epilogue
+// h = dropout(sum_z slabs[z] + bias) + residual -- slab_epilogue_kernel<EPI_BIAS_DROP_RESID>'s expression, additions in its order, the residual
+// either stored f32 rows or LN(resid) recomputed from the previous LayerNorm's input and statistics like the GEMM epilogues do -- and the
+// LayerNorm of h in ONE launch: h is written once (the backward pass and the next residual read it) and never read back here.
+struct LnFwdSlabs {
+  const float* slabs; int splits; long plane;
+  const float* bias; const float* resid; const float* resid_stats; const float* resid_gamma; const float* resid_beta;
+  Dropout drop; const int* row_map;
+  float* h_out;
+};
+__global__ __launch_bounds__(256) void ln_fwd_slabs_kernel(LnFwdSlabs q, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, long rows,
+                                                           float* __restrict__ x_f32, bf16_t* __restrict__ x_bf16, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  Row X = load_row(q.slabs + row * H, lane);
+  Row Rr = load_row(q.resid + row * H, lane);
+  for (int z = 1; z < q.splits; ++z) {
+    const Row Z = load_row(q.slabs + (long)z * q.plane + row * H, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { X.v[i].x += Z.v[i].x; X.v[i].y += Z.v[i].y; X.v[i].z += Z.v[i].z; X.v[i].w += Z.v[i].w; }
+  }
+  if (q.bias) {
+    const Row Bs = load_row(q.bias, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { X.v[i].x += Bs.v[i].x; X.v[i].y += Bs.v[i].y; X.v[i].z += Bs.v[i].z; X.v[i].w += Bs.v[i].w; }
+  }
+  if (q.resid_stats) {                 // the residual is LN(resid): the expression of ln_normalise / the GEMM epilogues (ln_apply)
+    const float pm = q.resid_stats[row * 2], pr = q.resid_stats[row * 2 + 1];
+    Row& A = Rr; const Row B = load_row(q.resid_gamma, lane), Cc = load_row(q.resid_beta, lane);
+    ROW_FOREACH(a = ln_apply(a, pm, pr, b, c); (void)e)
+  }
+  const long drow = q.row_map ? (long)q.row_map[row] : row;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float dm[4];
+    dropout_mult_n<4>(q.drop, (uint32_t)(drow * H + (i * 64 + lane) * 4), dm);
+    X.v[i].x = X.v[i].x * dm[0] + Rr.v[i].x; X.v[i].y = X.v[i].y * dm[1] + Rr.v[i].y;
+    X.v[i].z = X.v[i].z * dm[2] + Rr.v[i].z; X.v[i].w = X.v[i].w * dm[3] + Rr.v[i].w;
+  }
+  if (q.h_out) store_row(q.h_out + row * H, lane, X);
+  const Row G = load_row(gamma, lane), Bt = load_row(beta, lane);
+  float mean, rstd;
+  ln_normalise(X, G, Bt, eps, mean, rstd);
+  if (x_f32) store_row(x_f32 + row * H, lane, X);
+  if (x_bf16) store_row_bf16(x_bf16 + row * H, lane, X);
+  if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+
 // ------------------------------------------------------------------------------------------
 // Embeddings:  x0 = dropout(LN(word[ids] + pos[pid] + type[tt]))
 // position ids: BERT arange(S); RoBERTa cumsum(ids != pad) * (ids != pad) + pad
@@ -643,6 +692,20 @@ int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, c
                      (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
                      (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, LnSlabSrc{splits, (long)rows * H, (const float*)resid});
   return check_launch("ln_bwd_kernel<slabs>");
+}
+int layernorm_fwd_slabs(const void* slabs, int splits, const void* bias, const void* resid, const void* resid_stats, const void* resid_gamma,
+                        const void* resid_beta, uint32_t drop_seed, uint32_t drop_site, uint32_t drop_idx_offset, float drop_p, const void* drop_row_map,
+                        void* h_out, const void* gamma, const void* beta, float eps, int64_t rows, void* x_f32, void* x_bf16, void* stats,
+                        hipStream_t stream) {
+  if (!slabs || splits < 2 || !resid || !gamma || !beta || rows <= 0) return set_error(CAREL_ERR_ARG, "layernorm_fwd_slabs: bad arguments");
+  if (resid_stats && (!resid_gamma || !resid_beta)) return set_error(CAREL_ERR_ARG, "layernorm_fwd_slabs: recomputed residual needs gamma and beta");
+  LnFwdSlabs a;
+  a.slabs = (const float*)slabs; a.splits = splits; a.plane = (long)rows * H; a.bias = (const float*)bias; a.resid = (const float*)resid;
+  a.resid_stats = (const float*)resid_stats; a.resid_gamma = (const float*)resid_gamma; a.resid_beta = (const float*)resid_beta;
+  a.drop = make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset); a.row_map = (const int*)drop_row_map; a.h_out = (float*)h_out;
+  hipLaunchKernelGGL(ln_fwd_slabs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, (const float*)gamma, (const float*)beta, eps, (long)rows,
+                     (float*)x_f32, (bf16_t*)x_bf16, (float*)stats);
+  return check_launch("ln_fwd_slabs_kernel");
 }
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream) {
   const int nblk = carel_layernorm_bwd_blocks(rows);

@@ -656,7 +656,9 @@ def test_embedding_table_gradients_are_bit_reproducible(shape, variant):
 @pytest.mark.parametrize("cls_only", [True, False])
 def test_split_k_epilogues_fused_into_the_layernorm_backward_same_bits(cls_only):
     """Round 4, packed ECPE batches: the slab epilogue of the split-K FFN1 / QKV data-gradient GEMMs is deferred into the LayerNorm backward
-    that reads it (hook 271, the default; 270 = its own launch as before).  Same order of additions: the loss and EVERY gradient bit-identical,
+    that reads it, and the slab epilogue of the split-K out-projection / FFN2 forward GEMMs (bias + dropout + residual, stored or recomputed) into
+    the LayerNorm FORWARD behind it (ln_fwd_slabs_kernel) -- hook 271, the default; 270 = their own launches as before.  Same expressions in the
+    same order: the loss and EVERY gradient bit-identical,
     three layers (so that a middle layer both consumes the layer above's deferred rows and defers its own), with and without the [CLS]-only
     last layer, dropout on, side stream on and off."""
     lib = L.load()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the ping-pong GEMM's time goes: timing ablations (wrong results) of the QKV-forward (npn 3) and FFN2-forward-like
-(npn 1) launches.  Needs a library built with CAREL_BUILD_TAG=ablate CAREL_EXTRA_FLAGS=-DCAREL_GEMM_ABLATE python -m carel_vae_amd.build and loaded with CAREL_HIP_LIB=carel_vae_amd/libcarel_hip_ablate.so (the product library is not touched)."""
+(npn 1) launches.  Needs a library built with CAREL_BUILD_TAG=ablate CAREL_EXTRA_FLAGS=-DCAREL_GEMM_ABLATE python -m carel_vae_amd.build and (with -DCAREL_EXPERIMENTS too) loaded with CAREL_HIP_EXP_LIB=carel_vae_amd/libcarel_hip_ablate.so (the product library is not touched)."""
 import os, sys, statistics
 os.environ.setdefault("CAREL_USE_EXPERIMENTS", "1")      # tuning hooks live in libcarel_hip_exp.so only (carel_vae_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,9 @@ names = {3: "full", 61: "no DMA", 62: "no MFMA", 63: "no reads", 64: "no epilogu
 WIDE = int(os.environ.get("WIDE", 0))
 L.check(lib.carel_gemm_set_variant(90 + WIDE))
 print("wide-phase schedule" if WIDE else "fine schedule")
-for (M, N, K) in [(8192, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 768)]:
+MS = [int(x) for x in os.environ.get("MS", "8192").split(",")]          # MS=1664 for the packed ECPE row count
+if MS != [8192]: L.check(lib.carel_gemm_set_variant(51))                  # (small grids: the ping-pong kernel takes every grid of >= 32 tiles)
+for (M, N, K) in [(m, n, k) for m in MS for (n, k) in [(2304, 768), (3072, 768), (768, 3072), (768, 768)]]:
     A, B = rnd(M, K), rnd(N, K)
     out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     bias = torch.zeros(N, device="cuda")
