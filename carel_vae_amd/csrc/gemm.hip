@@ -447,6 +447,16 @@ static int auto_splits(const GemmParams& p, size_t ws_bytes) {
 
 CAREL_TUNABLE(int, g_pp_split, 1);       // carel_gemm_set_variant(140 / 141): internally split NT / NN GEMMs on the 128x128 kernel / on the ping-pong kernel where it fits
 CAREL_TUNABLE(int, g_pp_min_tiles, 96);  // carel_gemm_set_variant(50 + k): the ping-pong kernel runs grids of at least 32 * k tiles (round 4, packed ECPE step, tools/ab_ecpe.sh: 4.23 ms at 96, 4.25 at 128-160, 4.28-4.30 at 192, 4.32 at 64, 4.65 at 32)
+CAREL_TUNABLE(int, g_pp_min_tiles_k768, 32);   // carel_gemm_set_variant(40 + k): the same floor for K <= 768 (12 K tiles: a 56-tile grid of the ping-pong kernel is one short round; packed ECPE step 4.21 ms at 32 against 4.26 at 64-96, tools/ab_ecpe_k768.sh)
+// Packed batches, attention-output forward (K = 768, 56 tiles of the ping-pong kernel, dropout + residual epilogue of 24 k elements per workgroup): split
+// along K into slabs instead, so that the epilogue runs row-parallel inside the LayerNorm kernel behind it (ln_fwd_slabs_kernel).  Hook 330 + s.
+CAREL_TUNABLE(int, g_resid_split, 0);     // NOT adopted: packed ECPE step 4.157 -> 4.128 ms with 2 slabs (tools/ab_ecpe_resid_split.sh), but a K = 768 partition that depends on the row count makes a sample's bits depend on how the batch is sharded over ranks (tests/test_gpu_dp2.py: global MMD within 1e-5)
+static int resid_split(const GemmParams& p, int epi) {
+  if (g_resid_split < 2 || epi != EPI_BIAS_DROP_RESID || p.K != 768 || !p.splitk_ws || p.M <= 128 || (p.M % 128) || (p.N % 128) || (p.N % 96)) return 1;
+  const long t1 = (long)((p.M + 255) / 256) * (p.N / 96);
+  if (t1 >= 96 || t1 * g_resid_split > 256 || (size_t)g_resid_split * p.M * p.N * 4 > p.splitk_ws_bytes) return 1;
+  return g_resid_split;
+}
 CAREL_TUNABLE(int, g_big_auto, 0);       // set by carel_gemm_set_variant(30/31): 0 = never pick the big tile automatically
 static bool big_auto(const GemmParams& p, int splits) {
   if (!g_big_auto) return false;
@@ -462,7 +472,8 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     tl_split_plan = 1;
     if (!AT && g_gemm_variant == 0) {
       const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
-      if (gemm_pp_pick(p, BT, EPI, only_pp ? 1 : -g_pp_min_tiles)) return CAREL_OK;
+      if (resid_split(p, EPI) > 1) { tl_split_plan = resid_split(p, EPI); return CAREL_OK; }
+      if (gemm_pp_pick(p, BT, EPI, only_pp ? 1 : -(p.K <= 768 ? g_pp_min_tiles_k768 : g_pp_min_tiles))) return CAREL_OK;
       const bool big_ok = (p.M % 256 == 0) && (p.N % 192 == 0), v1_ok = (p.M % 128 == 0) && (p.N % 128 == 0);
       if ((big_ok && !v1_ok) || !v1_ok) return CAREL_OK;
       if (EPI != EPI_SLAB_F32 && p.splitk_ws) tl_split_plan = auto_splits(p, p.splitk_ws_bytes);
@@ -480,7 +491,8 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     if (!BT && g_gemm_variant == 0 && p.ldc == p.N && gemm_tri_pick(p, EPI)) return gemm_tri_launch(p, EPI, s);
 #endif
     const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
-    const int npn = gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60 || only_pp) ? 1 : -g_pp_min_tiles);
+    const int npn = (g_gemm_variant == 0 && resid_split(p, EPI) > 1) ? 0 :
+                    gemm_pp_pick(p, BT, EPI, (g_gemm_variant == 3 || g_gemm_variant >= 60 || only_pp) ? 1 : -(p.K <= 768 ? g_pp_min_tiles_k768 : g_pp_min_tiles));
 #ifdef CAREL_GEMM_ABLATE
     if (npn && !BT && EPI == EPI_BIAS_BF16 && g_gemm_variant >= 61 && g_gemm_variant <= 69) return gemm_pp_launch_dbg(p, npn, g_gemm_variant - 60, s);
 #endif
@@ -509,7 +521,8 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
   }
 #endif
   if (EPI != EPI_SLAB_F32 && p.splitk_ws) {
-    const int sp = auto_splits(p, p.splitk_ws_bytes);
+    const int rs = (!AT && g_gemm_variant == 0) ? resid_split(p, EPI) : 1;
+    const int sp = rs > 1 ? rs : auto_splits(p, p.splitk_ws_bytes);
     if (sp > 1) {
       GemmParams q = p;
       q.K = p.K / sp; q.outf = p.splitk_ws; q.ldc = p.N; q.colsum_part = nullptr;
@@ -748,6 +761,8 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
   if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }
   if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
+  if (v >= 330 && v <= 333) { g_resid_split = v - 330; return CAREL_OK; }
+  if (v >= 40 && v <= 49) { g_pp_min_tiles_k768 = (v - 40) * 32; return CAREL_OK; }
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }
   if (v >= 100 && v <= 116) { gemm_pp_wgrad_force(v - 100); return CAREL_OK; }         // ping-pong weight gradient: split-K factor forced (0 = heuristic)
   if (v == 130 || v == 131) { g_auto_split_min_k = v == 130 ? 1536 : 768; return CAREL_OK; }

@@ -921,7 +921,11 @@ int gemm_pp_pick(const GemmParams& p, bool bt, int epi, int force) {
   }
   if (!best) return 0;
   if (force <= 0) {                                                       // force = -(minimum tile count)
-    const long tiles = (long)tiles_m * (p.N / (96 * best));
+    // counted in 256 x 96 tiles over ALL the rows of the split_tile_factor equal GEMMs the caller runs side by side (the forward pass's half-batch
+    // chains): whether a GEMM runs here in one pass or split along K on the other path must not depend on how its rows are dealt to chains
+    // (a sample's bits would: tools/stress_streams.py), nor on which npn the fill score prefers for this call's own rows
+    const int factor = (p.split_tile_factor & 0xff) > 0 ? (p.split_tile_factor & 0xff) : 1;
+    const long tiles = (((long)p.M * factor + 255) / 256) * (p.N / 96);
     if (tiles < (long)(-force)) return 0;                                 // small grids: the 128x128 kernel (+ split-K) fills the chip better
   }
   return best;
