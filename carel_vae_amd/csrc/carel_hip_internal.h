@@ -43,6 +43,7 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        uint32_t drop_idx_offset, float drop_p, const void* drop_row_map, void* dh_f32, void* dy_bf16, void* partials,
                        hipStream_t stream);
 int layernorm_bwd_reduce(const void* partials, int64_t rows, void* dgamma, void* dbeta, void* dbias, hipStream_t stream);
+int layernorm_bwd_blocks_max(int64_t rows);    // the most partial blocks carel_layernorm_bwd_blocks(r) returns for any r <= rows (scratch sizing)
 // the same row kernel with its input gradient rows taken as  sum_z slabs[z][row] (+ resid[row])  -- the deferred epilogue (CAREL_EPI_ADD_F32) of a
 // split-K data-gradient GEMM, with that epilogue's order of additions (bit-identical to slab epilogue + layernorm_bwd_rows)
 int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, const void* h, const void* stats, const void* gamma, int64_t rows,

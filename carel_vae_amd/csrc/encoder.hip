@@ -92,7 +92,7 @@ ScratchLayout scratch_layout(long B, long S) {
   }
   s.o_slabs = o; o += al(slab); s.slab_bytes = al(slab);      // weight-gradient slabs (side stream when overlapping)
   s.o_ws = o; o += al(slab); s.ws_bytes = al(slab);      // split-K workspace of the forward / data-gradient GEMMs (main stream)
-  size_t part = (size_t)carel_layernorm_bwd_blocks((long)T) * 4 * EH * 4;
+  size_t part = (size_t)layernorm_bwd_blocks_max((long)T) * 4 * EH * 4;       // (a packed batch of fewer rows may use MORE, smaller blocks: ln.hip)
   const size_t cs = ((T + 255) / 256) * EI * 4;
   part = part > cs ? part : cs;
   for (int par = 0; par < 2; ++par) {

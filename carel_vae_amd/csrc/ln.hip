@@ -206,7 +206,7 @@ __device__ __forceinline__ void write_partials(float* lds /*[4][H]*/, const Row&
 // sum_z slabs[z][row] (+ resid[row]), added in the order slab_epilogue_kernel<CAREL_EPI_ADD_F32> uses -- so that the f32 rows never make a
 // round trip through memory and one launch per sub-layer goes away (at ~1.8 k rows every launch is ~6-10 us of mostly latency).
 struct LnSlabSrc { int splits; long plane; const float* resid; };
-template <bool SLAB>
+template <bool SLAB, int RPW = 4>        // RPW rows per wave, 4 * RPW rows per workgroup (ln_bwd_rpw: fewer at packed row counts)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy_out, const float* __restrict__ h,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      long rows, Dropout drop, const int* __restrict__ row_map,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int i = 0; i < NV; ++i) accG.v[i] = accB.v[i] = accBias.v[i] = float4{0.f, 0.f, 0.f, 0.f};
   // all of this wave's rows are requested up front: with one row in flight per wave (2 waves per SIMD at 8192 rows) the kernel ran at the
   // latency of its load -> reduce -> store chain (17.4 us for 88 MB); same arithmetic, same summation order
-  constexpr int RPW = LNB_ROWS / 4;
+  constexpr int WG_ROWS = 4 * RPW;
   Row DYr[RPW], XHr[RPW];
   float mr[RPW], rr[RPW];
   int dr[RPW];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   const int* rm = row_map ? row_map : (const int*)stats;
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const long row = (long)blockIdx.x * LNB_ROWS + wave + 4 * k;
+    const long row = (long)blockIdx.x * WG_ROWS + wave + 4 * k;
     const long lrow = row < rows ? row : rows - 1;
     DYr[k] = load_row(dy_out + lrow * H, lane);
     if constexpr (SLAB) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const long row = (long)blockIdx.x * LNB_ROWS + wave + 4 * k;
+    const long row = (long)blockIdx.x * WG_ROWS + wave + 4 * k;
     if (row >= rows) break;
     Row DY = DYr[k];
     Row XH = XHr[k];
@@ -659,7 +659,19 @@ extern "C" int carel_layernorm_fwd(const void* h, const void* gamma, const void*
   return check_launch("ln_fwd_kernel");
 }
 
-extern "C" int carel_layernorm_bwd_blocks(int64_t rows) { return (int)((rows + LNB_ROWS - 1) / LNB_ROWS); }
+// Rows per wave of the LayerNorm backward row kernel: 4 (16 rows per workgroup) fills the chip at the dense 8192 rows (512 workgroups); packed ECPE batches
+// (~1.7 k rows) gave 104 workgroups, each wave walking four rows' loads -> reductions -> stores in turn: one row per wave there (416 workgroups,
+// `ln_bwd_kernel<true>` 15 -> 9-10 us), two up to 4096 rows.  More blocks = more partial rows for the reduction behind it (at most 512 up to 8192 rows).
+static int ln_bwd_rpw(int64_t rows) { return rows <= 2048 ? 1 : (rows <= 4096 ? 2 : 4); }
+extern "C" int carel_layernorm_bwd_blocks(int64_t rows) { const int wg = 4 * ln_bwd_rpw(rows); return (int)((rows + wg - 1) / wg); }
+namespace carel {
+// the most blocks ANY row count <= rows can need (scratch sizing: a packed batch has fewer rows than batch x seq_len, and may need more blocks)
+int layernorm_bwd_blocks_max(int64_t rows) {
+  if (rows <= 2048) return (int)((rows + 3) / 4);
+  const int64_t big = (rows + 15) / 16;
+  return (int)(big > 512 ? big : 512);
+}
+}
 
 // partials: f32 scratch of carel_layernorm_bwd_blocks(rows) * 3 * hidden floats
 extern "C" int carel_layernorm_bwd(const void* dy, const void* h, const void* stats, const void* gamma, int64_t rows,
@@ -678,9 +690,12 @@ int layernorm_bwd_rows(const void* dy, const void* h, const void* stats, const v
                        hipStream_t stream) {
   if (!dy || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "carel_layernorm_bwd: bad arguments");
   const int nblk = carel_layernorm_bwd_blocks(rows);
-  hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats,
-                     (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
-                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, LnSlabSrc{1, 0, nullptr});
+  const Dropout drop = make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset);
+  const LnSlabSrc src{1, 0, nullptr};
+#define CAREL_LNB(R) hipLaunchKernelGGL((ln_bwd_kernel<false, R>), dim3(nblk), dim3(256), 0, stream, (const float*)dy, (const float*)h, (const float*)stats, \
+                     (const float*)gamma, (long)rows, drop, (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, src)
+  switch (ln_bwd_rpw(rows)) { case 1: CAREL_LNB(1); break; case 2: CAREL_LNB(2); break; default: CAREL_LNB(4); }
+#undef CAREL_LNB
   return check_launch("ln_bwd_kernel");
 }
 int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, const void* h, const void* stats, const void* gamma, int64_t rows,
@@ -688,9 +703,12 @@ int layernorm_bwd_rows_slabs(const void* slabs, int splits, const void* resid, c
                              void* dy_bf16, void* partials, hipStream_t stream) {
   if (!slabs || splits < 2 || !h || !stats || !gamma || !partials || rows <= 0) return set_error(CAREL_ERR_ARG, "layernorm_bwd_rows_slabs: bad arguments");
   const int nblk = carel_layernorm_bwd_blocks(rows);
-  hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, (const float*)slabs, (const float*)h, (const float*)stats,
-                     (const float*)gamma, (long)rows, make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset),
-                     (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, LnSlabSrc{splits, (long)rows * H, (const float*)resid});
+  const Dropout drop = make_dropout(drop_seed, drop_site, drop_p, drop_idx_offset);
+  const LnSlabSrc src{splits, (long)rows * H, (const float*)resid};
+#define CAREL_LNB(R) hipLaunchKernelGGL((ln_bwd_kernel<true, R>), dim3(nblk), dim3(256), 0, stream, (const float*)slabs, (const float*)h, (const float*)stats, \
+                     (const float*)gamma, (long)rows, drop, (const int*)drop_row_map, (float*)dh_f32, (bf16_t*)dy_bf16, (float*)partials, src)
+  switch (ln_bwd_rpw(rows)) { case 1: CAREL_LNB(1); break; case 2: CAREL_LNB(2); break; default: CAREL_LNB(4); }
+#undef CAREL_LNB
   return check_launch("ln_bwd_kernel<slabs>");
 }
 int layernorm_fwd_slabs(const void* slabs, int splits, const void* bias, const void* resid, const void* resid_stats, const void* resid_gamma,
