@@ -538,7 +538,7 @@ extern "C" int carel_en_tail_latents(const carel_en_tail_args* a, void* stream_)
   int rc = en_check(a, "carel_en_tail_latents");
   if (rc) return rc;
   const int B = a->batch, D = a->ec_dim, Cd = a->con_dim, LW = 2 * Cd + 4 * D;
-  auto groups = [&](int ncols) { int g = (1024 + ncols - 1) / ncols; const int mx = (B + 3) / 4; g = g > mx ? mx : g; return g < 1 ? 1 : g; };
+  auto groups = [&](int ncols) { int g = (4096 + ncols - 1) / ncols; const int mx = (B + 3) / 4; g = g > mx ? mx : g; return g < 1 ? 1 : g; };
   PtrSet4 pp; for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; }
   pp.w[0] = (const float*)a->pooler_w; pp.b[0] = (const float*)a->pooler_b;
   hipLaunchKernelGGL(rowvec_linear_kernel<1>, dim3(TH / 4, groups(TH)), dim3(256), 0, stream, (const float*)a->x_last_f32, (long)a->seq_len * TH,

@@ -66,10 +66,11 @@ static __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* _
 #pragma unroll
   for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
   float sb = 0.f;
-  for (int b = 0; b < B; b += 4) {          // loads of four samples in flight; accumulation order stays b = 0, 1, 2, ...
-    float g[4]; float4 xv[4][TNV];
+  constexpr int U = 8;                      // samples in flight per trip (round 4: 4 -> 8; every trip is one round trip to memory: 64 samples were 16 of them)
+  for (int b = 0; b < B; b += U) {          // accumulation order stays b = 0, 1, 2, ...
+    float g[U]; float4 xv[U][TNV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int bb = min(b + u, B - 1);
       g[u] = (b + u < B) ? dY[(long)bb * dy_stride + n] : 0.f;
       const float* x = row_idx ? X + (long)row_idx[bb] * TH : X + (long)bb * x_stride;
@@ -77,7 +78,7 @@ static __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* _
       for (int i = 0; i < TNV; ++i) xv[u][i] = *(const float4*)(x + (i * 64 + lane) * 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       sb += g[u];
 #pragma unroll
       for (int i = 0; i < TNV; ++i) {
@@ -95,7 +96,7 @@ static __global__ __launch_bounds__(256) void rowvec_wgrad_kernel(const float* _
 // part[c][b][k] = sum_{n in chunk c} dY[b][n] * W_n[k]  (one wave per (sample b, chunk of 64 outputs n));
 // MODE 1: dY is first multiplied by (1 - y^2) of the tanh output y (pooler) and the product is also written
 // to dpre (for the pooler wgrad).  The chunks are summed by sum_parts_kernel (fixed order).
-constexpr int DG_CHUNK = 64;
+constexpr int DG_CHUNK = 32;          // (round 4: 64 -> 32 outputs per wave, eight weight rows in flight: four trips to memory per wave instead of 16 -- pooler data gradient 28 -> ~9 us)
 template <int MODE>
 __global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restrict__ dY, long dy_stride, int B, int N, int seg,
                                                            PtrSet4 ps, const float* __restrict__ y, float* __restrict__ dpre,
@@ -107,10 +108,11 @@ __global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < TNV; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
   const int n0 = blockIdx.y * DG_CHUNK, n1 = min(N, n0 + DG_CHUNK);
-  for (int nb = n0; nb < n1; nb += 4) {     // four weight rows in flight; accumulation order stays n = n0, n0+1, ...
-    float g[4]; float4 wv[4][TNV];
+  constexpr int U = 8;
+  for (int nb = n0; nb < n1; nb += U) {     // eight weight rows in flight; accumulation order stays n = n0, n0+1, ...
+    float g[U]; float4 wv[U][TNV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int n = min(nb + u, n1 - 1);
       float gg = (nb + u < n1) ? dY[(long)b * dy_stride + n] : 0.f;
       if (MODE == 1) {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void rowvec_dgrad_kernel(const float* __restri
       for (int i = 0; i < TNV; ++i) wv[u][i] = *(const float4*)(w + (i * 64 + lane) * 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < TNV; ++i) {
         acc[i].x = fmaf(g[u], wv[u][i].x, acc[i].x); acc[i].y = fmaf(g[u], wv[u][i].y, acc[i].y);

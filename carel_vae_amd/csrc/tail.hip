@@ -689,7 +689,7 @@ extern "C" int carel_tail_latents(const carel_tail_args* a, void* stream_) {
   if (rc) return rc;
   PtrSet4 pp; for (int i = 0; i < 4; ++i) { pp.w[i] = nullptr; pp.b[i] = nullptr; }
   pp.w[0] = (const float*)a->pooler_w; pp.b[0] = (const float*)a->pooler_b;
-  auto sample_groups = [&](int ncols) { int g = (1024 + ncols - 1) / ncols; const int mx = (a->batch + 3) / 4; g = g > mx ? mx : g; return g < 1 ? 1 : g; };
+  auto sample_groups = [&](int ncols) { int g = (4096 + ncols - 1) / ncols;      /* ~4 k waves: each walks its samples four at a time, one round trip to memory per trip */ const int mx = (a->batch + 3) / 4; g = g > mx ? mx : g; return g < 1 ? 1 : g; };
   hipLaunchKernelGGL(rowvec_linear_kernel<1>, dim3(TH / 4, sample_groups(TH)), dim3(256), 0, stream, (const float*)a->x_last_f32,
                      (long)a->seq_len * TH, (const int*)a->cls_rows, a->batch, TH, TH, pp, (float*)a->pooled, (long)TH);
   PtrSet4 hp; for (int i = 0; i < 4; ++i) { hp.w[i] = (const float*)a->head_w[i]; hp.b[i] = (const float*)a->head_b[i]; }

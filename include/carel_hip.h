@@ -211,6 +211,9 @@ int carel_embed_ln_bwd(const carel_embed_args* args, const void* dx0_f32, void* 
  * ---------------------------------------------------------------------------------------------- */
 int carel_layernorm_fwd(const void* h_f32, const void* gamma, const void* beta, float eps, int64_t rows, int32_t hidden,
                         void* x_f32, void* x_bf16, void* stats, void* stream);
+/* number of partial blocks the backward kernel writes for EXACTLY this row count (4, 8 or 16 rows per block: fewer rows per block at small
+ * row counts, so the value is NOT monotonic in `rows` -- 2048 rows: 512 blocks, 2064 rows: 258; size a buffer that is reused for several row
+ * counts with the largest value over them; never more than max(512, ceil(rows / 16)) for any smaller count) */
 int carel_layernorm_bwd_blocks(int64_t rows);
 /* partials: f32 scratch of carel_layernorm_bwd_blocks(rows) * 3 * 768 floats */
 int carel_layernorm_bwd(const void* dy_f32, const void* h_f32, const void* stats, const void* gamma, int64_t rows,

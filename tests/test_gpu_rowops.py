@@ -23,9 +23,11 @@ def keep_mask(seed, site, n, p, off=0):
     return torch.from_numpy(O.dropout_keep(seed, site, idx, p).astype(np.float64) / (1 - p)).cuda()
 
 
-def test_layernorm_fwd_bwd():
+@pytest.mark.parametrize("rows", [1000, 2049, 3000, 4100])
+def test_layernorm_fwd_bwd(rows):
+    """rows not a multiple of the block row counts; the backward kernel runs 1 / 2 / 4 rows per wave (<= 2048 / <= 4096 / more rows)"""
     lib = L.load()
-    rows = 1000                       # not a multiple of the block row counts
+    assert lib.carel_layernorm_bwd_blocks(rows) == {1000: 250, 2049: 257, 3000: 375, 4100: 257}[rows]
     h, g, b = _rand((rows, H), 2.0, 1) + 0.3, 1 + _rand((H,), 0.1, 2), _rand((H,), 0.1, 3)
     xf = torch.empty((rows, H), device="cuda")
     xb = torch.empty((rows, H), device="cuda", dtype=torch.bfloat16)
