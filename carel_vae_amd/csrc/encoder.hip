@@ -4,6 +4,7 @@
 // `self.encoder(input_ids, attention_mask, token_type_ids)` (drl_classifier_ec_mmd_final_mul.py:202-206,
 // transformers BertModel.forward) and the encoder part of `loss.backward()` (:841).
 // Nothing is allocated here; every call only enqueues kernels on the caller's stream.
+#include <cstdlib>
 #include "carel_hip_internal.h"
 
 using namespace carel;
@@ -144,7 +145,11 @@ SideStream* side_stream() {
   if (!made[dev]) {
     SideStream& s = per_dev[dev];
     int lo = 0, hi = 0;
-    s.ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+    s.ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+#ifdef CAREL_EXPERIMENTS      // A/B of the side streams' priority (experiments build only): CAREL_SIDE_STREAM_PRIORITY = low (default) | normal | high
+    if (const char* e = getenv("CAREL_SIDE_STREAM_PRIORITY")) { if (e[0] == 'n') lo = 0; else if (e[0] == 'h') lo = hi; }
+#endif
+    s.ok = s.ok &&
            hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) == hipSuccess &&     // lo = lowest priority
            hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, lo) == hipSuccess &&
            hipStreamCreateWithFlags(&s.peer, hipStreamNonBlocking) == hipSuccess;               // default priority: the second forward chain
