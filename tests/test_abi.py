@@ -78,6 +78,23 @@ def test_argument_validation_without_a_gpu(lib_path):
     assert lib.carel_tail_workspace_floats(64, 24, 23771) > 0
 
 
+def test_layernorm_backward_block_counts_and_the_scratch_that_holds_them(lib_path):
+    """carel_layernorm_bwd_blocks is a pure host function: 4 / 8 / 16 rows per block (<= 2048 / <= 4096 / more rows), NOT monotonic in the row
+    count; include/carel_hip.h promises that no smaller count needs more than max(512, ceil(rows / 16)) blocks once rows > 2048 -- what the
+    encoder's scratch (sized for batch x seq_len rows, used by packed batches of fewer rows) relies on."""
+    from carel_vae_amd import _lib
+    lib = _lib.load()
+    f = lib.carel_layernorm_bwd_blocks
+    assert [f(r) for r in (1, 4, 5, 2048, 2049, 4096, 4097, 8192)] == [1, 1, 2, 512, 257, 512, 257, 512]
+    worst = 0
+    for rows in range(1, 9001, 7):
+        worst = max(worst, f(rows))
+        bound = (rows + 3) // 4 if rows <= 2048 else max(512, (rows + 15) // 16)
+        assert worst <= bound, (rows, worst, bound)
+    # the scratch block grows with the bound: a packed batch inside a (64, 128) scratch never overruns its partial buffers
+    assert lib.carel_encoder_scratch_bytes(36, 128) >= lib.carel_encoder_scratch_bytes(16, 128)
+
+
 def test_product_path_refuses_cpu_tensors(lib_path):
     """No CPU fallback: the module raises instead of computing when tensors are not on the GPU."""
     import torch
