@@ -464,12 +464,34 @@ static bool big_auto(const GemmParams& p, int splits) {
   return tiles >= 192 && (p.N >= 2304 || splits > 1);
 }
 
+// Small-M kernel (gemm_sm.hip): takes the row-major-A GEMMs of packed batches whose 128 x 128 tile grid is one round of at most 256 workgroups.
+// Returns 0 (not this kernel) or the number of K slices (1 = single pass; > 1: fp32 slabs + slab epilogue, K >= 1536 only -- a K = 768 partition that
+// depended on the row count would make a sample's bits depend on the shard size).  Tuning hook 340 + m (experiments build): 0 off, 2 on.
+CAREL_TUNABLE(int, g_sm_mode, 0);
+static int sm_plan(const GemmParams& p, int epi, bool at) {
+#ifndef CAREL_EXPERIMENTS
+  return 0;                                  // measured, not adopted: the kernel exists in the experiments build only
+#endif
+  if (at || g_sm_mode != 2 || g_gemm_variant != 0 || epi == EPI_SLAB_F32) return 0;
+  if (p.M % 128 || p.N % 128 || p.K % 64 || p.M > 4096 || p.M <= 128 || p.ldc != p.N) return 0;
+  const int factor = (p.split_tile_factor & 0xff) > 0 ? (p.split_tile_factor & 0xff) : 1;
+  const long tiles = (long)(p.M / 128) * (p.N / 128) * factor;
+  if (tiles > 256) return 0;
+  int s = 1;
+  if (p.splitk_ws && p.K >= 1536) {
+    for (int c = 4; c >= 2; --c)
+      if (tiles * c <= 256 && p.K % (64 * c) == 0 && p.K / c >= 512 && (size_t)c * p.M * p.N * 4 <= p.splitk_ws_bytes) { s = c; break; }
+  }
+  return s;
+}
+
 static thread_local int tl_split_plan = 1;      // result of the last GEMM_EX_PLAN_ONLY pass (gemm_bf16_split_plan)
 template <bool AT, bool BT, int EPI>
 static int launch(const GemmParams& p, int splits, hipStream_t s) {
   const bool plan_only = (p.split_tile_factor & GEMM_EX_PLAN_ONLY) != 0, defer = (p.split_tile_factor & GEMM_EX_DEFER_EPILOGUE) != 0;
   if (plan_only) {          // the decisions below without a launch: does this call take the internal split-K path, and with how many slabs?
     tl_split_plan = 1;
+    if (const int sms = sm_plan(p, EPI, AT)) { tl_split_plan = sms; return CAREL_OK; }
     if (!AT && g_gemm_variant == 0) {
       const bool only_pp = !((p.M % 128 == 0 && p.N % 128 == 0) || (p.M % 256 == 0 && p.N % 192 == 0));
       if (resid_split(p, EPI) > 1) { tl_split_plan = resid_split(p, EPI); return CAREL_OK; }
@@ -480,6 +502,21 @@ static int launch(const GemmParams& p, int splits, hipStream_t s) {
     }
     return CAREL_OK;
   }
+#ifdef CAREL_EXPERIMENTS
+  if (const int sms = sm_plan(p, EPI, AT)) {
+    if (sms == 1) {
+      if (defer) return set_error(CAREL_ERR_ARG, "carel_gemm_bf16: internal: epilogue deferred for a GEMM that does not split (plan / launch disagree)");
+      return gemm_sm_launch(p, BT, EPI, 1, s);
+    }
+    GemmParams q = p;
+    q.K = p.K / sms; q.outf = p.splitk_ws; q.ldc = p.N; q.colsum_part = nullptr;
+    const int rc = gemm_sm_launch(q, BT, EPI_SLAB_F32, sms, s);
+    if (rc || defer) return rc;
+    const long chunks = (long)p.M * (p.N >> 3);
+    hipLaunchKernelGGL((slab_epilogue_kernel<EPI>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, p, (const float*)p.splitk_ws, sms);
+    return check_launch("gemm_sm_kernel split-K + slab_epilogue_kernel");
+  }
+#endif
   if (!AT && g_gemm_variant != 1 && g_gemm_variant != 2 && !(g_gemm_variant >= 11 && g_gemm_variant <= 19)) {
     // row-major-A forms: the 256 x 96n ping-pong kernel (gemm_pp.hip) when the grid fills the chip (variant 3: always)
 #ifdef CAREL_EXPERIMENTS
@@ -761,6 +798,7 @@ extern "C" int carel_gemm_set_variant(int32_t v) {
   if (v == 24) { g_xcd_n = 0; return CAREL_OK; }                            // 24: XCD row bands walked M-fastest
   if (v == 30 || v == 31) { g_big_auto = v - 30; return CAREL_OK; }
   if (v >= 50 && v <= 59) { g_pp_min_tiles = (v - 50) * 32; return CAREL_OK; }
+  if (v >= 340 && v <= 342) { g_sm_mode = v - 340; return CAREL_OK; }              // small-M kernel (gemm_sm.hip) off / - / takes packed-batch GEMMs of <= 256 tiles
   if (v >= 330 && v <= 333) { g_resid_split = v - 330; return CAREL_OK; }
   if (v >= 40 && v <= 49) { g_pp_min_tiles_k768 = (v - 40) * 32; return CAREL_OK; }
   if (v >= 70 && v <= 73) { gemm_pp_force_npn(v - 70); return CAREL_OK; }

@@ -390,6 +390,8 @@ int gemm_pp_launch_tn(const GemmParams& p, int npn, int splits, hipStream_t s);
 int gemm_pp_launch_tn_dbg(const GemmParams& p, int npn, int splits, int dbg, hipStream_t s);
 #endif
 int gemm_pp_launch_slab(const GemmParams& p, bool bt, int npn, int splits, hipStream_t s);
+// gemm_sm.hip: 128 x 128 tiles, eight waves, four-stage LDS-DMA ring -- the row-major-A forms at packed row counts (one round of <= 256 workgroups)
+int gemm_sm_launch(const GemmParams& p, bool bt, int epi, int splits, hipStream_t s);
 // pair split-K (two workgroups per 256 x 192 tile, each half of K; gemm_pp.hip): 1 if this problem should run that way
 int gemm_pp_pick_pair(const GemmParams& p, bool bt, int epi);
 int gemm_pp_launch_pair(const GemmParams& p, bool bt, int epi, hipStream_t s);

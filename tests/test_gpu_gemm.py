@@ -703,3 +703,68 @@ def test_residual_recomputed_from_pre_layernorm_rows_same_bits(M, K, hook):
     x64 = (h64 - h64.mean(1, keepdim=True)) / torch.sqrt(h64.var(1, unbiased=False, keepdim=True) + 1e-12) * gamma.double() + beta.double()
     ref = A.double() @ B.double().t() + bias.double() + x64
     assert float((out.double() - ref).abs().max()) < 2e-2
+
+
+class _small_m:
+    """the small-M kernel (gemm_sm.hip) on (hook 342) / off (340) for the duration of the block"""
+    def __init__(self, on): self.on = on
+    def __enter__(self): L.check(L.load().carel_gemm_set_variant(342 if self.on else 340))
+    def __exit__(self, *a): L.check(L.load().carel_gemm_set_variant(340))
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("M,N,K", [(1664, 768, 768), (1664, 2304, 768), (1792, 768, 3072), (2048, 768, 2304), (256, 1536, 768), (1664, 1536, 192)])
+def test_small_m_kernel_bitwise_equals_the_128_tile_kernel_every_epilogue(M, N, K):
+    """gemm_sm.hip (128 x 128 tiles, eight waves, four-stage LDS-DMA ring, counted vmcnt: packed ECPE row counts) against the 128x128 kernel of
+    gemm.hip (variant 1) on the same calls: the K loop adds in the same order, so every output is bit-identical -- single pass (no workspace).
+    Covers K tiles fewer than the ring's stages (K = 192: three tiles) and a two-row-tile grid."""
+    A, W, b = _rand((M, K), 1, 41).bfloat16(), _rand((N, K), 0.05, 42).bfloat16(), _rand((N,), 0.1, 43)
+    Wn = _rand((K, N), 0.05, 44).bfloat16()
+    r, u = _rand((M, N), 1, 45), _rand((M, N), 1.5, 46).bfloat16()
+    st, gm, bt = torch.stack([_rand((M,), 0.2, 47), 1 + _rand((M,), 0.1, 48).abs()], 1).contiguous(), 1 + _rand((N,), 0.1, 49), _rand((N,), 0.1, 50)
+    res = {}
+    for on in (False, True):
+        with _variant(1 if not on else 0), _small_m(on):
+            o = {}
+            o["qkv"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_BF16, M, N, K, out_bf16=o["qkv"], bias=b)
+            o["u"], o["g"] = torch.empty_like(o["qkv"]), torch.empty_like(o["qkv"])
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU, M, N, K, out_bf16=o["u"], out2_bf16=o["g"], bias=b)
+            o["gp"], o["g2"] = torch.empty_like(o["qkv"]), torch.empty_like(o["qkv"])
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_GELU_DG, M, N, K, out_bf16=o["gp"], out2_bf16=o["g2"], bias=b)
+            o["h"] = torch.empty((M, N), device="cuda")
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=o["h"], bias=b, resid=r, drop=(9, 5, 3 * N, 0.1))
+            o["hl"] = torch.empty((M, N), device="cuda")
+            gemm(A, W, L.GEMM_NT, L.EPI_BIAS_DROP_RESID, M, N, K, out_f32=o["hl"], bias=b, resid=r, drop=(9, 5, 3 * N, 0.1), resid_ln=(st, gm, bt))
+            o["dx"] = torch.empty((M, N), device="cuda")
+            gemm(A, Wn, L.GEMM_NN, L.EPI_ADD_F32, M, N, K, out_f32=o["dx"], resid=r)
+            o["dc"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+            gemm(A, Wn, L.GEMM_NN, L.EPI_BIAS_BF16, M, N, K, out_bf16=o["dc"])
+            o["du"], o["cs"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M // 128, N), device="cuda")
+            gemm(A, Wn, L.GEMM_NN, L.EPI_DGELU_BF16, M, N, K, out_bf16=o["du"], aux=u, colsum_part=o["cs"])
+            o["dm"], o["cs_m"] = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M // 128, N), device="cuda")
+            gemm(A, Wn, L.GEMM_NN, L.EPI_MUL_BF16, M, N, K, out_bf16=o["dm"], aux=u, colsum_part=o["cs_m"])
+            res[on] = o
+    for k in res[False]:
+        if k in ("cs", "cs_m"):       # column sums: same addends, different summation tree (64 row slots instead of 32)
+            assert rel_err(res[True][k], res[False][k]) < 1e-5
+        else:
+            assert torch.equal(res[True][k], res[False][k]), (k, float((res[True][k].float() - res[False][k].float()).abs().max()))
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("form,M,N,K", [(L.GEMM_NT, 1664, 768, 3072), (L.GEMM_NN, 1664, 768, 2304), (L.GEMM_NN, 1920, 768, 3072)])
+def test_small_m_kernel_split_k_exact_integers(form, M, N, K):
+    """with a workspace the small-M kernel splits K >= 1536 into up to four slabs (one round of <= 256 workgroups) + slab epilogue: exact on
+    small-integer data, and the repeat launch is bit-identical"""
+    A = _ints((M, K), 7)
+    B = _ints((N, K), 8) if form == L.GEMM_NT else _ints((K, N), 8)
+    ref = A.double() @ (B.double().t() if form == L.GEMM_NT else B.double())
+    ws = torch.full((16 << 20,), float("nan"), device="cuda")
+    out = torch.empty((M, N), device="cuda")
+    with _small_m(True):
+        gemm(A, B, form, L.EPI_ADD_F32, M, N, K, out_f32=out, splitk_ws=ws)
+        assert torch.equal(out.double(), ref), float((out.double() - ref).abs().max())
+        out2 = torch.empty_like(out)
+        gemm(A, B, form, L.EPI_ADD_F32, M, N, K, out_f32=out2, splitk_ws=ws)
+        assert torch.equal(out, out2)
