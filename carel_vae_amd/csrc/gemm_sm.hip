@@ -13,6 +13,7 @@
 //   * the K loop adds in the same order as the other two kernels (k ascending, 32 at a time): the same bits;
 //   * epilogue through the LDS in two 64-column halves and the shared epi_store8 (every fused epilogue, split-K slabs included).
 #ifdef CAREL_EXPERIMENTS
+#include <type_traits>
 #include "gemm_epilogue.h"
 #include "reduce_device.h"
 
@@ -75,32 +76,58 @@ __global__ __launch_bounds__(512) void gemm_sm_kernel(GemmParams p) {
   };
 
   const int nk = p.K >> 6;
-#pragma unroll
-  for (int t = 0; t < SM_NST - 1; ++t)
-    if (t < nk) stage(t);
-  for (int kt = 0; kt < nk; ++kt) {
-    // K tile kt has landed once at most min(NST - 2, tiles issued after it) x 4 of this wave's copies are outstanding (vmcnt retires in order)
-    const int rem = nk - 1 - kt;
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                         // every wave's share of tile kt is in the LDS; every wave has finished reading tile kt - 1
-    if (kt + SM_NST - 1 < nk) stage(kt + SM_NST - 1);      // ... whose stage the new copies overwrite
+  // Software pipeline over K tiles: the fragments of tile kt + 1 are requested from the LDS BEFORE the MFMAs of tile kt run (two fragment sets in
+  // registers, the loop unrolled by two so that their indices are static): the LDS reads of one tile run under the matrix work of the previous one
+  // inside every wave -- behind one barrier per K tile both waves of a SIMD would otherwise read together and then multiply together.
+  bf16x8 fa[2][2][2], fb[2][2][4];          // [set][k32 step][block]
+  auto read_frags = [&](auto SET, int kt) {
+    constexpr int st = decltype(SET)::value;
     const char* ta = smem + (kt & (SM_NST - 1)) * SM_STAGE;
     const char* tb = ta + 16384;
 #pragma unroll
-    for (int ks = 0; ks < 64; ks += 32) {
-      bf16x8 fa[2], fb[4];
+    for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag16_row(ta, wr * 32 + i * 16, ks);
+      for (int i = 0; i < 2; ++i) fa[st][k2][i] = frag16_row(ta, wr * 32 + i * 16, k2 * 32);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = BT ? frag16_col(tb, wc * 64 + j * 16, ks) : frag16_row(tb, wc * 64 + j * 16, ks);
+      for (int jj = 0; jj < 4; ++jj) fb[st][k2][jj] = BT ? frag16_col(tb, wc * 64 + jj * 16, k2 * 32) : frag16_row(tb, wc * 64 + jj * 16, k2 * 32);
+    }
+  };
+  auto mfmas = [&](auto SET) {
+    constexpr int st = decltype(SET)::value;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);      // swapped: each lane's 4 registers are 4 consecutive columns of one row
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma16(fb[st][k2][jj], fa[st][k2][i], acc[i][jj]);      // swapped: each lane's 4 registers are 4 consecutive columns of one row
+  };
+  // one step: tile kt's fragments are in set SET; make tile kt + 1 ready in the other set, then multiply tile kt
+  auto step = [&](auto SET, int kt) {
+    constexpr int st = decltype(SET)::value;
+    if (kt + 1 < nk) {
+      // tile kt + 1 has landed once at most the copies of the ONE later tile in flight (kt + 2) are outstanding (vmcnt retires in order)
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                       // every wave's share of tile kt + 1 is in the LDS; every wave has its fragments of tile kt - 1 consumed
+      if (kt + SM_NST - 1 < nk) stage(kt + SM_NST - 1);    // ... so that tile's stage may be overwritten (stage (kt - 1) % 4)
+      read_frags(std::integral_constant<int, 1 - st>{}, kt + 1);
     }
+    mfmas(SET);
+  };
+#pragma unroll
+  for (int t = 0; t < SM_NST - 1; ++t)
+    if (t < nk) stage(t);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  read_frags(std::integral_constant<int, 0>{}, 0);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    step(std::integral_constant<int, 1>{}, kt + 1);
   }
+  if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
 
   // ------------------------------------------------------------------ epilogue (gemm_kernel's, for 512 threads and 32-row wave tiles)
   float* ct = (float*)smem;                 // [128][CT_LD] fp32
