@@ -248,6 +248,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto issue = [&](auto U, const char* ap, const char* bp, int d, int stg) {
     constexpr int u = decltype(U)::value;
     char* sb = smem + stg * STAGE;
+#ifdef CAREL_PP_HOT_TILE     // timing ablation (tagged build only, results wrong): every K tile re-reads the slice's FIRST tile -- L2-hot after the first touch
+    ap = a_ptr; bp = b_ptr; d = 0;
+#endif
     if constexpr (u < 2) {
       const char* g = ap + (long)d * a_step;
       __builtin_amdgcn_global_load_lds((const void*)(g + aoff[u][0]), (CAREL_LDS void*)(sb + adst[u][0]), 16, 0, 0);
