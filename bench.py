@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--gemm-variant", type=int, action="append", default=[],
                     help="A/B runs: tuning hook passed to carel_gemm_set_variant before the run (repeatable; switches the run to the EXPERIMENTS "
                          "library libcarel_hip_exp.so -- the product library has no hooks)")
+    ap.add_argument("--wire-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: format of the gradient buckets on the links (bf16 halves the all-reduce's bytes and time; DataParallel(wire_dtype=...), "
+                         "tests/test_gpu_dp2.py states its tolerance).  Default fp32: the single-GPU numerics")
     ap.add_argument("--no-overlap", action="store_true",
                     help="weight-gradient GEMMs on the main stream (serial kernels: the run to put under rocprofv3 --kernel-trace)")
     return ap.parse_args()
@@ -427,7 +430,7 @@ def main():
     dp = None
     if world > 1 or force_dp:
         from carel_vae_amd.dp import DataParallel
-        dp = DataParallel(model)
+        dp = DataParallel(model, wire_dtype=torch.bfloat16 if a.wire_dtype == "bf16" else None)
     # N > 1: each layer's Adam update starts as soon as that layer's gradient bucket has been all-reduced (dp.py), so the optimiser pass
     # hides behind the remaining backward kernels and collectives instead of trailing the last (embedding) bucket
     optim = torch.optim.Adam(model.get_params(), lr=opt.vae_lr) if a.torch_adam else M.FusedAdam(model, lr=opt.vae_lr, fuse_into_backward=(a.adam_in_backward if dp is not None else not a.adam_in_step) and not a.no_overlap)
@@ -680,6 +683,7 @@ def main():
                                   "vocab 21128, S=128 shape-%s, B=%d/GPU, bow V=23771, dropout on, random-init weights" % (a.shape, a.batch),
                       "input_path": "carel_vae_amd.data.PrefetchLoader(BatchLoader): one page-locked block + one async H2D per batch on a copy stream",
                       "global_batch": world * a.batch, "seq_len": 128, "parallelism": "dp%d" % world,
+                      "gradient_wire_dtype": (a.wire_dtype if dp is not None else None),
                       "attended_tokens_per_pair": sum(sum(l) for l in lengths) / (len(lengths) * a.batch),
                       "padding_skipped": bool(model.varlen and a.shape == "B"),
                       "optimizer": "torch.optim.Adam" if a.torch_adam else "fused HIP Adam",
